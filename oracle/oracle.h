@@ -1,0 +1,133 @@
+/*
+ * oracle.h -- CPU restatement of the reference's PHY DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so, and only as the
+ * checker / the reported CPU baseline.  The HIP library (srslte_amd/csrc) never links or calls it.
+ *
+ * Every function cites the reference file:line it restates (paths relative to /root/reference).
+ * Parity pinning:
+ *   - turbo / QPP / LDPC: pinned bit-exactly against the reference's own compiled sources
+ *     (oracle/_ref/libsrsran_ref.so, built by oracle/Makefile) and against the reference's golden
+ *     vectors (turbodecoder_test.h K=504 known answer; examplesBG1/BG2.dat) -- tests/test_oracle_*.py
+ *   - OFDM / DFT / PSS / SSS: the reference needs FFTW3, absent from this image -> unbuildable here.
+ *     The restatement is pinned by the reference's own acceptance criteria (ofdm_test.c:176 loop-back
+ *     RMS < 1e-4; sync_test.c:164 peak position) and a float64 direct DFT.  FFT values themselves are
+ *     parity-unpinned beyond 1e-4, exactly as in the reference (FFTW is an unpinned system library).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- LTE turbo code (TS 36.212 5.1.3) ---------------- */
+
+/* cbsegm.c:119-140 */
+int      orc_tc_cb_index(uint32_t long_cb); /* smallest table index with size >= long_cb, -1 if none */
+int      orc_tc_cb_size(uint32_t index);    /* -1 if out of range */
+/* tc_interl_lte.c:61-109 ; win = 1, 8, 16 or 32 */
+int      orc_qpp_gen(uint32_t long_cb, uint32_t win, uint16_t* forward, uint16_t* reverse);
+/* turbodecoder.c:381-393 (AVX2 host) */
+uint32_t orc_tdec_autoimp_subblocks(uint32_t long_cb);
+/* turbodecoder.c:410-424 (AVX2 host) */
+uint32_t orc_tdec_autoimp_subblocks_8bit(uint32_t long_cb);
+
+/* implementation selector, values follow srsran_tdec_impl_type_t (turbodecoder_impl.h:28-38) */
+enum { ORC_TDEC_AUTO = 0, ORC_TDEC_GENERIC = 1, ORC_TDEC_SSE_WINDOW = 3, ORC_TDEC_AVX_WINDOW = 5 };
+
+/* srsran_tdec_run_all (turbodecoder.c:536-549) for 16-bit LLRs.
+ *   input    : natural order [s0 p0 p0' s1 ...][12 tail]  (3K+12)  when sb_layout == 0
+ *              rm_turbo sub-block layout (3(K+32)+12)          when sb_layout == 1 (window impls only)
+ *   output   : K/8 bytes, MSB first
+ *   snap     : optional, nof_iterations*K int16: the SISO output vector (ext1 on even, ext2 on odd
+ *              n_iter) after every half iteration, in the decoder's internal lane layout
+ * returns 0, or -1 on invalid arguments */
+int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb,
+                     int impl, int sb_layout, int16_t* snap);
+
+/* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
+int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);
+
+/* ---------------- NR LDPC (TS 38.212 5.3.2) ---------------- */
+
+typedef struct {
+  int      bg;   /* 0 = BG1, 1 = BG2 */
+  uint16_t ls;   /* lifting size Z */
+  int      bgN, bgM, bgK;
+  int      nof_edges;
+  /* per layer (check row): first edge, number of edges */
+  uint16_t row_start[47];
+  /* per edge: variable node and shift (V mod Z) */
+  uint8_t  col[320];
+  uint16_t shift[320];
+} orc_ldpc_graph_t;
+
+/* base_graph.c:4467-4503 + base_graph.h:109-113; returns -1 for an invalid lifting size */
+int orc_ldpc_graph(orc_ldpc_graph_t* g, int bg, uint16_t ls);
+int orc_ldpc_ls_index(uint16_t ls); /* 0..7 or -1 */
+
+/* srsran_ldpc_decoder_decode_c (ldpc_decoder.c:44-104,657-685 with ldpc_dec_c.c), int8 layered min-sum.
+ *   llrs        : N-2Z ... at least cdwd_rm_length values (LLR > 0 <=> bit 0)
+ *   message     : liftK bytes, one bit per byte
+ *   crc_poly/crc_order : if crc_order > 0 the CRC (crc.c) is checked after each iteration for early
+ *                 stop: returns the iteration count, 0 if it never matched.  crc_order == 0: no CRC,
+ *                 returns max_nof_iter.
+ *   soft_out    : optional liftN int8 a-posteriori soft bits after the last executed iteration */
+int orc_ldpc_decode_c(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const int8_t* llrs,
+                      uint8_t* message, uint32_t cdwd_rm_length, uint32_t crc_poly, int crc_order,
+                      int8_t* soft_out);
+
+/* ldpc_enc_c.c / ldpc_encoder.c: systematic encoder, bit per byte, filler bits (value 254) allowed.
+ * output: N-2Z bits (cdwd_rm_length = full) */
+int orc_ldpc_encode(const orc_ldpc_graph_t* g, const uint8_t* message, uint8_t* codeword);
+
+/* crc.c:  bit-per-byte CRC as srsran_crc_checksum (no reversal) */
+uint32_t orc_crc_bits(uint32_t poly, int order, const uint8_t* bits, int len);
+
+/* ---------------- OFDM / DFT ---------------- */
+
+typedef struct {
+  uint32_t nof_prb;
+  uint32_t symbol_sz;        /* 0 -> orc_symbol_sz(nof_prb) (non-standard rates, phy_common.c:361-385) */
+  int      cp_ext;           /* 0 normal, 1 extended */
+  int      normalize;
+  float    freq_shift_f;
+  float    rx_window_offset;
+  int      keep_dc;
+} orc_ofdm_cfg_t;
+
+int  orc_symbol_sz(uint32_t nof_prb);            /* phy_common.c:361-385, default (non standard) rates */
+int  orc_symbol_sz_power2(uint32_t nof_prb);     /* phy_common.c:342-359 */
+int  orc_cp_len(uint32_t symbol_sz, int c);      /* SRSRAN_CP_LEN, phy_common.h:125 */
+/* srsran_ofdm_rx_sf (ofdm.c:453-466).  in: 15*N cf (interleaved re,im floats; NOT modified),
+ * out: nsymb*2*12*nof_prb cf.  Arithmetic in double, rounded to float at the end. */
+int  orc_ofdm_rx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out);
+/* srsran_ofdm_tx_sf (ofdm.c:562-576) */
+int  orc_ofdm_tx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out);
+/* srsran_dft_run_c (dft_fftw.c:297-354): forward (dir=0) / backward (dir=1), options mirror,dc,norm */
+void orc_dft_c(const float* in, float* out, int n, int backward, int mirror, int dc, int norm);
+/* fast float FFT used by the CPU-baseline timing leg (same math as orc_dft_c without options) */
+void orc_fft_f32(const float* in, float* out, int n, int backward);
+
+/* ---------------- PSS / SSS ---------------- */
+/* pss.c:341-368: 62 complex values */
+int  orc_pss_generate(float* signal, uint32_t N_id_2);
+/* gen_sss.c:55-163: two 62-float sequences for subframes 0 and 5 */
+int  orc_sss_generate(float* sf0, float* sf5, uint32_t cell_id);
+/* pss.c:31-62,446-534: correlate `frame_size` samples with the time-domain PSS replica of N_id_2,
+ * |.|^2, argmax.  corr_out (optional) receives frame_size+fft_size-1 floats.  Returns peak index,
+ * peak value and PSR (pss.c:408-437) */
+int  orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, uint32_t N_id_2,
+                  float* corr_out, float* peak_value, float* psr);
+/* find_sss.c:99-192 partial + sss.c:128-156; input points at the start of the SSS symbol (N samples) */
+int  orc_sss_m0m1_partial(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, uint32_t* m0,
+                          uint32_t* m1, int* n_id_1, int* sf_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,586 @@
+/*
+ * orc_turbo.c -- scalar restatement of the reference LTE turbo decoder (TEST INFRASTRUCTURE ONLY).
+ *
+ * Restates, lane by lane and with the exact integer semantics of the x86 instructions used there:
+ *   lib/src/phy/fec/turbo/turbodecoder.c:370-549        (dispatch, run_all, hard decision source)
+ *   lib/include/srsran/phy/fec/turbo/turbodecoder_iter.h:58-141 (half-iteration schedule)
+ *   lib/src/phy/fec/turbo/turbodecoder_gen.c:58-277      (scalar SISO, wrapping int16)
+ *   lib/include/srsran/phy/fec/turbo/turbodecoder_win.h:480-993 (windowed SISO: sse16 = 8 sub-blocks,
+ *                                                          avx16 = 16 sub-blocks, saturating int16)
+ *   lib/src/phy/fec/turbo/tc_interl_lte.c:61-109         (QPP interleaver + sub-block re-indexing)
+ *   lib/src/phy/fec/cbsegm.c:119-140                     (K table lookup)
+ *   lib/src/phy/fec/turbo/turbocoder.c:76-200            (bit encoder, used to make test vectors)
+ */
+#include "oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "../srslte_amd/csrc/tables/lte_qpp_table.h"
+
+#define WIN_OVERLAP 40 /* turbodecoder_win.h:54,141 */
+#define INF16 10000    /* turbodecoder_win.h:56, turbodecoder_gen.c:37 */
+
+/* ------------------------------------------------------------------ tables */
+
+int orc_tc_cb_index(uint32_t long_cb)
+{
+  int j = 0;
+  while (j < LTE_QPP_NOF_SIZES && lte_qpp_table[j][0] < long_cb) {
+    j++;
+  }
+  return (j == LTE_QPP_NOF_SIZES) ? -1 : j;
+}
+
+int orc_tc_cb_size(uint32_t index)
+{
+  return (index < LTE_QPP_NOF_SIZES) ? (int)lte_qpp_table[index][0] : -1;
+}
+
+int orc_qpp_gen(uint32_t K, uint32_t win, uint16_t* forward, uint16_t* reverse)
+{
+  int idx = orc_tc_cb_index(K);
+  if (idx < 0) {
+    return -1;
+  }
+  uint64_t f1 = lte_qpp_table[idx][1], f2 = lte_qpp_table[idx][2];
+  for (uint64_t i = 0; i < K; i++) {
+    uint64_t j = (f1 * i + f2 * i * i) % K;
+    forward[i] = (uint16_t)j;
+    reverse[j] = (uint16_t)i;
+  }
+  if (win != 1) {
+    /* tc_interl_lte.c:90-106: express both tables in the [step][sub-block] lane layout */
+    uint16_t* f = malloc(K * sizeof(uint16_t));
+    uint16_t* r = malloc(K * sizeof(uint16_t));
+    memcpy(f, forward, K * sizeof(uint16_t));
+    memcpy(r, reverse, K * sizeof(uint16_t));
+    uint32_t sb = K / win;
+    for (uint32_t i = 0; i < K; i++) {
+      uint32_t nat = (i % win) * sb + i / win; /* lane index -> natural position */
+      uint32_t a = f[nat], b = r[nat];
+      forward[i] = (uint16_t)((a % sb) * win + a / sb); /* natural -> lane index */
+      reverse[i] = (uint16_t)((b % sb) * win + b / sb);
+    }
+    free(f);
+    free(r);
+  }
+  return 0;
+}
+
+uint32_t orc_tdec_autoimp_subblocks(uint32_t K)
+{
+  if (!(K % 16) && K > 800) {
+    return 16;
+  } else if (!(K % 8) && K > 400) {
+    return 8;
+  }
+  return 0;
+}
+
+uint32_t orc_tdec_autoimp_subblocks_8bit(uint32_t K)
+{
+  if (!(K % 32) && K > 2048) {
+    return 32;
+  } else if (!(K % 16) && K > 800) {
+    return 16;
+  } else if (!(K % 8) && K > 400) {
+    return 8;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ int16 helpers */
+
+static inline int16_t adds16(int16_t a, int16_t b) /* _mm_adds_epi16 */
+{
+  int s = (int)a + (int)b;
+  return (int16_t)(s > 32767 ? 32767 : (s < -32768 ? -32768 : s));
+}
+static inline int16_t subs16(int16_t a, int16_t b) /* _mm_subs_epi16 */
+{
+  int s = (int)a - (int)b;
+  return (int16_t)(s > 32767 ? 32767 : (s < -32768 ? -32768 : s));
+}
+static inline int16_t wrap16(int v) /* C int16_t assignment */
+{
+  return (int16_t)(uint16_t)(unsigned)v;
+}
+static inline int16_t max16(int16_t a, int16_t b)
+{
+  return a > b ? a : b;
+}
+
+/* ------------------------------------------------------------------ windowed SISO (int16) */
+
+/* turbodecoder_win.h:480-498, normalize_period = 2, not normalize_max */
+static void win_normalize(int nb, uint32_t k, int16_t old[8][32])
+{
+  if ((k % 2) == 0 && k != 0) {
+    for (int d = 0; d < nb; d++) {
+      for (int i = 1; i < 8; i++) {
+        old[i][d] = subs16(old[i][d], old[0][d]);
+      }
+      old[0][d] = 0;
+    }
+  }
+}
+
+/* turbodecoder_win.h:500-548: last sub-block start state from the 3 tail steps; plain (wrapping) adds */
+static void win_beta_trellis(const int16_t* input, const int16_t* parity, uint32_t K, int16_t old[8])
+{
+  int16_t m_b[8], nw[8];
+  old[0] = 0;
+  for (int i = 1; i < 8; i++) {
+    old[i] = -INF16;
+  }
+  for (int k = (int)K + 2; k >= (int)K; k--) {
+    int16_t x = input[k], y = parity[k];
+    int16_t xy = wrap16(x + y);
+    m_b[0] = wrap16(old[4] + xy);
+    m_b[1] = old[4];
+    m_b[2] = wrap16(old[5] + y);
+    m_b[3] = wrap16(old[5] + x);
+    m_b[4] = wrap16(old[6] + x);
+    m_b[5] = wrap16(old[6] + y);
+    m_b[6] = old[7];
+    m_b[7] = wrap16(old[7] + xy);
+    nw[0] = old[0];
+    nw[1] = wrap16(old[0] + xy);
+    nw[2] = wrap16(old[1] + x);
+    nw[3] = wrap16(old[1] + y);
+    nw[4] = wrap16(old[2] + y);
+    nw[5] = wrap16(old[2] + x);
+    nw[6] = wrap16(old[3] + xy);
+    nw[7] = old[3];
+    for (int i = 0; i < 8; i++) {
+      old[i] = max16(m_b[i], nw[i]);
+    }
+  }
+}
+
+/* one backward trellis step for all lanes (turbodecoder_win.h:626-652) */
+static void win_beta_step(int nb, const int16_t* in_k, const int16_t* app_k, const int16_t* par_k, int16_t old[8][32])
+{
+  for (int d = 0; d < nb; d++) {
+    int16_t x = in_k[d], y = par_k[d];
+    if (app_k) {
+      x = adds16(app_k[d], x);
+    }
+    int16_t xy = adds16(x, y);
+    int16_t o[8], m_b[8], nw[8];
+    for (int i = 0; i < 8; i++) {
+      o[i] = old[i][d];
+    }
+    m_b[0] = adds16(o[4], xy);
+    m_b[1] = o[4];
+    m_b[2] = adds16(o[5], y);
+    m_b[3] = adds16(o[5], x);
+    m_b[4] = adds16(o[6], x);
+    m_b[5] = adds16(o[6], y);
+    m_b[6] = o[7];
+    m_b[7] = adds16(o[7], xy);
+    nw[0] = o[0];
+    nw[1] = adds16(o[0], xy);
+    nw[2] = adds16(o[1], x);
+    nw[3] = adds16(o[1], y);
+    nw[4] = adds16(o[2], y);
+    nw[5] = adds16(o[2], x);
+    nw[6] = adds16(o[3], xy);
+    nw[7] = o[3];
+    for (int i = 0; i < 8; i++) {
+      old[i][d] = max16(m_b[i], nw[i]);
+    }
+  }
+}
+
+/* turbodecoder_win.h:551-681.  beta: [(long_sb+1)][8][nb] */
+static void win_beta(int nb, const int16_t* input, const int16_t* app, const int16_t* parity, uint32_t K,
+                     int16_t* beta)
+{
+  uint32_t long_sb = K / nb;
+  int16_t  old[8][32];
+  /* pass 0: WIN_OVERLAP steps from "all unknown" on the first steps of every sub-block */
+  for (int i = 0; i < 8; i++) {
+    for (int d = 0; d < nb; d++) {
+      old[i][d] = -INF16;
+    }
+  }
+  for (int k = WIN_OVERLAP - 1; k >= 0; k--) {
+    win_beta_step(nb, &input[nb * k], app ? &app[nb * k] : NULL, &parity[nb * k], old);
+    win_normalize(nb, (uint32_t)k, old);
+  }
+  /* hand every estimate to the previous sub-block (lane d <- lane d+1); last lane: tail trellis
+   * (the AVX path's manual fix across the 128-bit boundary makes this a plain shift, :590-617) */
+  int16_t tr[8];
+  win_beta_trellis(input, parity, K, tr);
+  for (int i = 0; i < 8; i++) {
+    for (int d = 0; d < nb - 1; d++) {
+      old[i][d] = old[i][d + 1];
+    }
+    old[i][nb - 1] = tr[i];
+    memcpy(&beta[(8 * long_sb + i) * nb], old[i], nb * sizeof(int16_t));
+  }
+  for (int k = (int)long_sb - 1; k >= 0; k--) {
+    win_beta_step(nb, &input[nb * k], app ? &app[nb * k] : NULL, &parity[nb * k], old);
+    for (int i = 0; i < 8; i++) {
+      memcpy(&beta[(8 * k + i) * nb], old[i], nb * sizeof(int16_t));
+    }
+    win_normalize(nb, (uint32_t)k, old);
+  }
+}
+
+/* turbodecoder_win.h:684-832 */
+static void win_alpha(int nb, const int16_t* input, const int16_t* app, const int16_t* parity, int16_t* output,
+                      uint32_t K, const int16_t* beta)
+{
+  uint32_t long_sb = K / nb;
+  int16_t  old[8][32];
+  for (int pass = 0; pass < 2; pass++) {
+    uint32_t loop_len = pass ? long_sb : WIN_OVERLAP;
+    if (pass) {
+      for (int i = 0; i < 8; i++) {
+        for (int d = nb - 1; d > 0; d--) {
+          old[i][d] = old[i][d - 1];
+        }
+        old[i][0] = i ? -INF16 : 0;
+      }
+    } else {
+      for (int i = 0; i < 8; i++) {
+        for (int d = 0; d < nb; d++) {
+          old[i][d] = -INF16;
+        }
+      }
+    }
+    uint32_t base = long_sb - loop_len;
+    for (uint32_t k = 0; k < loop_len; k++) {
+      const int16_t* in_k  = &input[nb * (base + k)];
+      const int16_t* par_k = &parity[nb * (base + k)];
+      const int16_t* app_k = app ? &app[nb * (base + k)] : NULL;
+      for (int d = 0; d < nb; d++) {
+        int16_t x = in_k[d], y = par_k[d];
+        if (app_k) {
+          x = adds16(app_k[d], x);
+        }
+        int16_t xy = adds16(x, y);
+        int16_t o[8], m_b[8], nw[8];
+        for (int i = 0; i < 8; i++) {
+          o[i] = old[i][d];
+        }
+        m_b[0] = o[0];
+        m_b[1] = adds16(o[3], y);
+        m_b[2] = adds16(o[4], y);
+        m_b[3] = o[7];
+        m_b[4] = o[1];
+        m_b[5] = adds16(o[2], y);
+        m_b[6] = adds16(o[5], y);
+        m_b[7] = o[6];
+        nw[0] = adds16(o[1], xy);
+        nw[1] = adds16(o[2], x);
+        nw[2] = adds16(o[5], x);
+        nw[3] = adds16(o[6], xy);
+        nw[4] = adds16(o[0], xy);
+        nw[5] = adds16(o[3], x);
+        nw[6] = adds16(o[4], x);
+        nw[7] = adds16(o[7], xy);
+        if (pass) {
+          int16_t m1 = -32768, m0 = -32768;
+          for (int i = 0; i < 8; i++) {
+            int16_t b  = beta[(8 * (k + 1) + i) * nb + d];
+            int16_t v0 = adds16(b, m_b[i]);
+            int16_t v1 = adds16(b, nw[i]);
+            m0 = (i == 0) ? v0 : max16(m0, v0);
+            m1 = (i == 0) ? v1 : max16(m1, v1);
+          }
+          output[nb * k + d] = subs16(m1, m0);
+        }
+        for (int i = 0; i < 8; i++) {
+          old[i][d] = max16(m_b[i], nw[i]);
+        }
+      }
+      win_normalize(nb, k, old);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ scalar SISO (turbodecoder_gen.c) */
+
+static void gen_dec(const int16_t* input, const int16_t* app, const int16_t* parity, int16_t* output, uint32_t K,
+                    int16_t* beta)
+{
+  int16_t  m_b[8], nw[8], old[8];
+  uint32_t end = K + 3;
+  beta[8 * end] = 0;
+  for (int i = 1; i < 8; i++) {
+    beta[8 * end + i] = -INF16;
+  }
+  /* map_gen_beta :58-112 */
+  for (int i = 0; i < 8; i++) {
+    old[i] = beta[8 * end + i];
+  }
+  for (int k = (int)end - 1; k >= 0; k--) {
+    int16_t x = input[k];
+    if (app && (uint32_t)k < K) {
+      x = wrap16(x + app[k]);
+    }
+    int16_t y  = parity[k];
+    int16_t xy = wrap16(x + y);
+    m_b[0] = wrap16(old[4] + xy);
+    m_b[1] = old[4];
+    m_b[2] = wrap16(old[5] + y);
+    m_b[3] = wrap16(old[5] + x);
+    m_b[4] = wrap16(old[6] + x);
+    m_b[5] = wrap16(old[6] + y);
+    m_b[6] = old[7];
+    m_b[7] = wrap16(old[7] + xy);
+    nw[0] = old[0];
+    nw[1] = wrap16(old[0] + xy);
+    nw[2] = wrap16(old[1] + x);
+    nw[3] = wrap16(old[1] + y);
+    nw[4] = wrap16(old[2] + y);
+    nw[5] = wrap16(old[2] + x);
+    nw[6] = wrap16(old[3] + xy);
+    nw[7] = old[3];
+    for (int i = 0; i < 8; i++) {
+      old[i]          = max16(m_b[i], nw[i]);
+      beta[8 * k + i] = old[i];
+    }
+    if ((k % 4) == 0 && (uint32_t)k < K) {
+      for (int i = 1; i < 8; i++) {
+        old[i] = wrap16(old[i] - old[0]);
+      }
+      old[0] = 0;
+    }
+  }
+  /* map_gen_alpha :114-198 */
+  old[0] = 0;
+  for (int i = 1; i < 8; i++) {
+    old[i] = -INF16;
+  }
+  for (uint32_t k = 1; k < K + 1; k++) {
+    int16_t x = input[k - 1];
+    if (app) {
+      x = wrap16(x + app[k - 1]);
+    }
+    int16_t y  = parity[k - 1];
+    int16_t xy = wrap16(x + y);
+    m_b[0] = old[0];
+    m_b[1] = wrap16(old[3] + y);
+    m_b[2] = wrap16(old[4] + y);
+    m_b[3] = old[7];
+    m_b[4] = old[1];
+    m_b[5] = wrap16(old[2] + y);
+    m_b[6] = wrap16(old[5] + y);
+    m_b[7] = old[6];
+    nw[0] = wrap16(old[1] + xy);
+    nw[1] = wrap16(old[2] + x);
+    nw[2] = wrap16(old[5] + x);
+    nw[3] = wrap16(old[6] + xy);
+    nw[4] = wrap16(old[0] + xy);
+    nw[5] = wrap16(old[3] + x);
+    nw[6] = wrap16(old[4] + x);
+    nw[7] = wrap16(old[7] + xy);
+    int16_t m1 = 0, m0 = 0;
+    for (int i = 0; i < 8; i++) {
+      int16_t v0 = wrap16(m_b[i] + beta[8 * k + i]);
+      int16_t v1 = wrap16(nw[i] + beta[8 * k + i]);
+      m0 = (i == 0) ? v0 : max16(m0, v0);
+      m1 = (i == 0) ? v1 : max16(m1, v1);
+    }
+    for (int i = 0; i < 8; i++) {
+      old[i] = max16(m_b[i], nw[i]);
+    }
+    if ((k % 4) == 0) {
+      for (int i = 1; i < 8; i++) {
+        old[i] = wrap16(old[i] - old[0]);
+      }
+      old[0] = 0;
+    }
+    output[k - 1] = wrap16(m1 - m0);
+  }
+}
+
+/* ------------------------------------------------------------------ run_all */
+
+int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t K, int impl,
+                     int sb_layout, int16_t* snap)
+{
+  int cbidx = orc_tc_cb_index(K);
+  if (cbidx < 0 || K > 6144) {
+    return -1;
+  }
+  uint32_t nb;
+  switch (impl) {
+    case ORC_TDEC_AUTO:
+      nb = orc_tdec_autoimp_subblocks(K);
+      break;
+    case ORC_TDEC_GENERIC:
+      nb = 0;
+      break;
+    case ORC_TDEC_SSE_WINDOW:
+      nb = 8;
+      break;
+    case ORC_TDEC_AVX_WINDOW:
+      nb = 16;
+      break;
+    default:
+      return -1;
+  }
+  if (nb && (K % nb || K / nb < WIN_OVERLAP)) {
+    return -1; /* the reference reads out of bounds here; refuse */
+  }
+  if (sb_layout && !nb) {
+    return -1;
+  }
+  uint32_t  len  = K + 12;
+  int16_t*  syst = calloc(len, 2), *par0 = calloc(len, 2), *par1 = calloc(len, 2);
+  int16_t*  app1 = calloc(len, 2), *app2 = calloc(len, 2), *ext1 = calloc(len, 2), *ext2 = calloc(len, 2);
+  uint16_t* inter = malloc(K * 2), *deinter = malloc(K * 2);
+  int16_t*  beta = malloc(sizeof(int16_t) * 8 * (K + 16) * (nb ? 1 : 1) + 64);
+  orc_qpp_gen(K, nb ? nb : 1, inter, deinter);
+
+  /* input extraction: turbodecoder_gen.c:238-258, turbodecoder_win.h:888-930, turbodecoder_iter.h:58-70,88-102 */
+  if (sb_layout) {
+    memcpy(syst, input, K * 2);
+    memcpy(par0, &input[K + 32], K * 2);
+    memcpy(par1, &input[2 * (K + 32)], K * 2);
+    for (uint32_t i = K; i < K + 3; i++) {
+      syst[i] = input[3 * (K + 32) + 2 * (i - K)];
+      par0[i] = input[3 * (K + 32) + 2 * (i - K) + 1];
+      app2[i] = input[3 * (K + 32) + 6 + 2 * (i - K)];
+      par1[i] = input[3 * (K + 32) + 6 + 2 * (i - K) + 1];
+    }
+  } else {
+    uint32_t long_sb = nb ? K / nb : K;
+    for (uint32_t n = 0; n < K; n++) {
+      uint32_t idx = nb ? (n % long_sb) * nb + n / long_sb : n;
+      syst[idx] = input[3 * n];
+      par0[idx] = input[3 * n + 1];
+      par1[idx] = input[3 * n + 2];
+    }
+    for (uint32_t i = K; i < K + 3; i++) {
+      syst[i] = input[3 * K + 2 * (i - K)];
+      par0[i] = input[3 * K + 2 * (i - K) + 1];
+      app2[i] = input[3 * K + 6 + 2 * (i - K)];
+      par1[i] = input[3 * K + 6 + 2 * (i - K) + 1];
+    }
+  }
+
+  uint32_t n_iter = 0;
+  do {
+    if ((n_iter % 2) == 0) {
+      if (n_iter) {
+        for (uint32_t i = 0; i < K; i++) {
+          app1[i] = wrap16(app1[i] - ext1[i]); /* srsran_vec_sub_sss, vector_simd.c:132-160 */
+        }
+      }
+      if (nb) {
+        win_beta(nb, syst, n_iter ? app1 : NULL, par0, K, beta);
+        win_alpha(nb, syst, n_iter ? app1 : NULL, par0, ext1, K, beta);
+      } else {
+        gen_dec(syst, n_iter ? app1 : NULL, par0, ext1, K, beta);
+      }
+      if (snap) {
+        memcpy(&snap[n_iter * K], ext1, K * 2);
+      }
+    } else {
+      if (n_iter > 1) {
+        for (uint32_t i = 0; i < K; i++) {
+          ext1[i] = wrap16(ext1[i] - app1[i]);
+        }
+      }
+      for (uint32_t i = 0; i < K; i++) {
+        app2[deinter[i]] = ext1[i]; /* srsran_vec_lut_sss, vector_simd.c:291-329 */
+      }
+      if (nb) {
+        win_beta(nb, app2, NULL, par1, K, beta);
+        win_alpha(nb, app2, NULL, par1, ext2, K, beta);
+      } else {
+        gen_dec(app2, NULL, par1, ext2, K, beta);
+      }
+      for (uint32_t i = 0; i < K; i++) {
+        app1[inter[i]] = ext2[i];
+      }
+      if (snap) {
+        memcpy(&snap[n_iter * K], ext2, K * 2);
+      }
+    }
+    n_iter++;
+  } while (n_iter < nof_iterations);
+
+  /* turbodecoder.c:370-378 + decision_byte (turbodecoder_gen.c:260-277 / turbodecoder_win.h:973-993) */
+  const int16_t* dec     = !(n_iter % 2) ? app1 : ext1;
+  uint32_t       long_sb = nb ? K / nb : K;
+  memset(output, 0, K / 8);
+  for (uint32_t n = 0; n < K; n++) {
+    uint32_t idx = nb ? (n % long_sb) * nb + n / long_sb : n;
+    if (dec[idx] > 0) {
+      output[n / 8] |= (uint8_t)(0x80u >> (n % 8));
+    }
+  }
+
+  free(syst);
+  free(par0);
+  free(par1);
+  free(app1);
+  free(app2);
+  free(ext1);
+  free(ext2);
+  free(inter);
+  free(deinter);
+  free(beta);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ encoder (turbocoder.c:76-200) */
+
+int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t K)
+{
+  if (orc_tc_cb_index(K) < 0 || (uint32_t)orc_tc_cb_size(orc_tc_cb_index(K)) != K) {
+    return -1;
+  }
+  uint16_t* fw = malloc(K * 2), *rv = malloc(K * 2);
+  orc_qpp_gen(K, 1, fw, rv);
+  uint8_t r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < K; i++) {
+    uint8_t bit = input[i] & 1;
+    output[k++] = bit;
+    uint8_t in  = bit ^ (r1[2] ^ r1[1]);
+    uint8_t out = r1[2] ^ (r1[0] ^ in);
+    r1[2] = r1[1];
+    r1[1] = r1[0];
+    r1[0] = in;
+    output[k++] = out;
+    bit = input[fw[i]] & 1;
+    in  = bit ^ (r2[2] ^ r2[1]);
+    out = r2[2] ^ (r2[0] ^ in);
+    r2[2] = r2[1];
+    r2[1] = r2[0];
+    r2[0] = in;
+    output[k++] = out;
+  }
+  for (int j = 0; j < 3; j++) { /* tail of constituent encoder 1 */
+    uint8_t bit = r1[2] ^ r1[1];
+    output[k++] = bit;
+    uint8_t in  = bit ^ (r1[2] ^ r1[1]);
+    uint8_t out = r1[2] ^ (r1[0] ^ in);
+    r1[2] = r1[1];
+    r1[1] = r1[0];
+    r1[0] = in;
+    output[k++] = out;
+  }
+  for (int j = 0; j < 3; j++) { /* tail of constituent encoder 2 */
+    uint8_t bit = r2[2] ^ r2[1];
+    output[k++] = bit;
+    uint8_t in  = bit ^ (r2[2] ^ r2[1]);
+    uint8_t out = r2[2] ^ (r2[0] ^ in);
+    r2[2] = r2[1];
+    r2[1] = r2[0];
+    r2[0] = in;
+    output[k++] = out;
+  }
+  free(fw);
+  free(rv);
+  return 0;
+}

@@ -1,0 +1,80 @@
+/*
+ * phy_batch.h -- batched, device-resident extension of the drop-in ABI (libsrsran_phy_hip.so).
+ *
+ * One subframe / one code block per call cannot fill 256 CUs.  These entry points run the same
+ * kernels as the handle API of phy_abi.h over a batch of independent units whose buffers already
+ * live in HBM (plain device pointers; no torch types).  Semantics per unit are exactly those of
+ * the cited reference function.  `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * calls are asynchronous on that stream.
+ */
+#ifndef SRSRAN_AMD_PHY_BATCH_H
+#define SRSRAN_AMD_PHY_BATCH_H
+
+#include "srsran_amd/phy_abi.h"
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device plumbing for C hosts (thin wrappers over hipMalloc/hipMemcpy/hipStreamSynchronize) ---- */
+SRSRAN_API int         srsran_hip_device_count(void);
+SRSRAN_API int         srsran_hip_set_device(int device);
+SRSRAN_API void*       srsran_hip_malloc(size_t bytes);
+SRSRAN_API void        srsran_hip_free(void* dptr);
+SRSRAN_API int         srsran_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+SRSRAN_API int         srsran_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+SRSRAN_API int         srsran_hip_memset(void* dst, int value, size_t bytes, void* stream);
+SRSRAN_API int         srsran_hip_stream_sync(void* stream);
+SRSRAN_API const char* srsran_hip_last_error(void);
+SRSRAN_API const char* srsran_hip_build_info(void);
+
+/* ---- turbo decoder: srsran_tdec_run_all (turbodecoder.c:536-549) over n_cb code blocks ---- */
+typedef struct srsran_hip_tdec_batch srsran_hip_tdec_batch_t;
+
+/* impl: SRSRAN_TDEC_AUTO / _GENERIC / _SSE_WINDOW / _AVX_WINDOW select which reference decoder is
+ * reproduced bit-exactly (AUTO = the reference's choice on an AVX2 host, turbodecoder.c:381-408). */
+SRSRAN_API int  srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** h, uint32_t long_cb, uint32_t max_nof_cb, int impl);
+SRSRAN_API void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h);
+/* d_input : n_cb blocks of int16 LLRs, `in_stride` int16 apart.  sb_layout = 0: natural order
+ *           [s p0 p1]xK + 12 tail (3K+12);  sb_layout = 1: srsran_rm_turbo_rx_lut sub-block layout
+ *           (3(K+32)+12, turbodecoder_iter.h:88-102; window impls only).
+ * d_output: n_cb blocks of K/8 bytes (MSB first), `out_stride` bytes apart. */
+SRSRAN_API int  srsran_hip_tdec_batch_run(srsran_hip_tdec_batch_t* h, const int16_t* d_input, uint32_t in_stride,
+                                          uint8_t* d_output, uint32_t out_stride, uint32_t n_cb,
+                                          uint32_t nof_iterations, int sb_layout, void* stream);
+/* debug/parity aid: copy the SISO output of the last half iteration (K int16 per CB, natural order) */
+SRSRAN_API int  srsran_hip_tdec_batch_last_llr(srsran_hip_tdec_batch_t* h, int16_t* d_llr, uint32_t n_cb, void* stream);
+
+/* ---- LDPC: srsran_ldpc_decoder_decode_c (ldpc_decoder.c:657-685, int8 layered) over n_cw words ---- */
+typedef struct srsran_hip_ldpc_batch srsran_hip_ldpc_batch_t;
+
+SRSRAN_API int  srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** h, srsran_basegraph_t bg, uint16_t ls,
+                                             float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw);
+SRSRAN_API void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h);
+/* d_llrs   : n_cw x (N-2Z) int8 (only the first cdwd_rm_length... all N-2Z are read, as the reference does),
+ *            `llr_stride` bytes apart;  d_message: n_cw x K bytes, one bit per byte, `msg_stride` apart.
+ * d_iter_msgs (optional, may be NULL): n_cw x max_nof_iter x K/8 packed hard decisions after every
+ *            iteration (used by the handle API to reproduce the CRC early stop of decode_crc_c). */
+SRSRAN_API int  srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride,
+                                          uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
+                                          uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream);
+
+/* ---- OFDM: srsran_ofdm_rx_sf / srsran_ofdm_tx_sf (ofdm.c:453-466,562-576) over n_sf subframes ---- */
+typedef struct srsran_hip_ofdm_batch srsran_hip_ofdm_batch_t;
+
+/* cfg: as for srsran_ofdm_rx_init_cfg / tx_init_cfg (in_buffer/out_buffer ignored). */
+SRSRAN_API int  srsran_hip_ofdm_batch_create(srsran_hip_ofdm_batch_t** h, const srsran_ofdm_cfg_t* cfg, srsran_dft_dir_t dir);
+SRSRAN_API void srsran_hip_ofdm_batch_free(srsran_hip_ofdm_batch_t* h);
+SRSRAN_API uint32_t srsran_hip_ofdm_batch_sf_sz(srsran_hip_ofdm_batch_t* h);    /* time samples per subframe */
+SRSRAN_API uint32_t srsran_hip_ofdm_batch_sf_re(srsran_hip_ofdm_batch_t* h);    /* resource elements per subframe */
+/* rx: d_in n_sf x sf_sz time samples -> d_out n_sf x sf_re REs.  The input is NOT modified (the
+ * reference multiplies in_buffer by the shift table in place, ofdm.c:455-457; here it is applied on load). */
+SRSRAN_API int  srsran_hip_ofdm_batch_rx(srsran_hip_ofdm_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t n_sf, void* stream);
+/* tx: d_in n_sf x sf_re REs -> d_out n_sf x sf_sz time samples */
+SRSRAN_API int  srsran_hip_ofdm_batch_tx(srsran_hip_ofdm_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t n_sf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

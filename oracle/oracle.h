@@ -45,9 +45,10 @@ enum { ORC_TDEC_AUTO = 0, ORC_TDEC_GENERIC = 1, ORC_TDEC_SSE_WINDOW = 3, ORC_TDE
  *   output   : K/8 bytes, MSB first
  *   snap     : optional, nof_iterations*K int16: the SISO output vector (ext1 on even, ext2 on odd
  *              n_iter) after every half iteration, in the decoder's internal lane layout
+ *   dec_llr  : optional, K int16: the LLRs the hard decision is taken from (app1 / ext1), natural order
  * returns 0, or -1 on invalid arguments */
 int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb,
-                     int impl, int sb_layout, int16_t* snap);
+                     int impl, int sb_layout, int16_t* snap, int16_t* dec_llr);
 
 /* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
 int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);

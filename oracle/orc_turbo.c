@@ -403,7 +403,7 @@ static void gen_dec(const int16_t* input, const int16_t* app, const int16_t* par
 /* ------------------------------------------------------------------ run_all */
 
 int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t K, int impl,
-                     int sb_layout, int16_t* snap)
+                     int sb_layout, int16_t* snap, int16_t* dec_llr)
 {
   int cbidx = orc_tc_cb_index(K);
   if (cbidx < 0 || K > 6144) {
@@ -516,6 +516,9 @@ int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterati
     uint32_t idx = nb ? (n % long_sb) * nb + n / long_sb : n;
     if (dec[idx] > 0) {
       output[n / 8] |= (uint8_t)(0x80u >> (n % 8));
+    }
+    if (dec_llr) {
+      dec_llr[n] = dec[idx];
     }
   }
 

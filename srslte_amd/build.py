@@ -1,0 +1,71 @@
+"""Build libsrsran_phy_hip.so (gfx950 only) in-tree with hipcc.
+
+    python -m srslte_amd.build            # build if sources are newer than the library
+    python -m srslte_amd.build --force
+
+The library is the product: hand-written HIP kernels + the C-ABI host layer (srslte_amd/csrc).
+It is built IN-TREE (srslte_amd/lib/) so that it travels with the repository snapshot to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libsrsran_phy_hip.so")
+
+SOURCES = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "tables", "*.h")) +
+                 glob.glob(os.path.join(ROOT, "include", "srsran_amd", "*.h")))
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
+         "-Wno-unused-value", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [__file__])
+
+
+def build(force=False, verbose=True, jobs=8):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    procs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        if len(procs) >= jobs:
+            _drain(procs)
+    _drain(procs)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def _drain(procs):
+    while procs:
+        src, p = procs.pop(0)
+        out, _ = p.communicate()
+        if out.strip():
+            print(out)
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s" % src)
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,169 @@
+"""ctypes binding of libsrsran_phy_hip.so -- the thin Python mirror of the reference's C interface.
+
+Nothing is computed here: every call goes through the C ABI declared in include/srsran_amd/*.h.
+There is NO fallback: if the shared library (or, at run time, a HIP device) is missing the calls fail
+loudly.  The structures mirror lib/include/srsran/phy/{dft/dft.h,dft/ofdm.h,fec/turbo/turbodecoder.h,
+fec/ldpc/ldpc_decoder.h} of the reference field by field.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsrsran_phy_hip.so")
+
+SRSRAN_SUCCESS = 0
+SRSRAN_ERROR = -1
+SRSRAN_ERROR_INVALID_INPUTS = -2
+
+# srsran_tdec_impl_type_t (turbodecoder_impl.h:28-38)
+TDEC_AUTO, TDEC_GENERIC, TDEC_SSE, TDEC_SSE_WINDOW, TDEC_NEON_WINDOW, TDEC_AVX_WINDOW, TDEC_SSE8_WINDOW, TDEC_AVX8_WINDOW = range(8)
+# srsran_ldpc_decoder_type_t (ldpc_decoder.h:41-55)
+LDPC_F, LDPC_S, LDPC_C, LDPC_C_FLOOD, LDPC_C_AVX2, LDPC_C_AVX2_FLOOD, LDPC_C_AVX512, LDPC_C_AVX512_FLOOD = range(8)
+BG1, BG2 = 0, 1
+CP_NORM, CP_EXT = 0, 1
+SF_NORM, SF_MBSFN = 0, 1
+DFT_FORWARD, DFT_BACKWARD = 0, 1
+
+
+class DftPlan(C.Structure):
+    _fields_ = [("init_size", C.c_int), ("size", C.c_int), ("in_", C.c_void_p), ("out", C.c_void_p), ("p", C.c_void_p),
+                ("is_guru", C.c_bool), ("forward", C.c_bool), ("mirror", C.c_bool), ("db", C.c_bool), ("norm", C.c_bool),
+                ("dc", C.c_bool), ("dir", C.c_int), ("mode", C.c_int)]
+
+
+class OfdmCfg(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("in_buffer", C.c_void_p), ("out_buffer", C.c_void_p), ("cp", C.c_int),
+                ("sf_type", C.c_int), ("normalize", C.c_bool), ("freq_shift_f", C.c_float),
+                ("rx_window_offset", C.c_float), ("symbol_sz", C.c_uint32), ("keep_dc", C.c_bool)]
+
+
+class Ofdm(C.Structure):
+    _fields_ = [("cfg", OfdmCfg), ("fft_plan", DftPlan), ("fft_plan_sf", DftPlan * 2), ("max_prb", C.c_uint32),
+                ("nof_symbols", C.c_uint32), ("nof_guards", C.c_uint32), ("nof_re", C.c_uint32), ("slot_sz", C.c_uint32),
+                ("sf_sz", C.c_uint32), ("tmp", C.c_void_p), ("mbsfn_subframe", C.c_bool), ("mbsfn_guard_len", C.c_uint32),
+                ("nof_symbols_mbsfn", C.c_uint32), ("non_mbsfn_region", C.c_uint8), ("window_offset_n", C.c_uint32),
+                ("shift_buffer", C.c_void_p), ("window_offset_buffer", C.c_void_p)]
+
+
+class TcInterl(C.Structure):
+    _fields_ = [("forward", C.POINTER(C.c_uint16)), ("reverse", C.POINTER(C.c_uint16)), ("max_long_cb", C.c_uint32)]
+
+
+class Tdec(C.Structure):
+    _fields_ = [("max_long_cb", C.c_uint32), ("dec8_hdlr", C.c_void_p * 2), ("dec16_hdlr", C.c_void_p * 3),
+                ("dec8", C.c_void_p * 2), ("dec16", C.c_void_p * 3), ("nof_blocks8", C.c_int * 2),
+                ("nof_blocks16", C.c_int * 3), ("app1", C.c_void_p), ("app2", C.c_void_p), ("ext1", C.c_void_p),
+                ("ext2", C.c_void_p), ("syst0", C.c_void_p), ("parity0", C.c_void_p), ("parity1", C.c_void_p),
+                ("input_conv", C.c_void_p), ("force_not_sb", C.c_bool), ("dec_type", C.c_int),
+                ("current_llr_type", C.c_int), ("current_dec", C.c_uint32), ("current_long_cb", C.c_uint32),
+                ("current_inter_idx", C.c_uint32), ("current_cbidx", C.c_int), ("interleaver", (TcInterl * 188) * 4),
+                ("n_iter", C.c_int)]
+
+
+class Crc(C.Structure):
+    _fields_ = [("table", C.c_uint64 * 256), ("polynom", C.c_int), ("order", C.c_int), ("crcinit", C.c_uint64),
+                ("crcmask", C.c_uint64), ("crchighbit", C.c_uint64), ("srsran_crc_out", C.c_uint32)]
+
+
+class LdpcDecoderArgs(C.Structure):
+    _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float),
+                ("max_nof_iter", C.c_uint32)]
+
+
+class LdpcDecoder(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("bg", C.c_int), ("ls", C.c_uint16), ("max_nof_iter", C.c_uint32),
+                ("bgN", C.c_uint8), ("liftN", C.c_uint16), ("bgM", C.c_uint8), ("liftM", C.c_uint16), ("bgK", C.c_uint8),
+                ("liftK", C.c_uint16), ("pcm", C.c_void_p), ("var_indices", C.c_void_p), ("scaling_fctr", C.c_float),
+                ("free", C.c_void_p), ("decode_f", C.c_void_p), ("decode_s", C.c_void_p), ("decode_c", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libsrsran_phy_hip.so (built by srslte_amd.build).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: run `python -m srslte_amd.build` (hipcc, gfx950). "
+                               "There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32, u8p = C.c_void_p, C.c_uint32, C.c_int, C.c_void_p
+        sig = {
+            "srsran_hip_device_count": (i32, []),
+            "srsran_hip_set_device": (i32, [i32]),
+            "srsran_hip_malloc": (vp, [C.c_size_t]),
+            "srsran_hip_free": (None, [vp]),
+            "srsran_hip_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),
+            "srsran_hip_memcpy_d2h": (i32, [vp, vp, C.c_size_t, vp]),
+            "srsran_hip_memset": (i32, [vp, i32, C.c_size_t, vp]),
+            "srsran_hip_stream_sync": (i32, [vp]),
+            "srsran_hip_last_error": (C.c_char_p, []),
+            "srsran_hip_build_info": (C.c_char_p, []),
+            "srsran_hip_tdec_batch_create": (i32, [C.POINTER(vp), u32, u32, i32]),
+            "srsran_hip_tdec_batch_free": (None, [vp]),
+            "srsran_hip_tdec_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, vp]),
+            "srsran_hip_tdec_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, i32, vp]),
+            "srsran_hip_tdec_batch_last_llr": (i32, [vp, vp, u32, vp]),
+            "srsran_hip_ldpc_batch_create": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32]),
+            "srsran_hip_ldpc_batch_free": (None, [vp]),
+            "srsran_hip_ldpc_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
+            "srsran_hip_ofdm_batch_create": (i32, [C.POINTER(vp), C.POINTER(OfdmCfg), i32]),
+            "srsran_hip_ofdm_batch_free": (None, [vp]),
+            "srsran_hip_ofdm_batch_sf_sz": (u32, [vp]),
+            "srsran_hip_ofdm_batch_sf_re": (u32, [vp]),
+            "srsran_hip_ofdm_batch_rx": (i32, [vp, vp, vp, u32, vp]),
+            "srsran_hip_ofdm_batch_tx": (i32, [vp, vp, vp, u32, vp]),
+            "srsran_tdec_init": (i32, [C.POINTER(Tdec), u32]),
+            "srsran_tdec_init_manual": (i32, [C.POINTER(Tdec), u32, i32]),
+            "srsran_tdec_free": (None, [C.POINTER(Tdec)]),
+            "srsran_tdec_force_not_sb": (None, [C.POINTER(Tdec)]),
+            "srsran_tdec_new_cb": (i32, [C.POINTER(Tdec), u32]),
+            "srsran_tdec_get_nof_iterations": (i32, [C.POINTER(Tdec)]),
+            "srsran_tdec_autoimp_get_subblocks": (u32, [u32]),
+            "srsran_tdec_autoimp_get_subblocks_8bit": (u32, [u32]),
+            "srsran_tdec_iteration": (None, [C.POINTER(Tdec), vp, vp]),
+            "srsran_tdec_run_all": (i32, [C.POINTER(Tdec), vp, vp, u32, u32]),
+            "srsran_tc_interl_init": (i32, [C.POINTER(TcInterl), u32]),
+            "srsran_tc_interl_free": (None, [C.POINTER(TcInterl)]),
+            "srsran_tc_interl_LTE_gen": (i32, [C.POINTER(TcInterl), u32]),
+            "srsran_tc_interl_LTE_gen_interl": (i32, [C.POINTER(TcInterl), u32, u32]),
+            "srsran_cbsegm_cbindex": (i32, [u32]),
+            "srsran_cbsegm_cbsize": (i32, [u32]),
+            "srsran_ldpc_decoder_init": (i32, [C.POINTER(LdpcDecoder), C.POINTER(LdpcDecoderArgs)]),
+            "srsran_ldpc_decoder_free": (None, [C.POINTER(LdpcDecoder)]),
+            "srsran_ldpc_decoder_decode_c": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32]),
+            "srsran_ldpc_decoder_decode_crc_c": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32, C.POINTER(Crc)]),
+            "create_compact_pcm": (i32, [vp, vp, i32, C.c_uint16]),
+            "srsran_ofdm_rx_init_cfg": (i32, [C.POINTER(Ofdm), C.POINTER(OfdmCfg)]),
+            "srsran_ofdm_tx_init_cfg": (i32, [C.POINTER(Ofdm), C.POINTER(OfdmCfg)]),
+            "srsran_ofdm_rx_init": (i32, [C.POINTER(Ofdm), i32, vp, vp, u32]),
+            "srsran_ofdm_tx_init": (i32, [C.POINTER(Ofdm), i32, vp, vp, u32]),
+            "srsran_ofdm_rx_set_prb": (i32, [C.POINTER(Ofdm), i32, u32]),
+            "srsran_ofdm_tx_set_prb": (i32, [C.POINTER(Ofdm), i32, u32]),
+            "srsran_ofdm_rx_free": (None, [C.POINTER(Ofdm)]),
+            "srsran_ofdm_tx_free": (None, [C.POINTER(Ofdm)]),
+            "srsran_ofdm_rx_sf": (None, [C.POINTER(Ofdm)]),
+            "srsran_ofdm_rx_sf_ng": (None, [C.POINTER(Ofdm), vp, vp]),
+            "srsran_ofdm_tx_sf": (None, [C.POINTER(Ofdm)]),
+            "srsran_ofdm_set_freq_shift": (i32, [C.POINTER(Ofdm), C.c_float]),
+            "srsran_ofdm_set_normalize": (None, [C.POINTER(Ofdm), C.c_bool]),
+            "srsran_symbol_sz": (i32, [u32]),
+            "srsran_symbol_sz_power2": (i32, [u32]),
+            "srsran_use_standard_symbol_size": (None, [C.c_bool]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().srsran_hip_last_error().decode()
+
+
+def check(rc, what):
+    if rc != SRSRAN_SUCCESS:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

@@ -1,0 +1,33 @@
+// ldpc_device.h -- kernel parameter block and launcher of ldpc_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace phyhip {
+namespace ldpc {
+
+struct Params {
+  const int8_t*   llrs;      // n_cw x (N-2Z) int8, llr_stride bytes apart
+  uint8_t*        msg;       // n_cw x K*Z bytes (bit per byte), msg_stride apart
+  uint8_t*        iter_msgs; // optional: n_cw x max_iter x ceil(K*Z/8) packed hard decisions per iteration
+  const uint16_t* row_start; // bgM+1 : first edge of every base-graph row
+  const uint8_t*  col;       // per edge: variable node
+  const uint16_t* shift;     // per edge: circular shift (V mod Z)
+  uint32_t        llr_stride;
+  uint32_t        msg_stride;
+  int             Z;
+  int             bgN;
+  int             bgK;
+  int             n_layers;
+  int             n_edges; // edges of the first n_layers rows
+  int             max_iter;
+  int             sf; // (int)(scaling_fctr * 100)
+  int             n_cw;
+  int             cpb; // code words per workgroup
+};
+
+hipError_t launch(const Params& p, hipStream_t stream);
+size_t     lds_bytes(const Params& p);
+
+} // namespace ldpc
+} // namespace phyhip

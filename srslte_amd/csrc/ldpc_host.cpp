@@ -1,0 +1,421 @@
+// ldpc_host.cpp -- host side of the NR LDPC decoder: base graphs, batch object, srsran_ldpc_decoder_* ABI.
+//
+// Mirrors (interface + behaviour) lib/src/phy/fec/ldpc/ldpc_decoder.c:540-685 and
+// lib/src/phy/fec/ldpc/base_graph.c:50,4467-4503 of the reference.
+#include "hip_common.h"
+#include "ldpc_device.h"
+#include "tables/nr_ldpc_bg_table.h"
+#include "tables/nr_ldpc_lsindex.h"
+
+#include <vector>
+
+using namespace phyhip;
+
+// ------------------------------------------------------------------------------------------------ base graph
+
+static int ls_index_of(unsigned ls)
+{
+  // TS 38.212 Table 5.3.2-1: Z = a * 2^j, a in {2,3,5,7,9,11,13,15} (set index 0..7), 2 <= Z <= 384
+  if (ls < 2 || ls > MAX_LIFTSIZE) {
+    return VOID_LIFTSIZE;
+  }
+  unsigned odd = ls;
+  while (!(odd & 1)) {
+    odd >>= 1;
+  }
+  static const int set_of_odd[16] = {-1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, 5, -1, 6, -1, 7};
+  if (odd > 15 || set_of_odd[odd] < 0) {
+    return VOID_LIFTSIZE;
+  }
+  return set_of_odd[odd];
+}
+
+// base_graph.c:50 -- exported under the reference's name
+extern "C" const uint8_t LSindex[385] = NR_LDPC_LSINDEX_INIT;
+
+struct BgDims {
+  int N, M, K, E;
+  const nr_ldpc_edge_t* edges;
+};
+
+static bool bg_dims(int bg, BgDims* d)
+{
+  if (bg == BG1) {
+    *d = {68, 46, 22, NR_LDPC_BG1_NOF_EDGES, nr_ldpc_bg1_edges};
+    return true;
+  }
+  if (bg == BG2) {
+    *d = {52, 42, 10, NR_LDPC_BG2_NOF_EDGES, nr_ldpc_bg2_edges};
+    return true;
+  }
+  return false;
+}
+
+extern "C" int create_compact_pcm(uint16_t* pcm, int8_t (*positions)[MAX_CNCT], srsran_basegraph_t bg, uint16_t ls)
+{
+  BgDims d;
+  int    ils = ls_index_of(ls);
+  if (!bg_dims(bg, &d) || ils == VOID_LIFTSIZE) {
+    fprintf(stderr, "Invalid lifting size %d\n", ls);
+    return -1;
+  }
+  for (int i = 0; i < d.M * d.N; i++) {
+    pcm[i] = NO_CNCT;
+  }
+  if (positions) {
+    for (int m = 0; m < d.M; m++) {
+      for (int j = 0; j < MAX_CNCT; j++) {
+        positions[m][j] = -1;
+      }
+    }
+  }
+  std::vector<int> fill(d.M, 0);
+  for (int e = 0; e < d.E; e++) {
+    const nr_ldpc_edge_t& ed = d.edges[e];
+    pcm[ed.row * d.N + ed.col] = (uint16_t)(ed.v[ils] % ls);
+    if (positions) {
+      positions[ed.row][fill[ed.row]++] = (int8_t)ed.col;
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ batch object
+
+struct srsran_hip_ldpc_batch {
+  int      bg = 0, Z = 0, N = 0, M = 0, K = 0, E = 0;
+  int      max_iter = 0;
+  int      sf       = 0;
+  uint32_t max_cw   = 0;
+  std::vector<uint16_t> row_start;
+  uint16_t* d_row_start = nullptr;
+  uint8_t*  d_col       = nullptr;
+  uint16_t* d_shift     = nullptr;
+};
+
+extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran_basegraph_t bg, uint16_t ls,
+                                            float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw)
+{
+  if (!hh) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *hh = nullptr;
+  BgDims d;
+  int    ils = ls_index_of(ls);
+  if (!bg_dims(bg, &d) || ils == VOID_LIFTSIZE) {
+    set_error("invalid base graph %d / lifting size %d", bg, ls);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (scaling_fctr <= 0 || scaling_fctr > 1) { // ldpc_decoder.c:601
+    set_error("The scaling factor of the min-sum algorithm should be larger than 0 and not larger than 1.");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  auto* h     = new srsran_hip_ldpc_batch;
+  h->bg       = bg;
+  h->Z        = ls;
+  h->N        = d.N;
+  h->M        = d.M;
+  h->K        = d.K;
+  h->E        = d.E;
+  h->max_iter = max_nof_iter ? (int)max_nof_iter : 10; // ldpc_decoder.c:42,579
+  h->sf       = (int)(scaling_fctr * 100);             // ldpc_dec_c.c:150 (float * int, truncated)
+  h->max_cw   = max_nof_cw;
+  std::vector<uint8_t>  col(d.E);
+  std::vector<uint16_t> shift(d.E);
+  h->row_start.assign(d.M + 1, 0);
+  int row = 0;
+  for (int e = 0; e < d.E; e++) {
+    while (row < d.edges[e].row) {
+      h->row_start[++row] = (uint16_t)e;
+    }
+    col[e]   = d.edges[e].col;
+    shift[e] = (uint16_t)(d.edges[e].v[ils] % ls);
+  }
+  while (row < d.M) {
+    h->row_start[++row] = (uint16_t)d.E;
+  }
+  PHY_HIP_CHECK(hipMalloc(&h->d_row_start, (d.M + 1) * sizeof(uint16_t)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMalloc(&h->d_col, d.E), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMalloc(&h->d_shift, d.E * sizeof(uint16_t)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(h->d_row_start, h->row_start.data(), (d.M + 1) * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(h->d_col, col.data(), d.E, hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(h->d_shift, shift.data(), d.E * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  *hh = h;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
+{
+  if (!h) {
+    return;
+  }
+  hipFree(h->d_row_start);
+  hipFree(h->d_col);
+  hipFree(h->d_shift);
+  delete h;
+}
+
+extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride,
+                                         uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
+                                         uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream)
+{
+  if (!h || !d_llrs || !d_message || n_cw == 0) {
+    set_error("ldpc batch: invalid arguments");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  const uint32_t Z = h->Z, liftN = h->N * Z;
+  // ldpc_decoder.c:51-65
+  if (cdwd_rm_length > liftN - 2 * Z) {
+    cdwd_rm_length = liftN - 2 * Z;
+  }
+  if (cdwd_rm_length < (uint32_t)(h->K + 2) * Z) {
+    cdwd_rm_length = (h->K + 2) * Z;
+  }
+  if (cdwd_rm_length % Z) {
+    cdwd_rm_length = (cdwd_rm_length / Z + 1) * Z;
+  }
+  const int n_layers = (uint8_t)(cdwd_rm_length / Z - h->K + 2); // :73
+  if (n_cw > 1 && (llr_stride < liftN - 2 * Z || msg_stride < (uint32_t)h->K * Z)) {
+    set_error("ldpc batch: strides too small");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  ldpc::Params p;
+  p.llrs       = d_llrs;
+  p.msg        = d_message;
+  p.iter_msgs  = d_iter_msgs;
+  p.row_start  = h->d_row_start;
+  p.col        = h->d_col;
+  p.shift      = h->d_shift;
+  p.llr_stride = llr_stride;
+  p.msg_stride = msg_stride;
+  p.Z          = Z;
+  p.bgN        = h->N;
+  p.bgK        = h->K;
+  p.n_layers   = n_layers;
+  p.n_edges    = h->row_start[n_layers];
+  p.max_iter   = h->max_iter;
+  p.sf         = h->sf;
+  p.n_cw       = (int)n_cw;
+  p.cpb        = Z <= 128 ? (int)(256 / Z) : 1;
+  // keep the workgroup's LDS slab under 64 KB when several words share it
+  while (p.cpb > 1 && ldpc::lds_bytes(p) > 64 * 1024) {
+    p.cpb--;
+  }
+  PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ handle ABI
+
+namespace {
+struct LdpcCtx {
+  srsran_hip_ldpc_batch_t* b      = nullptr;
+  hipStream_t              stream = nullptr;
+  int8_t*                  d_llr  = nullptr;
+  uint8_t*                 d_msg  = nullptr;
+  uint8_t*                 d_iter = nullptr;
+  int8_t*                  h_llr  = nullptr; // pinned
+  uint8_t*                 h_msg  = nullptr; // pinned
+  uint8_t*                 h_iter = nullptr; // pinned
+};
+
+uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int len)
+{
+  // crc.c:92-140 restated bitwise: zero init, MSB first, a byte counts as 1 when (int8) > 0 (crc.c:117)
+  const uint64_t mask = ((((uint64_t)1 << (order - 1)) - 1) << 1) | 1;
+  const uint64_t high = (uint64_t)1 << (order - 1);
+  uint64_t       crc  = 0;
+  for (int i = 0; i < len; i++) {
+    uint64_t b   = ((int8_t)bits[i] > 0) ? 1 : 0;
+    uint64_t top = (crc & high) ? 1 : 0;
+    crc          = (crc << 1) & mask;
+    if (top ^ b) {
+      crc ^= (uint64_t)poly;
+    }
+  }
+  return (uint32_t)(crc & mask);
+}
+
+void ldpc_ctx_free(void* o)
+{
+  auto*    q = reinterpret_cast<srsran_ldpc_decoder_t*>(o);
+  LdpcCtx* c = reinterpret_cast<LdpcCtx*>(q->ptr);
+  if (c) {
+    srsran_hip_ldpc_batch_free(c->b);
+    hipFree(c->d_llr);
+    hipFree(c->d_msg);
+    hipFree(c->d_iter);
+    hipHostFree(c->h_llr);
+    hipHostFree(c->h_msg);
+    hipHostFree(c->h_iter);
+    if (c->stream) {
+      hipStreamDestroy(c->stream);
+    }
+    delete c;
+  }
+  if (q->pcm) {
+    free(q->pcm);
+  }
+  if (q->var_indices) {
+    free(q->var_indices);
+  }
+}
+
+int ldpc_decode_c(void* o, const int8_t* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc)
+{
+  auto*    q = reinterpret_cast<srsran_ldpc_decoder_t*>(o);
+  LdpcCtx* c = reinterpret_cast<LdpcCtx*>(q->ptr);
+  if (!c) {
+    return -1;
+  }
+  const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
+  const uint32_t liftK     = q->liftK;
+  const uint32_t msg_bytes = (liftK + 7) / 8;
+  memcpy(c->h_llr, llrs, n_llr);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr, hipMemcpyHostToDevice, c->stream), -1);
+  if (srsran_hip_ldpc_batch_run(c->b, c->d_llr, n_llr, c->d_msg, liftK, 1, cdwd_rm_length, crc ? c->d_iter : nullptr, c->stream)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
+    return -1;
+  }
+  if (!crc) {
+    PHY_HIP_CHECK(hipMemcpyAsync(c->h_msg, c->d_msg, liftK, hipMemcpyDeviceToHost, c->stream), -1);
+    PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
+    memcpy(message, c->h_msg, liftK);
+    return (int)q->max_nof_iter;
+  }
+  // CRC early stop (ldpc_decoder.c:87-99): the device ran every iteration and kept each iteration's
+  // hard decisions; the first one whose CRC matches is what the reference would have returned.
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_iter, c->d_iter, (size_t)msg_bytes * q->max_nof_iter, hipMemcpyDeviceToHost, c->stream), -1);
+  PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
+  for (uint32_t it = 0; it < q->max_nof_iter; it++) {
+    const uint8_t* pk = c->h_iter + (size_t)it * msg_bytes;
+    for (uint32_t i = 0; i < liftK; i++) {
+      message[i] = (pk[i >> 3] >> (7 - (i & 7))) & 1;
+    }
+    uint32_t c1 = crc_bits((uint32_t)crc->polynom, crc->order, message, (int)liftK - crc->order);
+    uint32_t c2 = 0;
+    for (int i = 0; i < crc->order; i++) {
+      c2 = (c2 << 1) | (message[liftK - crc->order + i] & 1);
+    }
+    if (c1 == c2) {
+      return (int)it + 1;
+    }
+  }
+  return 0;
+}
+} // namespace
+
+extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_ldpc_decoder_args_t* args)
+{
+  if (q == NULL || args == NULL) {
+    return -1;
+  }
+  BgDims d;
+  if (ls_index_of(args->ls) == VOID_LIFTSIZE) {
+    fprintf(stderr, "Invalid lifting size %d\n", args->ls);
+    return -1;
+  }
+  if (!bg_dims(args->bg, &d)) {
+    fprintf(stderr, "Base Graph BG%d does not exist\n", args->bg + 1);
+    return -1;
+  }
+  switch (args->type) {
+    case SRSRAN_LDPC_DECODER_C:
+    case SRSRAN_LDPC_DECODER_C_AVX2:
+    case SRSRAN_LDPC_DECODER_C_AVX512:
+      break; // one family: int8 layered min-sum, identical results in the reference
+    default:
+      fprintf(stderr, "[srsran_phy_hip] LDPC decoder type %d (float / int16 / flooded) is not implemented in the HIP engine\n", args->type);
+      return -1;
+  }
+  memset(q, 0, sizeof(*q));
+  q->bg           = args->bg;
+  q->bgN          = (uint8_t)d.N;
+  q->bgM          = (uint8_t)d.M;
+  q->bgK          = (uint8_t)d.K;
+  q->ls           = args->ls;
+  q->liftK        = (uint16_t)(args->ls * d.K);
+  q->liftM        = (uint16_t)(args->ls * d.M);
+  q->liftN        = (uint16_t)(args->ls * d.N);
+  q->max_nof_iter = args->max_nof_iter == 0 ? 10 : args->max_nof_iter;
+  q->pcm          = (uint16_t*)malloc(sizeof(uint16_t) * d.M * d.N);
+  q->var_indices  = (int8_t(*)[MAX_CNCT])malloc(sizeof(int8_t[MAX_CNCT]) * d.M);
+  if (!q->pcm || !q->var_indices || create_compact_pcm(q->pcm, q->var_indices, q->bg, q->ls)) {
+    free(q->pcm);
+    free(q->var_indices);
+    memset(q, 0, sizeof(*q));
+    return -1;
+  }
+  if (args->scaling_fctr <= 0 || args->scaling_fctr > 1) {
+    perror("The scaling factor of the min-sum algorithm should be larger than 0 and not larger than 1.");
+    free(q->pcm);
+    free(q->var_indices);
+    memset(q, 0, sizeof(*q));
+    return -1;
+  }
+  q->scaling_fctr = args->scaling_fctr;
+
+  auto* c = new LdpcCtx;
+  q->ptr  = c;
+  q->free = ldpc_ctx_free;
+  q->decode_c = ldpc_decode_c;
+  const uint32_t n_llr = q->liftN - 2 * q->ls, msg_bytes = (q->liftK + 7) / 8;
+  bool ok = srsran_hip_ldpc_batch_create(&c->b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, 1) == SRSRAN_SUCCESS &&
+            hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&c->d_llr, n_llr) == hipSuccess && hipMalloc(&c->d_msg, q->liftK) == hipSuccess &&
+            hipMalloc(&c->d_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess &&
+            hipHostMalloc(&c->h_llr, n_llr) == hipSuccess && hipHostMalloc(&c->h_msg, q->liftK) == hipSuccess &&
+            hipHostMalloc(&c->h_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_init: %s\n", get_error());
+    srsran_ldpc_decoder_free(q);
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" void srsran_ldpc_decoder_free(srsran_ldpc_decoder_t* q)
+{
+  if (q->free) {
+    q->free(q);
+  }
+  memset(q, 0, sizeof(srsran_ldpc_decoder_t));
+}
+
+extern "C" int srsran_ldpc_decoder_decode_f(srsran_ldpc_decoder_t* q, const float* llrs, uint8_t* message, uint32_t cdwd_rm_length)
+{
+  if (!q->decode_f) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_f: float decoder not implemented in the HIP engine\n");
+    return -1;
+  }
+  return q->decode_f(q, llrs, message, cdwd_rm_length, NULL);
+}
+
+extern "C" int srsran_ldpc_decoder_decode_s(srsran_ldpc_decoder_t* q, const int16_t* llrs, uint8_t* message, uint32_t cdwd_rm_length)
+{
+  if (!q->decode_s) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_s: int16 decoder not implemented in the HIP engine\n");
+    return -1;
+  }
+  return q->decode_s(q, llrs, message, cdwd_rm_length, NULL);
+}
+
+extern "C" int srsran_ldpc_decoder_decode_c(srsran_ldpc_decoder_t* q, const int8_t* llrs, uint8_t* message, uint32_t cdwd_rm_length)
+{
+  if (!q->decode_c) {
+    return -1;
+  }
+  return q->decode_c(q, llrs, message, cdwd_rm_length, NULL);
+}
+
+extern "C" int srsran_ldpc_decoder_decode_crc_c(srsran_ldpc_decoder_t* q, const int8_t* llrs, uint8_t* message,
+                                                uint32_t cdwd_rm_length, srsran_crc_t* crc)
+{
+  if (!q->decode_c) {
+    return -1;
+  }
+  return q->decode_c(q, llrs, message, cdwd_rm_length, crc);
+}

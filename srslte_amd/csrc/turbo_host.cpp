@@ -1,0 +1,537 @@
+// turbo_host.cpp -- host side of the turbo decoder: QPP tables, batch object, srsran_tdec_* handle ABI.
+//
+// Mirrors (interface + behaviour, not code) lib/src/phy/fec/turbo/turbodecoder.c, tc_interl_lte.c,
+// tc_interl_umts.c:51-90 (init/free) and lib/src/phy/fec/cbsegm.c:119-140 of the reference.
+#include "hip_common.h"
+#include "tables/lte_qpp_table.h"
+#include "turbo_device.h"
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace phyhip;
+
+// ------------------------------------------------------------------------------------------------ tables
+
+extern "C" int srsran_cbsegm_cbindex(uint32_t long_cb)
+{
+  // cbsegm.c:119-130: first table entry >= long_cb
+  int j = 0;
+  while (j < LTE_QPP_NOF_SIZES && lte_qpp_table[j][0] < long_cb) {
+    j++;
+  }
+  return (j == LTE_QPP_NOF_SIZES) ? SRSRAN_ERROR : j;
+}
+
+extern "C" int srsran_cbsegm_cbsize(uint32_t index)
+{
+  return (index < LTE_QPP_NOF_SIZES) ? (int)lte_qpp_table[index][0] : SRSRAN_ERROR;
+}
+
+extern "C" int srsran_tc_interl_init(srsran_tc_interl_t* h, uint32_t max_long_cb)
+{
+  h->max_long_cb = max_long_cb;
+  h->forward     = (uint16_t*)calloc(max_long_cb ? max_long_cb : 1, sizeof(uint16_t));
+  h->reverse     = (uint16_t*)calloc(max_long_cb ? max_long_cb : 1, sizeof(uint16_t));
+  if (!h->forward || !h->reverse) {
+    perror("malloc");
+    srsran_tc_interl_free(h);
+    return SRSRAN_ERROR;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_tc_interl_free(srsran_tc_interl_t* h)
+{
+  if (h->forward) {
+    free(h->forward);
+  }
+  if (h->reverse) {
+    free(h->reverse);
+  }
+  memset(h, 0, sizeof(*h));
+}
+
+// natural-order QPP permutation PI(i) = (f1 i + f2 i^2) mod K and its inverse
+static int qpp_natural(uint32_t K, std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev)
+{
+  int idx = srsran_cbsegm_cbindex(K);
+  if (idx < 0) {
+    return SRSRAN_ERROR;
+  }
+  const uint64_t f1 = lte_qpp_table[idx][1], f2 = lte_qpp_table[idx][2];
+  fwd.resize(K);
+  rev.resize(K);
+  for (uint64_t i = 0; i < K; i++) {
+    uint64_t j = (f1 * i + f2 * i * i) % K;
+    fwd[i]     = (uint16_t)j;
+    rev[j]     = (uint16_t)i;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_tc_interl_LTE_gen_interl(srsran_tc_interl_t* h, uint32_t long_cb, uint32_t interl_win)
+{
+  if (long_cb > h->max_long_cb) {
+    fprintf(stderr, "Interleaver initiated for max_long_cb=%d\n", h->max_long_cb);
+    return SRSRAN_ERROR;
+  }
+  std::vector<uint16_t> f, r;
+  if (qpp_natural(long_cb, f, r) || interl_win == 0 || long_cb % interl_win) {
+    fprintf(stderr, "Can't find long_cb=%d in valid TC CB table\n", long_cb);
+    return SRSRAN_ERROR;
+  }
+  if (interl_win == 1) {
+    memcpy(h->forward, f.data(), long_cb * sizeof(uint16_t));
+    memcpy(h->reverse, r.data(), long_cb * sizeof(uint16_t));
+  } else {
+    // tc_interl_lte.c:90-106: the same permutation seen through the [step][sub-block] lane order
+    const uint32_t sb = long_cb / interl_win;
+    for (uint32_t i = 0; i < long_cb; i++) {
+      uint32_t nat = (i % interl_win) * sb + i / interl_win;
+      uint32_t a = f[nat], b = r[nat];
+      h->forward[i] = (uint16_t)((a % sb) * interl_win + a / sb);
+      h->reverse[i] = (uint16_t)((b % sb) * interl_win + b / sb);
+    }
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_tc_interl_LTE_gen(srsran_tc_interl_t* h, uint32_t long_cb)
+{
+  return srsran_tc_interl_LTE_gen_interl(h, long_cb, 1);
+}
+
+extern "C" uint32_t srsran_tdec_autoimp_get_subblocks(uint32_t long_cb)
+{
+  // turbodecoder.c:381-393 on an AVX2 host.  MUST stay in step with the reference: srsran_rm_turbo_rx_lut
+  // picks its output layout from this value (rm_turbo.c:412-413).
+  if (!(long_cb % 16) && long_cb > 800) {
+    return 16;
+  } else if (!(long_cb % 8) && long_cb > 400) {
+    return 8;
+  }
+  return 0;
+}
+
+extern "C" uint32_t srsran_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb)
+{
+  // turbodecoder.c:410-424
+  if (!(long_cb % 32) && long_cb > 2048) {
+    return 32;
+  } else if (!(long_cb % 16) && long_cb > 800) {
+    return 16;
+  } else if (!(long_cb % 8) && long_cb > 400) {
+    return 8;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ batch object
+
+struct srsran_hip_tdec_batch {
+  uint32_t K       = 0;
+  uint32_t max_cb  = 0;
+  int      nb      = 0; // 16, 8 (window decoders) or 0 (scalar decoder)
+  // window decoder
+  uint32_t* d_ws     = nullptr;
+  uint32_t  ws_stride = 0;
+  uint32_t* d_deint  = nullptr;
+  uint32_t* d_inter  = nullptr;
+  // scalar decoder
+  short*    d_ws_gen    = nullptr;
+  uint16_t* d_inter16   = nullptr;
+  uint16_t* d_deinter16 = nullptr;
+  // optional parity aid
+  short* d_dec_llr = nullptr;
+};
+
+static int impl_to_nb(int impl, uint32_t K, int* nb)
+{
+  switch (impl) {
+    case SRSRAN_TDEC_AUTO:
+      *nb = (int)srsran_tdec_autoimp_get_subblocks(K);
+      return 0;
+    case SRSRAN_TDEC_GENERIC:
+      *nb = 0;
+      return 0;
+    case SRSRAN_TDEC_SSE_WINDOW:
+      *nb = 8;
+      return 0;
+    case SRSRAN_TDEC_AVX_WINDOW:
+      *nb = 16;
+      return 0;
+    default:
+      return -1;
+  }
+}
+
+extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl)
+{
+  if (!hh || max_nof_cb == 0) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *hh = nullptr;
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  int idx = srsran_cbsegm_cbindex(long_cb);
+  if (idx < 0 || (uint32_t)srsran_cbsegm_cbsize(idx) != long_cb) {
+    set_error("invalid turbo code block size %u", long_cb);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  int nb = 0;
+  if (impl_to_nb(impl, long_cb, &nb)) {
+    set_error("turbo decoder implementation %d not supported by the HIP engine", impl);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (nb && (long_cb % nb || long_cb / nb < 40)) {
+    // the reference's window decoders read out of bounds in this case (40-step warm-up > sub-block)
+    set_error("window decoder with %d sub-blocks is invalid for K=%u", nb, long_cb);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  auto* h   = new srsran_hip_tdec_batch;
+  h->K      = long_cb;
+  h->max_cb = max_nof_cb;
+  h->nb     = nb;
+  std::vector<uint16_t> f, r;
+  qpp_natural(long_cb, f, r);
+  const uint32_t K = long_cb;
+  if (nb) {
+    const uint32_t lpc = nb / 2, long_sb = K / nb, nblk = (long_sb + 7) / 8;
+    h->ws_stride = turbo::win_ws_dwords(K, nb);
+    std::vector<uint32_t> deint(nblk * lpc * 8, 0), inter(nblk * lpc * 8, 0);
+    for (uint32_t k = 0; k < long_sb; k++) {
+      for (uint32_t d = 0; d < (uint32_t)nb; d++) {
+        uint32_t n  = d * long_sb + k;                        // natural position of (step k, sub-block d)
+        uint32_t e  = turbo::win_elem_index(nb, k, d);        // where that element lives
+        uint32_t td = r[n], ti = f[n];                        // app2[rev[n]] = ext1[n]; app1[fwd[n]] = ext2[n]
+        uint32_t ed = turbo::win_elem_index(nb, td % long_sb, td / long_sb);
+        uint32_t ei = turbo::win_elem_index(nb, ti % long_sb, ti / long_sb);
+        deint[e >> 1] |= ed << (16 * (e & 1));
+        inter[e >> 1] |= ei << (16 * (e & 1));
+      }
+    }
+    size_t tb = deint.size() * sizeof(uint32_t);
+    PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * max_nof_cb * sizeof(uint32_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_deint, tb), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_inter, tb), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_deint, deint.data(), tb, hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_inter, inter.data(), tb, hipMemcpyHostToDevice), SRSRAN_ERROR);
+  } else {
+    size_t nwaves = ceil_div(max_nof_cb, 64);
+    PHY_HIP_CHECK(hipMalloc(&h->d_ws_gen, turbo::gen_ws_shorts(K) * nwaves * sizeof(short)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_inter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_deinter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_inter16, f.data(), K * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_deinter16, r.data(), K * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  }
+  *hh = h;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
+{
+  if (!h) {
+    return;
+  }
+  hipFree(h->d_ws);
+  hipFree(h->d_deint);
+  hipFree(h->d_inter);
+  hipFree(h->d_ws_gen);
+  hipFree(h->d_inter16);
+  hipFree(h->d_deinter16);
+  hipFree(h->d_dec_llr);
+  delete h;
+}
+
+// run half iterations [n_begin, n_end) and take the hard decision for n_iter = n_end
+static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const int16_t* d_input, uint32_t in_stride, uint8_t* d_output,
+                                uint32_t out_stride, uint32_t n_cb, uint32_t n_begin, uint32_t n_end, int sb_layout,
+                                bool want_llr, hipStream_t stream)
+{
+  if (!h || !d_output || (!d_input && n_begin == 0) || n_cb == 0 || n_cb > h->max_cb || n_end <= n_begin) {
+    set_error("tdec batch: invalid arguments (n_cb=%u max=%u)", n_cb, h ? h->max_cb : 0);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (sb_layout && !h->nb) {
+    set_error("tdec batch: sub-block input layout needs a window decoder");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  const uint32_t need_in = sb_layout ? 3 * (h->K + 32) + 12 : 3 * h->K + 12;
+  if ((n_cb > 1 && (in_stride < need_in || out_stride < h->K / 8))) {
+    set_error("tdec batch: strides too small");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (want_llr && !h->d_dec_llr) {
+    PHY_HIP_CHECK(hipMalloc(&h->d_dec_llr, (size_t)h->K * h->max_cb * sizeof(short)), SRSRAN_ERROR);
+  }
+  if (h->nb) {
+    turbo::WinParams p;
+    p.input      = d_input;
+    p.output     = d_output;
+    p.dec_llr    = want_llr ? h->d_dec_llr : nullptr;
+    p.ws         = h->d_ws;
+    p.deint      = h->d_deint;
+    p.inter      = h->d_inter;
+    p.in_stride  = in_stride;
+    p.out_stride = out_stride;
+    p.ws_stride  = h->ws_stride;
+    p.K          = h->K;
+    p.n_begin    = n_begin;
+    p.n_end      = n_end;
+    p.n_cb       = (int)n_cb;
+    p.sb_layout  = sb_layout;
+    PHY_HIP_CHECK(turbo::launch_win(h->nb, p, stream), SRSRAN_ERROR);
+  } else {
+    turbo::GenParams p;
+    p.input      = d_input;
+    p.output     = d_output;
+    p.dec_llr    = want_llr ? h->d_dec_llr : nullptr;
+    p.ws         = h->d_ws_gen;
+    p.inter      = h->d_inter16;
+    p.deinter    = h->d_deinter16;
+    p.ws_stride  = turbo::gen_ws_shorts(h->K);
+    p.in_stride  = in_stride;
+    p.out_stride = out_stride;
+    p.K          = h->K;
+    p.n_begin    = n_begin;
+    p.n_end      = n_end;
+    p.n_cb       = (int)n_cb;
+    PHY_HIP_CHECK(turbo::launch_gen(p, stream), SRSRAN_ERROR);
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_tdec_batch_run(srsran_hip_tdec_batch_t* h, const int16_t* d_input, uint32_t in_stride,
+                                         uint8_t* d_output, uint32_t out_stride, uint32_t n_cb,
+                                         uint32_t nof_iterations, int sb_layout, void* stream)
+{
+  // turbodecoder.c:542-544 is a do/while: at least one half iteration runs
+  uint32_t nit = nof_iterations ? nof_iterations : 1;
+  return tdec_batch_run_range(h, d_input, in_stride, d_output, out_stride, n_cb, 0, nit, sb_layout, false, (hipStream_t)stream);
+}
+
+extern "C" int srsran_hip_tdec_batch_last_llr(srsran_hip_tdec_batch_t* h, int16_t* d_llr, uint32_t n_cb, void* stream)
+{
+  if (!h || !h->d_dec_llr || n_cb > h->max_cb) {
+    set_error("tdec batch: no decision LLRs recorded (run with the debug entry point first)");
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(d_llr, h->d_dec_llr, (size_t)h->K * n_cb * sizeof(short), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream),
+                SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+// debug/parity entry point (not in the public header on purpose: tests bind it by name)
+extern "C" SRSRAN_API int srsran_hip_tdec_batch_run_dbg(srsran_hip_tdec_batch_t* h, const int16_t* d_input,
+                                                        uint32_t in_stride, uint8_t* d_output, uint32_t out_stride,
+                                                        uint32_t n_cb, uint32_t n_begin, uint32_t n_end, int sb_layout,
+                                                        void* stream)
+{
+  return tdec_batch_run_range(h, d_input, in_stride, d_output, out_stride, n_cb, n_begin, n_end, sb_layout, true, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ handle ABI
+
+namespace {
+struct TdecCtx {
+  hipStream_t stream = nullptr;
+  // one batch object (max_cb = 1) per (K, nb), created on first use
+  std::map<uint64_t, srsran_hip_tdec_batch_t*> dec;
+  int16_t* d_in  = nullptr; // 3*(Kmax+32)+12
+  uint8_t* d_out = nullptr; // Kmax/8
+  int16_t* h_in  = nullptr; // pinned
+  uint8_t* h_out = nullptr; // pinned
+  size_t   in_cap = 0;
+};
+
+TdecCtx* ctx_of(srsran_tdec_t* h)
+{
+  return reinterpret_cast<TdecCtx*>(h->dec16_hdlr[0]);
+}
+} // namespace
+
+extern "C" int srsran_tdec_init(srsran_tdec_t* h, uint32_t max_long_cb)
+{
+  return srsran_tdec_init_manual(h, max_long_cb, SRSRAN_TDEC_AUTO);
+}
+
+extern "C" int srsran_tdec_init_manual(srsran_tdec_t* h, uint32_t max_long_cb, srsran_tdec_impl_type_t dec_type)
+{
+  memset(h, 0, sizeof(srsran_tdec_t)); // turbodecoder.c:150
+  switch (dec_type) {
+    case SRSRAN_TDEC_AUTO:
+    case SRSRAN_TDEC_GENERIC:
+    case SRSRAN_TDEC_SSE_WINDOW:
+    case SRSRAN_TDEC_AVX_WINDOW:
+      break;
+    default:
+      // SSE (non-window), NEON and the 8-bit decoders are not reproduced by the HIP engine (yet)
+      fprintf(stderr, "Error decoder %d not supported\n", dec_type);
+      return SRSRAN_ERROR;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  h->dec_type         = dec_type;
+  h->max_long_cb      = max_long_cb;
+  h->current_llr_type = SRSRAN_TDEC_16;
+  h->current_cbidx    = -1;
+  if (dec_type == SRSRAN_TDEC_AUTO) {
+    // what the reference's tdec_init() of gen / sse16win / avx16win return (turbodecoder.c:252-258)
+    h->nof_blocks16[0] = 1;
+    h->nof_blocks16[1] = 8;
+    h->nof_blocks16[2] = 16;
+    h->nof_blocks8[0]  = 16;
+    h->nof_blocks8[1]  = 32;
+  } else {
+    h->nof_blocks16[0] = dec_type == SRSRAN_TDEC_GENERIC ? 1 : (dec_type == SRSRAN_TDEC_SSE_WINDOW ? 8 : 16);
+  }
+  auto* c   = new TdecCtx;
+  c->in_cap = 3 * ((size_t)max_long_cb + 32) + 12;
+  PHY_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMalloc(&c->d_in, c->in_cap * sizeof(int16_t)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMalloc(&c->d_out, max_long_cb / 8 + 8), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipHostMalloc(&c->h_in, c->in_cap * sizeof(int16_t)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipHostMalloc(&c->h_out, max_long_cb / 8 + 8), SRSRAN_ERROR);
+  h->dec16_hdlr[0] = c;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_tdec_free(srsran_tdec_t* h)
+{
+  TdecCtx* c = ctx_of(h);
+  if (c) {
+    for (auto& kv : c->dec) {
+      srsran_hip_tdec_batch_free(kv.second);
+    }
+    hipFree(c->d_in);
+    hipFree(c->d_out);
+    hipHostFree(c->h_in);
+    hipHostFree(c->h_out);
+    if (c->stream) {
+      hipStreamDestroy(c->stream);
+    }
+    delete c;
+  }
+  memset(h, 0, sizeof(srsran_tdec_t)); // turbodecoder.c:362
+}
+
+extern "C" void srsran_tdec_force_not_sb(srsran_tdec_t* h)
+{
+  h->force_not_sb = true;
+}
+
+extern "C" int srsran_tdec_new_cb(srsran_tdec_t* h, uint32_t long_cb)
+{
+  if (long_cb > h->max_long_cb) {
+    fprintf(stderr, "TDEC was initialized for max_long_cb=%d\n", h->max_long_cb);
+    return -1;
+  }
+  h->n_iter          = 0;
+  h->current_long_cb = long_cb;
+  h->current_cbidx   = srsran_cbsegm_cbindex(long_cb);
+  if (h->current_cbidx < 0) {
+    fprintf(stderr, "Invalid CB length %d\n", long_cb);
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" int srsran_tdec_get_nof_iterations(srsran_tdec_t* h)
+{
+  return h->n_iter;
+}
+
+// one half iteration on the device + hard decision into `output` (turbodecoder.c:495-533)
+static void tdec_handle_iterate(srsran_tdec_t* h, int16_t* input, uint8_t* output, uint32_t n_end)
+{
+  TdecCtx* c = ctx_of(h);
+  if (!c) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tdec: handle not initialised\n");
+    return;
+  }
+  const uint32_t K = h->current_long_cb;
+  if ((uint32_t)srsran_cbsegm_cbsize(h->current_cbidx) != K) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tdec: K=%u is not a valid turbo block size\n", K);
+    return;
+  }
+  int nb = 0;
+  impl_to_nb(h->dec_type, K, &nb);
+  // input layout, turbodecoder_iter.h:88 : AUTO + window decoder + !force_not_sb -> rm_turbo sub-block layout
+  const int sb_layout = (h->dec_type == SRSRAN_TDEC_AUTO && nb > 0 && !h->force_not_sb) ? 1 : 0;
+  h->current_dec       = h->dec_type == SRSRAN_TDEC_AUTO ? (nb == 16 ? 2 : (nb == 8 ? 1 : 0)) : 0;
+  h->current_inter_idx = nb == 16 ? 2 : (nb == 8 ? 1 : 0);
+
+  uint64_t key = ((uint64_t)K << 8) | (uint64_t)nb;
+  auto     it  = c->dec.find(key);
+  if (it == c->dec.end()) {
+    srsran_hip_tdec_batch_t* b = nullptr;
+    int impl = nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC);
+    if (srsran_hip_tdec_batch_create(&b, K, 1, impl)) {
+      fprintf(stderr, "[srsran_phy_hip] srsran_tdec: %s\n", get_error());
+      return;
+    }
+    it = c->dec.emplace(key, b).first;
+  }
+  const uint32_t n_begin = (uint32_t)h->n_iter;
+  const size_t   in_len  = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
+  if (n_begin == 0) {
+    memcpy(c->h_in, input, in_len * sizeof(int16_t));
+    if (sb_layout) {
+      // the reference writes the tail into the caller's buffer here (turbodecoder_iter.h:58-70,92-96)
+      for (uint32_t i = K; i < K + 3; i++) {
+        input[i]          = input[3 * (K + 32) + 2 * (i - K)];
+        input[K + 32 + i] = input[3 * (K + 32) + 2 * (i - K) + 1];
+      }
+    }
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, in_len * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+  }
+  if (tdec_batch_run_range(it->second, c->d_in, (uint32_t)in_len, c->d_out, K / 8, 1, n_begin, n_end, sb_layout, false,
+                           c->stream)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tdec: %s\n", get_error());
+    return;
+  }
+  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, K / 8, hipMemcpyDeviceToHost, c->stream));
+  PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
+  memcpy(output, c->h_out, K / 8);
+  h->n_iter = (int)n_end;
+}
+
+extern "C" void srsran_tdec_iteration(srsran_tdec_t* h, int16_t* input, uint8_t* output)
+{
+  if (h->current_cbidx >= 0) {
+    tdec_handle_iterate(h, input, output, (uint32_t)h->n_iter + 1);
+  }
+}
+
+extern "C" int srsran_tdec_run_all(srsran_tdec_t* h, int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{
+  if (srsran_tdec_new_cb(h, long_cb)) {
+    return SRSRAN_ERROR;
+  }
+  tdec_handle_iterate(h, input, output, nof_iterations ? nof_iterations : 1);
+  return h->n_iter ? SRSRAN_SUCCESS : SRSRAN_ERROR;
+}
+
+extern "C" void srsran_tdec_iteration_8bit(srsran_tdec_t* h, int8_t* input, uint8_t* output)
+{
+  (void)h;
+  (void)input;
+  (void)output;
+  fprintf(stderr, "[srsran_phy_hip] srsran_tdec_iteration_8bit: 8-bit LLR decoders are not implemented in the HIP engine\n");
+}
+
+extern "C" int srsran_tdec_run_all_8bit(srsran_tdec_t* h, int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{
+  (void)h;
+  (void)input;
+  (void)output;
+  (void)nof_iterations;
+  (void)long_cb;
+  fprintf(stderr, "[srsran_phy_hip] srsran_tdec_run_all_8bit: 8-bit LLR decoders are not implemented in the HIP engine\n");
+  return SRSRAN_ERROR;
+}

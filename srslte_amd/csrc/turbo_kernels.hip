@@ -1,0 +1,788 @@
+// turbo_kernels.hip -- LTE turbo decoder (max-log-MAP SISO + QPP interleaver) for gfx950.
+//
+// Bit-exact re-design of the decoders srsran_tdec_run_all() dispatches to on an AVX2 host
+// (reference: lib/src/phy/fec/turbo/turbodecoder.c:381-408):
+//   * window decoder, 16 sub-blocks  (turbodecoder_win.h, WINIMP_IS_AVX16)  K%16==0 && K>800
+//   * window decoder,  8 sub-blocks  (turbodecoder_win.h, WINIMP_IS_SSE16)  K%8==0  && K>400
+//   * scalar decoder                 (turbodecoder_gen.c)                   otherwise
+//
+// MI355X mapping (not the SIMD layout of the reference):
+//   * one lane owns TWO adjacent sub-blocks of one code block, packed as int16x2 in one VGPR; all 8
+//     trellis states of both live in 8 VGPRs -> the ACS recursion is v_pk_add_i16(clamp)/v_pk_max_i16
+//     with no cross-lane traffic; a code block is 8 lanes (16 sub-blocks) or 4 lanes (8 sub-blocks),
+//     a wave decodes 8 or 16 code blocks in lock step.
+//   * state metrics of the backward recursion are NOT stored for every step (that is 16 B per
+//     trellis step, 196 KB of HBM traffic per half iteration at K=6144): the beta pass keeps one
+//     check-point per 8 steps and the forward pass re-derives the 7 steps in between into registers
+//     (bit-identical because the normalisation schedule is replayed exactly).
+//   * per-code-block vectors live in HBM in a blocked layout [step/8][lane][step%8] of int16x2, so a
+//     lane fetches 8 trellis steps with two dwordx4 loads and 8 lanes of a block read 256 contiguous
+//     bytes.
+//   * extrinsic exchange (turbodecoder_iter.h:104-128) is fused into the forward pass: a-priori
+//     subtraction on load, QPP scatter on store.
+#include "hip_common.h"
+#include "turbo_device.h"
+
+namespace phyhip {
+namespace turbo {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+#define TD_INF 10000 // turbodecoder_win.h:56 / turbodecoder_gen.c:37
+#define TD_WIN_OVERLAP 40
+
+__device__ __forceinline__ s2 adds(s2 a, s2 b)
+{
+  return __builtin_elementwise_add_sat(a, b);
+}
+__device__ __forceinline__ s2 subs(s2 a, s2 b)
+{
+  return __builtin_elementwise_sub_sat(a, b);
+}
+__device__ __forceinline__ s2 vmax(s2 a, s2 b)
+{
+  return __builtin_elementwise_max(a, b);
+}
+__device__ __forceinline__ s2 from_u(uint32_t u)
+{
+  return __builtin_bit_cast(s2, u);
+}
+__device__ __forceinline__ uint32_t to_u(s2 v)
+{
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ s2 splat(short v)
+{
+  s2 r = {v, v};
+  return r;
+}
+
+// turbodecoder_win.h:480-498 (normalize_period 2; caller checks the step index)
+__device__ __forceinline__ void normalize(s2 (&o)[8])
+{
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    o[i] = subs(o[i], o[0]);
+  }
+  o[0] = splat(0);
+}
+
+// one backward step, turbodecoder_win.h:626-652
+__device__ __forceinline__ void beta_step(s2 (&o)[8], s2 x, s2 y)
+{
+  s2 xy = adds(x, y);
+  s2 n0 = vmax(adds(o[4], xy), o[0]);
+  s2 n1 = vmax(o[4], adds(o[0], xy));
+  s2 n2 = vmax(adds(o[5], y), adds(o[1], x));
+  s2 n3 = vmax(adds(o[5], x), adds(o[1], y));
+  s2 n4 = vmax(adds(o[6], x), adds(o[2], y));
+  s2 n5 = vmax(adds(o[6], y), adds(o[2], x));
+  s2 n6 = vmax(o[7], adds(o[3], xy));
+  s2 n7 = vmax(adds(o[7], xy), o[3]);
+  o[0] = n0;
+  o[1] = n1;
+  o[2] = n2;
+  o[3] = n3;
+  o[4] = n4;
+  o[5] = n5;
+  o[6] = n6;
+  o[7] = n7;
+}
+
+// one forward step, turbodecoder_win.h:753-826.  WITH_LLR: also max1-max0 using the beta of the next step.
+template <bool WITH_LLR>
+__device__ __forceinline__ s2 alpha_step(s2 (&o)[8], const s2 (&b)[8], s2 x, s2 y)
+{
+  s2 xy = adds(x, y);
+  s2 m_b[8], nw[8];
+  m_b[0] = o[0];
+  m_b[1] = adds(o[3], y);
+  m_b[2] = adds(o[4], y);
+  m_b[3] = o[7];
+  m_b[4] = o[1];
+  m_b[5] = adds(o[2], y);
+  m_b[6] = adds(o[5], y);
+  m_b[7] = o[6];
+  nw[0] = adds(o[1], xy);
+  nw[1] = adds(o[2], x);
+  nw[2] = adds(o[5], x);
+  nw[3] = adds(o[6], xy);
+  nw[4] = adds(o[0], xy);
+  nw[5] = adds(o[3], x);
+  nw[6] = adds(o[4], x);
+  nw[7] = adds(o[7], xy);
+  s2 out = splat(0);
+  if (WITH_LLR) {
+    s2 m0 = adds(b[0], m_b[0]);
+    s2 m1 = adds(b[0], nw[0]);
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      m0 = vmax(m0, adds(b[i], m_b[i]));
+      m1 = vmax(m1, adds(b[i], nw[i]));
+    }
+    out = subs(m1, m0);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    o[i] = vmax(m_b[i], nw[i]);
+  }
+  return out;
+}
+
+__device__ __forceinline__ short wrap16(int v)
+{
+  return (short)v;
+}
+
+// turbodecoder_win.h:500-548: start state of the last sub-block from the 3 tail steps (plain adds)
+__device__ __forceinline__ void tail_trellis(const short* xt, const short* yt, short (&old)[8])
+{
+  old[0] = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) {
+    old[i] = -TD_INF;
+  }
+#pragma unroll
+  for (int k = 2; k >= 0; k--) {
+    short x = xt[k], y = yt[k];
+    short xy = wrap16(x + y);
+    short m_b[8], nw[8];
+    m_b[0] = wrap16(old[4] + xy);
+    m_b[1] = old[4];
+    m_b[2] = wrap16(old[5] + y);
+    m_b[3] = wrap16(old[5] + x);
+    m_b[4] = wrap16(old[6] + x);
+    m_b[5] = wrap16(old[6] + y);
+    m_b[6] = old[7];
+    m_b[7] = wrap16(old[7] + xy);
+    nw[0] = old[0];
+    nw[1] = wrap16(old[0] + xy);
+    nw[2] = wrap16(old[1] + x);
+    nw[3] = wrap16(old[1] + y);
+    nw[4] = wrap16(old[2] + y);
+    nw[5] = wrap16(old[2] + x);
+    nw[6] = wrap16(old[3] + xy);
+    nw[7] = old[3];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      old[i] = m_b[i] > nw[i] ? m_b[i] : nw[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void load_block(const uint32_t* arr, uint32_t blk_lane, uint32_t (&r)[8])
+{
+  const uint4* q = reinterpret_cast<const uint4*>(arr + (size_t)blk_lane * 8);
+  uint4        a = q[0], c = q[1];
+  r[0] = a.x;
+  r[1] = a.y;
+  r[2] = a.z;
+  r[3] = a.w;
+  r[4] = c.x;
+  r[5] = c.y;
+  r[6] = c.z;
+  r[7] = c.w;
+}
+
+__device__ __forceinline__ void store_block(uint32_t* arr, uint32_t blk_lane, const uint32_t (&r)[8])
+{
+  uint4* q = reinterpret_cast<uint4*>(arr + (size_t)blk_lane * 8);
+  q[0]     = make_uint4(r[0], r[1], r[2], r[3]);
+  q[1]     = make_uint4(r[4], r[5], r[6], r[7]);
+}
+
+// Blocked int16 index of trellis step k of sub-block d (LPC lanes per code block)
+template <int LPC>
+__host__ __device__ __forceinline__ uint32_t elem_index(uint32_t k, uint32_t d)
+{
+  return ((((k >> 3) * LPC + (d >> 1)) * 8 + (k & 7)) << 1) + (d & 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Windowed decoder kernel: one wave per 64/LPC code blocks, whole srsran_tdec_run_all in one launch.
+// ------------------------------------------------------------------------------------------------
+template <int LPC>
+__global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
+{
+  constexpr int NB  = 2 * LPC;
+  constexpr int CPW = 64 / LPC;
+  const int     lane = threadIdx.x;
+  const int     pl   = lane % LPC;
+  const int     cb   = blockIdx.x * CPW + lane / LPC;
+  if (cb >= p.n_cb) {
+    return; // whole lane group leaves together
+  }
+  const uint32_t K       = p.K;
+  const uint32_t long_sb = K / NB;
+  const uint32_t nblk    = (long_sb + 7) >> 3;
+  const uint32_t AW      = nblk * LPC * 8;
+
+  uint32_t* ws  = p.ws + (size_t)cb * p.ws_stride;
+  uint32_t* S   = ws;
+  uint32_t* P0  = ws + AW;
+  uint32_t* P1  = ws + 2 * AW;
+  uint32_t* A1  = ws + 3 * AW;
+  uint32_t* E1  = ws + 4 * AW;
+  uint32_t* A2  = ws + 5 * AW;
+  uint32_t* CK  = ws + 6 * AW;
+  short*    TL  = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * LPC * 8); // 12 tail LLRs
+
+  // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102)
+  if (p.n_begin == 0) {
+    const short* in = p.input + (size_t)cb * p.in_stride;
+    for (uint32_t b = 0; b < nblk; b++) {
+      uint32_t s[8], y0[8], y1[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        uint32_t k = b * 8 + j;
+        uint32_t vs = 0, v0 = 0, v1 = 0;
+        if (k < long_sb) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            uint32_t d = 2 * pl + h;
+            short    a, bq, c;
+            if (p.sb_layout) {
+              uint32_t i = k * NB + d;
+              a  = in[i];
+              bq = in[K + 32 + i];
+              c  = in[2 * (K + 32) + i];
+            } else {
+              uint32_t n = d * long_sb + k;
+              a  = in[3 * n];
+              bq = in[3 * n + 1];
+              c  = in[3 * n + 2];
+            }
+            vs |= (uint32_t)(uint16_t)a << (16 * h);
+            v0 |= (uint32_t)(uint16_t)bq << (16 * h);
+            v1 |= (uint32_t)(uint16_t)c << (16 * h);
+          }
+        }
+        s[j]  = vs;
+        y0[j] = v0;
+        y1[j] = v1;
+      }
+      store_block(S, b * LPC + pl, s);
+      store_block(P0, b * LPC + pl, y0);
+      store_block(P1, b * LPC + pl, y1);
+    }
+    if (pl == 0) {
+      const uint32_t tb = p.sb_layout ? 3 * (K + 32) : 3 * K;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        TL[i]     = in[tb + 2 * i];         // syst tail
+        TL[3 + i] = in[tb + 2 * i + 1];     // parity0 tail
+        TL[6 + i] = in[tb + 6 + 2 * i];     // app2 tail
+        TL[9 + i] = in[tb + 6 + 2 * i + 1]; // parity1 tail
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- half iterations (turbodecoder_iter.h:72-141)
+  for (uint32_t n = p.n_begin; n < p.n_end; n++) {
+    const bool      dec1    = !(n & 1);
+    const bool      has_app = dec1 && n > 0;
+    const uint32_t* X       = dec1 ? S : A2;
+    const uint32_t* Y       = dec1 ? P0 : P1;
+    const short*    xt      = dec1 ? TL : TL + 6;
+    const short*    yt      = dec1 ? TL + 3 : TL + 9;
+
+    s2 o[8];
+    // ================= backward recursion (turbodecoder_win.h:551-681)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      o[i] = splat(-TD_INF);
+    }
+    // pass 0: 40 steps on the head of every sub-block, all states unknown
+    for (int b = TD_WIN_OVERLAP / 8 - 1; b >= 0; b--) {
+      uint32_t xr[8], yr[8], ar[8], er[8];
+      load_block(X, b * LPC + pl, xr);
+      load_block(Y, b * LPC + pl, yr);
+      if (has_app) {
+        load_block(A1, b * LPC + pl, ar);
+        load_block(E1, b * LPC + pl, er);
+      }
+#pragma unroll
+      for (int j = 7; j >= 0; j--) {
+        s2 x = from_u(xr[j]);
+        if (has_app) {
+          x = adds(from_u(ar[j]) - from_u(er[j]), x);
+        }
+        beta_step(o, x, from_u(yr[j]));
+        uint32_t k = b * 8 + j;
+        if ((k & 1) == 0 && k != 0) {
+          normalize(o);
+        }
+      }
+    }
+    // hand every estimate to the previous sub-block; the last one starts from the tail trellis
+    {
+      short tr[8];
+      tail_trellis(xt, yt, tr);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        uint32_t u   = to_u(o[i]);
+        uint32_t nxt = __shfl_down(u, 1, LPC);
+        uint32_t lo  = u >> 16;
+        uint32_t hi  = (pl == LPC - 1) ? (uint32_t)(uint16_t)tr[i] : (nxt & 0xffffu);
+        o[i]         = from_u(lo | (hi << 16));
+      }
+      uint32_t ck[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ck[i] = to_u(o[i]);
+      }
+      store_block(CK, nblk * LPC + pl, ck);
+    }
+    // pass 1: whole sub-block, keep a check-point at every block boundary
+    for (int b = (int)nblk - 1; b >= 0; b--) {
+      uint32_t xr[8], yr[8], ar[8], er[8];
+      load_block(X, b * LPC + pl, xr);
+      load_block(Y, b * LPC + pl, yr);
+      if (has_app) {
+        load_block(A1, b * LPC + pl, ar);
+        load_block(E1, b * LPC + pl, er);
+      }
+#pragma unroll
+      for (int j = 7; j >= 0; j--) {
+        uint32_t k = b * 8 + j;
+        if (k < long_sb) {
+          s2 x = from_u(xr[j]);
+          if (has_app) {
+            x = adds(from_u(ar[j]) - from_u(er[j]), x);
+          }
+          beta_step(o, x, from_u(yr[j]));
+          if (j == 0 && b > 0) {
+            uint32_t ck[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              ck[i] = to_u(o[i]);
+            }
+            store_block(CK, b * LPC + pl, ck);
+          }
+          if ((k & 1) == 0 && k != 0) {
+            normalize(o);
+          }
+        }
+      }
+    }
+    __syncthreads(); // check-points visible (same wave wrote them; orders the stores before the loads)
+
+    // ================= forward recursion + LLR (turbodecoder_win.h:684-832)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      o[i] = splat(-TD_INF);
+    }
+    {
+      const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
+      for (uint32_t b = w0 >> 3; b <= (long_sb - 1) >> 3; b++) {
+        uint32_t xr[8], yr[8], ar[8], er[8];
+        load_block(X, b * LPC + pl, xr);
+        load_block(Y, b * LPC + pl, yr);
+        if (has_app) {
+          load_block(A1, b * LPC + pl, ar);
+          load_block(E1, b * LPC + pl, er);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          uint32_t k = b * 8 + j;
+          if (k >= w0 && k < long_sb) {
+            s2 x = from_u(xr[j]);
+            if (has_app) {
+              x = adds(from_u(ar[j]) - from_u(er[j]), x);
+            }
+            alpha_step<false>(o, o, x, from_u(yr[j]));
+            uint32_t kk = k - w0;
+            if ((kk & 1) == 0 && kk != 0) {
+              normalize(o);
+            }
+          }
+        }
+      }
+    }
+    // hand every estimate to the next sub-block; the first one starts in state 0
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t u   = to_u(o[i]);
+      uint32_t prv = __shfl_up(u, 1, LPC);
+      uint32_t lo  = (pl == 0) ? (uint32_t)(uint16_t)(short)(i ? -TD_INF : 0) : (prv >> 16);
+      uint32_t hi  = u & 0xffffu;
+      o[i]         = from_u(lo | (hi << 16));
+    }
+
+    const uint32_t* lut  = dec1 ? p.deint : p.inter;   // blocked-layout scatter tables
+    short*          dsts = reinterpret_cast<short*>(dec1 ? A2 : A1);
+    // ext1 -= app1 of the next half iteration (turbodecoder_iter.h:115) is applied here, always: the
+    // kernel is resumable and cannot know whether another half iteration follows.  The raw LLR the
+    // decision needs after an odd number of half iterations is recovered as E1 + A1 (exact, wrapping).
+    const bool      fuse = dec1 && n >= 2;
+
+    for (uint32_t b = 0; b < nblk; b++) {
+      const int len = (long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
+      uint32_t  xr[8], yr[8], ar[8], er[8], ck[8];
+      load_block(X, b * LPC + pl, xr);
+      load_block(Y, b * LPC + pl, yr);
+      if (has_app) {
+        load_block(A1, b * LPC + pl, ar);
+        load_block(E1, b * LPC + pl, er);
+      }
+      load_block(CK, (b + 1) * LPC + pl, ck);
+      s2 xs[8], ap[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        xs[j] = from_u(xr[j]);
+        ap[j] = splat(0);
+        if (has_app) {
+          ap[j] = from_u(ar[j]) - from_u(er[j]); // srsran_vec_sub_sss: wrapping
+          xs[j] = adds(ap[j], xs[j]);
+        }
+      }
+      // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point
+      s2 B[8][8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (j == len - 1) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            B[j][i] = from_u(ck[i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 6; j >= 0; j--) {
+        if (j <= len - 2) {
+          s2 st[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            st[i] = B[j + 1][i];
+          }
+          uint32_t idx = b * 8 + j + 2; // index of the stored value we start from
+          if (idx != long_sb && (idx & 1) == 0) {
+            normalize(st);
+          }
+          beta_step(st, xs[j + 1], from_u(yr[j + 1]));
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            B[j][i] = st[i];
+          }
+        }
+      }
+      uint32_t outv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        outv[j] = 0;
+        if (j < len) {
+          s2       llr = alpha_step<true>(o, B[j], xs[j], from_u(yr[j]));
+          uint32_t k   = b * 8 + j;
+          if ((k & 1) == 0 && k != 0) {
+            normalize(o);
+          }
+          if (fuse) {
+            llr = llr - ap[j];
+          }
+          outv[j] = to_u(llr);
+        }
+      }
+      if (dec1) {
+        if (has_app) {
+          uint32_t aw[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            aw[j] = to_u(ap[j]);
+          }
+          store_block(A1, b * LPC + pl, aw); // app1 -= ext1 persists (turbodecoder_iter.h:108)
+        }
+        store_block(E1, b * LPC + pl, outv);
+      }
+      {
+        uint32_t lr[8];
+        load_block(lut, b * LPC + pl, lr);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (j < len) {
+            dsts[lr[j] & 0xffffu] = (short)(outv[j] & 0xffffu);
+            dsts[lr[j] >> 16]     = (short)(outv[j] >> 16);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- hard decision (turbodecoder.c:370-378 + turbodecoder_win.h:973-993): bit = LLR > 0, MSB first.
+  // Source: app1 after an even number of half iterations, else ext1.  After >= 3 half iterations E1
+  // holds ext1 - app1 (fused above) and A1 holds that app1, so the raw ext1 is E1 + A1 (wrapping).
+  {
+    const bool odd  = p.n_end & 1;
+    const bool unfz = odd && p.n_end >= 3;
+    uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
+    short*     o16  = p.dec_llr ? p.dec_llr + (size_t)cb * K : nullptr;
+    if ((long_sb & 7) == 0) {
+      const uint32_t bps = long_sb >> 3; // bytes per sub-block
+      for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t r[8], r2[8];
+        load_block(odd ? E1 : A1, b * LPC + pl, r);
+        if (unfz) {
+          load_block(A1, b * LPC + pl, r2);
+        }
+        uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          s2 v = from_u(r[j]);
+          if (unfz) {
+            v = v + from_u(r2[j]);
+          }
+          b0 |= (v.x > 0 ? 0x80u : 0u) >> j;
+          b1 |= (v.y > 0 ? 0x80u : 0u) >> j;
+          if (o16) { // parity aid: decision LLRs in natural order
+            o16[(2 * pl) * long_sb + b * 8 + j]     = v.x;
+            o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
+          }
+        }
+        out[(2 * pl) * bps + b]     = (uint8_t)b0;
+        out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
+      }
+    } else {
+      const short* s  = reinterpret_cast<const short*>(odd ? E1 : A1);
+      const short* sa = reinterpret_cast<const short*>(A1);
+      for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
+        uint32_t byte = 0;
+        for (int t = 0; t < 8; t++) {
+          uint32_t nn = jb * 8 + t;
+          uint32_t d = nn / long_sb, k = nn % long_sb;
+          uint32_t e = elem_index<LPC>(k, d);
+          short    v = s[e];
+          if (unfz) {
+            v = wrap16(v + sa[e]);
+          }
+          byte |= (v > 0 ? 0x80u : 0u) >> t;
+          if (o16) {
+            o16[nn] = v;
+          }
+        }
+        out[jb] = (uint8_t)byte;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar decoder (turbodecoder_gen.c): one lane per code block, wrapping int16, beta kept in HBM.
+// Used for K <= 400 (AUTO) or SRSRAN_TDEC_GENERIC.  Vectors are stored lane-interleaved
+// [index][64 lanes] so that a wave's accesses coalesce.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gen_acs_beta(short (&old)[8], short x, short y)
+{
+  short xy = wrap16(x + y);
+  short m_b[8], nw[8];
+  m_b[0] = wrap16(old[4] + xy);
+  m_b[1] = old[4];
+  m_b[2] = wrap16(old[5] + y);
+  m_b[3] = wrap16(old[5] + x);
+  m_b[4] = wrap16(old[6] + x);
+  m_b[5] = wrap16(old[6] + y);
+  m_b[6] = old[7];
+  m_b[7] = wrap16(old[7] + xy);
+  nw[0] = old[0];
+  nw[1] = wrap16(old[0] + xy);
+  nw[2] = wrap16(old[1] + x);
+  nw[3] = wrap16(old[1] + y);
+  nw[4] = wrap16(old[2] + y);
+  nw[5] = wrap16(old[2] + x);
+  nw[6] = wrap16(old[3] + xy);
+  nw[7] = old[3];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    old[i] = m_b[i] > nw[i] ? m_b[i] : nw[i];
+  }
+}
+
+__global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
+{
+  const int lane = threadIdx.x;
+  const int cb   = blockIdx.x * 64 + lane;
+  if (cb >= p.n_cb) {
+    return;
+  }
+  const uint32_t K  = p.K;
+  const uint32_t L  = K + 4; // K + 3 tail (+1 for the beta terminal state)
+  // per-wave slab, element (array, index, lane): ((array_base + index) * 64 + lane)
+  short* ws = p.ws + (size_t)blockIdx.x * p.ws_stride;
+#define GV(base, idx) ws[((size_t)(base) + (idx)) * 64 + lane]
+  const uint32_t oS = 0, oP0 = L, oP1 = 2 * L, oA1 = 3 * L, oA2 = 4 * L, oE1 = 5 * L, oE2 = 6 * L, oB = 7 * L;
+  // beta: 8 * (K+4) from oB
+
+  if (p.n_begin == 0) {
+    const short* in = p.input + (size_t)cb * p.in_stride;
+    for (uint32_t i = 0; i < K; i++) { // turbodecoder_gen.c:238-258
+      GV(oS, i)  = in[3 * i];
+      GV(oP0, i) = in[3 * i + 1];
+      GV(oP1, i) = in[3 * i + 2];
+    }
+    for (uint32_t i = K; i < K + 3; i++) {
+      GV(oS, i)  = in[3 * K + 2 * (i - K)];
+      GV(oP0, i) = in[3 * K + 2 * (i - K) + 1];
+      GV(oA2, i) = in[3 * K + 6 + 2 * (i - K)];
+      GV(oP1, i) = in[3 * K + 6 + 2 * (i - K) + 1];
+    }
+  }
+  const uint16_t* inter   = p.inter;
+  const uint16_t* deinter = p.deinter;
+
+  for (uint32_t n = p.n_begin; n < p.n_end; n++) {
+    const bool     dec1    = !(n & 1);
+    const bool     has_app = dec1 && n > 0;
+    const uint32_t oX = dec1 ? oS : oA2, oY = dec1 ? oP0 : oP1, oOut = dec1 ? oE1 : oE2;
+    if (dec1) {
+      if (n) {
+        for (uint32_t i = 0; i < K; i++) {
+          GV(oA1, i) = wrap16(GV(oA1, i) - GV(oE1, i));
+        }
+      }
+    } else {
+      for (uint32_t i = 0; i < K; i++) {
+        short e = GV(oE1, i);
+        if (n > 1) {
+          e          = wrap16(e - GV(oA1, i));
+          GV(oE1, i) = e;
+        }
+        GV(oA2, deinter[i]) = e;
+      }
+    }
+    // map_gen_beta (turbodecoder_gen.c:58-112)
+    short old[8];
+    old[0] = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      old[i] = -TD_INF;
+    }
+    const uint32_t end = K + 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      GV(oB + 8 * end, i) = old[i];
+    }
+    for (int k = (int)end - 1; k >= 0; k--) {
+      short x = GV(oX, k);
+      if (has_app && (uint32_t)k < K) {
+        x = wrap16(x + GV(oA1, k));
+      }
+      short y = GV(oY, k);
+      gen_acs_beta(old, x, y);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        GV(oB + 8 * k, i) = old[i];
+      }
+      if ((k % 4) == 0 && (uint32_t)k < K) {
+#pragma unroll
+        for (int i = 1; i < 8; i++) {
+          old[i] = wrap16(old[i] - old[0]);
+        }
+        old[0] = 0;
+      }
+    }
+    // map_gen_alpha (turbodecoder_gen.c:114-198)
+    old[0] = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      old[i] = -TD_INF;
+    }
+    for (uint32_t k = 1; k < K + 1; k++) {
+      short x = GV(oX, k - 1);
+      if (has_app) {
+        x = wrap16(x + GV(oA1, k - 1));
+      }
+      short y  = GV(oY, k - 1);
+      short xy = wrap16(x + y);
+      short m_b[8], nw[8];
+      m_b[0] = old[0];
+      m_b[1] = wrap16(old[3] + y);
+      m_b[2] = wrap16(old[4] + y);
+      m_b[3] = old[7];
+      m_b[4] = old[1];
+      m_b[5] = wrap16(old[2] + y);
+      m_b[6] = wrap16(old[5] + y);
+      m_b[7] = old[6];
+      nw[0] = wrap16(old[1] + xy);
+      nw[1] = wrap16(old[2] + x);
+      nw[2] = wrap16(old[5] + x);
+      nw[3] = wrap16(old[6] + xy);
+      nw[4] = wrap16(old[0] + xy);
+      nw[5] = wrap16(old[3] + x);
+      nw[6] = wrap16(old[4] + x);
+      nw[7] = wrap16(old[7] + xy);
+      short m1 = 0, m0 = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        short bq = GV(oB + 8 * k, i);
+        short v0 = wrap16(m_b[i] + bq);
+        short v1 = wrap16(nw[i] + bq);
+        m0 = (i == 0) ? v0 : (v0 > m0 ? v0 : m0);
+        m1 = (i == 0) ? v1 : (v1 > m1 ? v1 : m1);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        old[i] = m_b[i] > nw[i] ? m_b[i] : nw[i];
+      }
+      if ((k % 4) == 0) {
+#pragma unroll
+        for (int i = 1; i < 8; i++) {
+          old[i] = wrap16(old[i] - old[0]);
+        }
+        old[0] = 0;
+      }
+      GV(oOut, k - 1) = wrap16(m1 - m0);
+    }
+    if (!dec1) {
+      for (uint32_t i = 0; i < K; i++) {
+        GV(oA1, inter[i]) = GV(oE2, i);
+      }
+    }
+  }
+  // decision (turbodecoder.c:370-378, turbodecoder_gen.c:260-277)
+  const uint32_t oD  = (p.n_end & 1) ? oE1 : oA1;
+  uint8_t*       out = p.output + (size_t)cb * p.out_stride;
+  for (uint32_t jb = 0; jb < K / 8; jb++) {
+    uint32_t byte = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      byte |= (GV(oD, jb * 8 + t) > 0 ? 0x80u : 0u) >> t;
+    }
+    out[jb] = (uint8_t)byte;
+  }
+  if (p.dec_llr) {
+    short* o16 = p.dec_llr + (size_t)cb * K;
+    for (uint32_t i = 0; i < K; i++) {
+      o16[i] = GV(oD, i);
+    }
+  }
+#undef GV
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+hipError_t launch_win(int nb, const WinParams& p, hipStream_t stream)
+{
+  if (nb == 16) {
+    dim3 grid(ceil_div(p.n_cb, 8));
+    hipLaunchKernelGGL(tdec_win_kernel<8>, grid, dim3(64), 0, stream, p);
+  } else {
+    dim3 grid(ceil_div(p.n_cb, 16));
+    hipLaunchKernelGGL(tdec_win_kernel<4>, grid, dim3(64), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gen(const GenParams& p, hipStream_t stream)
+{
+  dim3 grid(ceil_div(p.n_cb, 64));
+  hipLaunchKernelGGL(tdec_gen_kernel, grid, dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+uint32_t win_elem_index(int nb, uint32_t k, uint32_t d)
+{
+  return nb == 16 ? elem_index<8>(k, d) : elem_index<4>(k, d);
+}
+
+} // namespace turbo
+} // namespace phyhip

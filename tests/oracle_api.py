@@ -1,0 +1,182 @@
+"""ctypes access to oracle/liboracle.so (the CPU restatement of the reference) for the tests.
+
+TEST INFRASTRUCTURE ONLY: nothing in srslte_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libsrsran_ref.so")
+
+ORC_TDEC_AUTO, ORC_TDEC_GENERIC, ORC_TDEC_SSE_WINDOW, ORC_TDEC_AVX_WINDOW = 0, 1, 3, 5
+
+
+class LdpcGraph(C.Structure):
+    _fields_ = [("bg", C.c_int), ("ls", C.c_uint16), ("bgN", C.c_int), ("bgM", C.c_int), ("bgK", C.c_int),
+                ("nof_edges", C.c_int), ("row_start", C.c_uint16 * 47), ("col", C.c_uint8 * 320),
+                ("shift", C.c_uint16 * 320)]
+
+
+class OfdmCfg(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("symbol_sz", C.c_uint32), ("cp_ext", C.c_int), ("normalize", C.c_int),
+                ("freq_shift_f", C.c_float), ("rx_window_offset", C.c_float), ("keep_dc", C.c_int)]
+
+
+_orc = None
+
+
+def build_oracle():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if not os.path.exists(ORACLE_LIB) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
+    return ORACLE_LIB
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        L = C.CDLL(build_oracle())
+        vp = C.c_void_p
+        L.orc_tdec_run_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]
+        L.orc_tcod_encode.argtypes = [vp, vp, C.c_uint32]
+        L.orc_qpp_gen.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
+        L.orc_ldpc_graph.argtypes = [C.POINTER(LdpcGraph), C.c_int, C.c_uint16]
+        L.orc_ldpc_decode_c.argtypes = [C.POINTER(LdpcGraph), C.c_float, C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
+        L.orc_ldpc_encode.argtypes = [C.POINTER(LdpcGraph), vp, vp]
+        L.orc_crc_bits.argtypes = [C.c_uint32, C.c_int, vp, C.c_int]
+        L.orc_crc_bits.restype = C.c_uint32
+        L.orc_ofdm_rx_sf.argtypes = [C.POINTER(OfdmCfg), vp, vp]
+        L.orc_ofdm_tx_sf.argtypes = [C.POINTER(OfdmCfg), vp, vp]
+        L.orc_dft_c.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        _orc = L
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ turbo helpers
+def tc_sizes():
+    return [orc().orc_tc_cb_size(i) for i in range(188)]
+
+
+def turbo_encode(bits):
+    K = bits.size
+    out = np.zeros(3 * K + 12, np.uint8)
+    assert orc().orc_tcod_encode(P(np.ascontiguousarray(bits, np.uint8)), P(out), K) == 0
+    return out
+
+
+def turbo_llrs(K, n_cb, esn0_db, seed, scale=100.0):
+    """random messages -> turbo code -> BPSK -> AWGN -> int16 LLR = round(scale*y)  (turbodecoder_test.c:254)"""
+    rng = np.random.default_rng(seed)
+    msgs = rng.integers(0, 2, (n_cb, K)).astype(np.uint8)
+    llr = np.zeros((n_cb, 3 * K + 12), np.int16)
+    sigma = 10 ** (-esn0_db / 20)
+    for i in range(n_cb):
+        enc = turbo_encode(msgs[i])
+        y = (2.0 * enc - 1.0) + sigma * rng.standard_normal(enc.size)
+        llr[i] = np.clip(np.round(scale * y), -32768, 32767).astype(np.int16)
+    return msgs, llr
+
+
+def turbo_decode(llr, nof_iterations, K, impl=ORC_TDEC_AUTO, sb_layout=0, want_llr=False):
+    llr = np.ascontiguousarray(llr, np.int16)
+    n_cb = llr.shape[0]
+    out = np.zeros((n_cb, K // 8), np.uint8)
+    dl = np.zeros((n_cb, K), np.int16)
+    for i in range(n_cb):
+        rc = orc().orc_tdec_run_all(P(llr[i]), P(out[i]), nof_iterations, K, impl, sb_layout, None, P(dl[i]))
+        assert rc == 0, rc
+    return (out, dl) if want_llr else out
+
+
+def natural_to_sb_layout(llr_nat, K, nb):
+    """what srsran_rm_turbo_rx_lut hands to the window decoders (rm_turbo.c:260-273,
+    turbodecoder_iter.h:88-102): syst @0, parity0 @K+32, parity1 @2(K+32) in [step][sub-block] order,
+    12 tail LLRs @3(K+32)."""
+    out = np.zeros(3 * (K + 32) + 12, np.int16)
+    sb = K // nb
+    n = np.arange(K)
+    idx = (n % sb) * nb + n // sb
+    out[idx] = llr_nat[3 * n]
+    out[K + 32 + idx] = llr_nat[3 * n + 1]
+    out[2 * (K + 32) + idx] = llr_nat[3 * n + 2]
+    out[3 * (K + 32):] = llr_nat[3 * K:]
+    return out
+
+
+# ------------------------------------------------------------------ LDPC helpers
+def ldpc_graph(bg, ls):
+    g = LdpcGraph()
+    assert orc().orc_ldpc_graph(C.byref(g), bg, ls) == 0
+    return g
+
+
+def ldpc_llrs(bg, ls, n_cw, esn0_db, seed, clip=63):
+    """random messages -> LDPC code -> BPSK -> AWGN -> int8 LLR (positive <=> bit 0)"""
+    g = ldpc_graph(bg, ls)
+    rng = np.random.default_rng(seed)
+    K, N = g.bgK * ls, g.bgN * ls
+    msgs = rng.integers(0, 2, (n_cw, K)).astype(np.uint8)
+    llrs = np.zeros((n_cw, N - 2 * ls), np.int8)
+    sigma = 10 ** (-esn0_db / 20)
+    for i in range(n_cw):
+        cw = np.zeros(N - 2 * ls, np.uint8)
+        assert orc().orc_ldpc_encode(C.byref(g), P(msgs[i]), P(cw)) == 0
+        y = (1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.size)
+        llrs[i] = np.clip(np.round(y * 2.0 / sigma ** 2 * 4), -clip, clip).astype(np.int8)
+    return msgs, llrs
+
+
+def ldpc_decode(bg, ls, llrs, scaling_fctr, max_iter, cdwd_rm_length=None, crc=None):
+    g = ldpc_graph(bg, ls)
+    K, N = g.bgK * ls, g.bgN * ls
+    llrs = np.ascontiguousarray(llrs, np.int8)
+    n_cw = llrs.shape[0]
+    out = np.zeros((n_cw, K), np.uint8)
+    rets = []
+    for i in range(n_cw):
+        poly, order = crc if crc else (0, 0)
+        rets.append(orc().orc_ldpc_decode_c(C.byref(g), scaling_fctr, max_iter, P(llrs[i]), P(out[i]),
+                                            N - 2 * ls if cdwd_rm_length is None else cdwd_rm_length, poly, order, None))
+    return out, rets
+
+
+# ------------------------------------------------------------------ OFDM helpers
+def ofdm_cfg(nof_prb, symbol_sz=0, cp_ext=0, normalize=0, freq_shift_f=0.0, rx_window_offset=0.0, keep_dc=0):
+    return OfdmCfg(nof_prb, symbol_sz, cp_ext, normalize, freq_shift_f, rx_window_offset, keep_dc)
+
+
+def ofdm_geometry(cfg):
+    N = cfg.symbol_sz if cfg.symbol_sz else orc().orc_symbol_sz(cfg.nof_prb)
+    nsym = 12 if cfg.cp_ext else 14
+    return N, nsym, 15 * N, nsym * 12 * cfg.nof_prb
+
+
+def ofdm_rx(cfg, x):
+    N, nsym, sf_sz, sf_re = ofdm_geometry(cfg)
+    x = np.ascontiguousarray(x, np.complex64)
+    out = np.zeros((x.shape[0], sf_re), np.complex64)
+    for i in range(x.shape[0]):
+        assert orc().orc_ofdm_rx_sf(C.byref(cfg), P(x[i]), P(out[i])) == 0
+    return out
+
+
+def ofdm_tx(cfg, x):
+    N, nsym, sf_sz, sf_re = ofdm_geometry(cfg)
+    x = np.ascontiguousarray(x, np.complex64)
+    out = np.zeros((x.shape[0], sf_sz), np.complex64)
+    for i in range(x.shape[0]):
+        assert orc().orc_ofdm_tx_sf(C.byref(cfg), P(x[i]), P(out[i])) == 0
+    return out

@@ -77,6 +77,22 @@ SRSRAN_API void srsran_dft_run_c_zerocopy(srsran_dft_plan_t* plan, const cf_t* i
 SRSRAN_API void srsran_dft_run_c(srsran_dft_plan_t* plan, const cf_t* in, cf_t* out);
 SRSRAN_API void srsran_dft_run_guru_c(srsran_dft_plan_t* plan);
 
+/* DFT transform precoding (SC-FDMA), lib/include/srsran/phy/dft/dft_precoding.h:39-59, dft_precoding.c */
+#define SRSRAN_MAX_PRB 110
+#define SRSRAN_NRE 12
+typedef struct SRSRAN_API {
+  uint32_t          max_prb;
+  srsran_dft_plan_t dft_plan[SRSRAN_MAX_PRB + 1];
+} srsran_dft_precoding_t;
+
+SRSRAN_API int      srsran_dft_precoding_init(srsran_dft_precoding_t* q, uint32_t max_prb, bool is_tx);
+SRSRAN_API int      srsran_dft_precoding_init_tx(srsran_dft_precoding_t* q, uint32_t max_prb);
+SRSRAN_API int      srsran_dft_precoding_init_rx(srsran_dft_precoding_t* q, uint32_t max_prb);
+SRSRAN_API void     srsran_dft_precoding_free(srsran_dft_precoding_t* q);
+SRSRAN_API bool     srsran_dft_precoding_valid_prb(uint32_t nof_prb);
+SRSRAN_API uint32_t srsran_dft_precoding_get_valid_prb(uint32_t nof_prb);
+SRSRAN_API int      srsran_dft_precoding(srsran_dft_precoding_t* q, cf_t* input, cf_t* output, uint32_t nof_prb, uint32_t nof_symbols);
+
 /* ------------------------------------------------------------------------------------------------
  * OFDM  (lib/include/srsran/phy/dft/ofdm.h:48-142, lib/src/phy/dft/ofdm.c)
  * ---------------------------------------------------------------------------------------------- */

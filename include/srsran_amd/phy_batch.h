@@ -74,6 +74,14 @@ SRSRAN_API int  srsran_hip_ofdm_batch_rx(srsran_hip_ofdm_batch_t* h, const cf_t*
 /* tx: d_in n_sf x sf_re REs -> d_out n_sf x sf_sz time samples */
 SRSRAN_API int  srsran_hip_ofdm_batch_tx(srsran_hip_ofdm_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t n_sf, void* stream);
 
+/* ---- generic DFT / SC-FDMA transform precoding: srsran_dft_run_c (dft_fftw.c:336-354) over `how_many`
+ *      back-to-back transforms of `dft_points` (<= 4096) samples, options fused ---- */
+typedef struct srsran_hip_dft_batch srsran_hip_dft_batch_t;
+
+SRSRAN_API int  srsran_hip_dft_batch_create(srsran_hip_dft_batch_t** h, int dft_points, srsran_dft_dir_t dir, bool mirror, bool dc, bool norm);
+SRSRAN_API void srsran_hip_dft_batch_free(srsran_hip_dft_batch_t* h);
+SRSRAN_API int  srsran_hip_dft_batch_run(srsran_hip_dft_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t how_many, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

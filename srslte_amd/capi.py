@@ -31,6 +31,10 @@ class DftPlan(C.Structure):
                 ("dc", C.c_bool), ("dir", C.c_int), ("mode", C.c_int)]
 
 
+class DftPrecoding(C.Structure):
+    _fields_ = [("max_prb", C.c_uint32), ("dft_plan", DftPlan * 111)]
+
+
 class OfdmCfg(C.Structure):
     _fields_ = [("nof_prb", C.c_uint32), ("in_buffer", C.c_void_p), ("out_buffer", C.c_void_p), ("cp", C.c_int),
                 ("sf_type", C.c_int), ("normalize", C.c_bool), ("freq_shift_f", C.c_float),
@@ -148,6 +152,27 @@ def lib():
             "srsran_ofdm_tx_sf": (None, [C.POINTER(Ofdm)]),
             "srsran_ofdm_set_freq_shift": (i32, [C.POINTER(Ofdm), C.c_float]),
             "srsran_ofdm_set_normalize": (None, [C.POINTER(Ofdm), C.c_bool]),
+            "srsran_dft_plan_c": (i32, [C.POINTER(DftPlan), i32, i32]),
+            "srsran_dft_plan": (i32, [C.POINTER(DftPlan), i32, i32, i32]),
+            "srsran_dft_plan_guru_c": (i32, [C.POINTER(DftPlan), i32, i32, vp, vp, i32, i32, i32, i32, i32]),
+            "srsran_dft_replan": (i32, [C.POINTER(DftPlan), i32]),
+            "srsran_dft_replan_c": (i32, [C.POINTER(DftPlan), i32]),
+            "srsran_dft_plan_free": (None, [C.POINTER(DftPlan)]),
+            "srsran_dft_plan_set_mirror": (None, [C.POINTER(DftPlan), C.c_bool]),
+            "srsran_dft_plan_set_db": (None, [C.POINTER(DftPlan), C.c_bool]),
+            "srsran_dft_plan_set_norm": (None, [C.POINTER(DftPlan), C.c_bool]),
+            "srsran_dft_plan_set_dc": (None, [C.POINTER(DftPlan), C.c_bool]),
+            "srsran_dft_run_c": (None, [C.POINTER(DftPlan), vp, vp]),
+            "srsran_dft_run_c_zerocopy": (None, [C.POINTER(DftPlan), vp, vp]),
+            "srsran_dft_run_guru_c": (None, [C.POINTER(DftPlan)]),
+            "srsran_dft_precoding_init": (i32, [C.POINTER(DftPrecoding), u32, C.c_bool]),
+            "srsran_dft_precoding_free": (None, [C.POINTER(DftPrecoding)]),
+            "srsran_dft_precoding_valid_prb": (C.c_bool, [u32]),
+            "srsran_dft_precoding_get_valid_prb": (u32, [u32]),
+            "srsran_dft_precoding": (i32, [C.POINTER(DftPrecoding), vp, vp, u32, u32]),
+            "srsran_hip_dft_batch_create": (i32, [C.POINTER(vp), i32, i32, C.c_bool, C.c_bool, C.c_bool]),
+            "srsran_hip_dft_batch_free": (None, [vp]),
+            "srsran_hip_dft_batch_run": (i32, [vp, vp, vp, u32, vp]),
             "srsran_symbol_sz": (i32, [u32]),
             "srsran_symbol_sz_power2": (i32, [u32]),
             "srsran_use_standard_symbol_size": (None, [C.c_bool]),

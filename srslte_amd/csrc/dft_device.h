@@ -1,0 +1,27 @@
+// dft_device.h -- kernel parameter block and launcher of dft_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace phyhip {
+namespace dft {
+
+struct Params {
+  const void* in;
+  void*       out;
+  const void* twiddle; // N x cf: e^{-j 2 pi i / N}
+  long        idist, odist; // distance between transforms (in cf)
+  int         istride, ostride;
+  int         how_many;
+  int         N;
+  int         npass;     // 0: N is not 2^a 3^b 5^c -> direct evaluation
+  int         radix[16];
+  int         backward;
+  int         mirror, dc, db;
+  float       norm; // 1/sqrt(N) or 0
+};
+
+hipError_t launch(const Params& p, hipStream_t stream);
+
+} // namespace dft
+} // namespace phyhip

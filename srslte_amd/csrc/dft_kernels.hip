@@ -1,0 +1,187 @@
+// dft_kernels.hip -- generic batched 1-D complex DFT of any length N <= 4096 for gfx950
+// (srsran_dft_run_c / srsran_dft_run_guru_c / srsran_dft_precoding of the reference).
+//
+//   * N = 2^a 3^b 5^c : Stockham passes of radix 16/8/4/2/3/5 between two LDS images (one barrier per
+//     pass), one workgroup per transform, strided/batched in and out ("guru" plans of dft_fftw.c:170-206)
+//   * any other N      : direct O(N^2) evaluation from the LDS image (exact twiddle table); these
+//     lengths do not occur on the hot path (PSS/SSS use 128..2048, transform precoding 12*2^a3^b5^c)
+// The mirror / dc / norm / dB options of srsran_dft_run_c (dft_fftw.c:297-354) are fused into the
+// load and the store.
+#include "dft_device.h"
+#include "fft_device.h"
+#include "hip_common.h"
+
+namespace phyhip {
+namespace dft {
+
+using namespace fft;
+
+// source index of element n of the transform input (copy_pre, dft_fftw.c:297-308); -1 = zero
+__device__ __forceinline__ int pre_index(const Params& p, int n)
+{
+  if (p.mirror && p.backward) {
+    const int len = p.N, hlen = len / 2, offset = p.dc ? 1 : 0;
+    if (n < offset) {
+      return -1;
+    }
+    if (n < len - hlen) {
+      return hlen + n - offset;
+    }
+    return n - (len - hlen);
+  }
+  return n;
+}
+
+// transform output index feeding element j of the caller's output (copy_post, :310-320); -1 = untouched
+__device__ __forceinline__ int post_index(const Params& p, int j)
+{
+  if (p.mirror && !p.backward) {
+    const int len = p.N, hlen = (len + 1) / 2, offset = p.dc ? 1 : 0;
+    if (j < len - hlen) {
+      return hlen + j;
+    }
+    if (j < len - offset) {
+      return offset + j - (len - hlen);
+    }
+    return -1;
+  }
+  return j;
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void lds_pass(const float2* a, float2* b, int N, int NS, const float2* __restrict__ tw)
+{
+  const int NB = N / R;
+  for (int q = threadIdx.x; q < NB; q += blockDim.x) {
+    float2    v[R];
+    const int k = q % NS;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      v[r] = a[q + r * NB];
+    }
+    if (NS > 1) {
+      float2 w[R];
+      float2 w1 = tw[k * (N / (NS * R))];
+      if (INV) {
+        w1.y = -w1.y;
+      }
+      w[1] = w1;
+#pragma unroll
+      for (int r = 2; r < R; r++) {
+        w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+      }
+#pragma unroll
+      for (int r = 1; r < R; r++) {
+        v[r] = cmul(v[r], w[r]);
+      }
+    }
+    Dft<R, INV>::run(v);
+    const int j0 = (q / NS) * NS * R + k;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      b[j0 + r * NS] = v[r];
+    }
+  }
+}
+
+template <bool INV>
+__device__ void run_passes(float2*& a, float2*& b, const Params& p, const float2* tw)
+{
+  int NS = 1;
+  for (int i = 0; i < p.npass; i++) {
+    const int R = p.radix[i];
+    switch (R) {
+      case 16:
+        lds_pass<16, INV>(a, b, p.N, NS, tw);
+        break;
+      case 8:
+        lds_pass<8, INV>(a, b, p.N, NS, tw);
+        break;
+      case 5:
+        lds_pass<5, INV>(a, b, p.N, NS, tw);
+        break;
+      case 4:
+        lds_pass<4, INV>(a, b, p.N, NS, tw);
+        break;
+      case 3:
+        lds_pass<3, INV>(a, b, p.N, NS, tw);
+        break;
+      default:
+        lds_pass<2, INV>(a, b, p.N, NS, tw);
+        break;
+    }
+    NS *= R;
+    __syncthreads();
+    float2* t = a;
+    a         = b;
+    b         = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void dft_kernel(const Params p)
+{
+  extern __shared__ float2 lds[];
+  const int     N  = p.N;
+  float2*       a  = lds;
+  float2*       b  = lds + N;
+  const float2* tw = reinterpret_cast<const float2*>(p.twiddle);
+  const float2* in = reinterpret_cast<const float2*>(p.in) + (long)blockIdx.x * p.idist;
+  float2*       out = reinterpret_cast<float2*>(p.out) + (long)blockIdx.x * p.odist;
+
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const int s = pre_index(p, n);
+    a[n]        = s < 0 ? make_float2(0.f, 0.f) : in[(long)s * p.istride];
+  }
+  __syncthreads();
+  if (p.npass > 0) {
+    if (p.backward) {
+      run_passes<true>(a, b, p, tw);
+    } else {
+      run_passes<false>(a, b, p, tw);
+    }
+  } else {
+    // direct evaluation: X[k] = sum_n x[n] w^(n k mod N)
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      float2 acc = make_float2(0.f, 0.f);
+      int    idx = 0;
+      for (int n = 0; n < N; n++) {
+        float2 w = tw[idx];
+        if (p.backward) {
+          w.y = -w.y;
+        }
+        const float2 x = a[n];
+        acc.x += x.x * w.x - x.y * w.y;
+        acc.y += x.x * w.y + x.y * w.x;
+        idx += k;
+        idx = idx >= N ? idx - N : idx;
+      }
+      b[k] = acc;
+    }
+    __syncthreads();
+    float2* t = a;
+    a         = b;
+    b         = t;
+  }
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const int s = post_index(p, j);
+    if (s >= 0) {
+      float2 v = a[s];
+      if (p.norm != 0.0f) {
+        v = cscale(v, p.norm);
+      }
+      if (p.db) {
+        v = make_float2(10.0f * log10f(v.x), 0.f); // dft_fftw.c:348-351: complex -> float takes the real part
+      }
+      out[(long)j * p.ostride] = v;
+    }
+  }
+}
+
+hipError_t launch(const Params& p, hipStream_t stream)
+{
+  hipLaunchKernelGGL(dft_kernel, dim3(p.how_many), dim3(256), 2 * (size_t)p.N * sizeof(float2), stream, p);
+  return hipGetLastError();
+}
+
+} // namespace dft
+} // namespace phyhip

@@ -1,0 +1,147 @@
+"""Parity of the generic DFT / transform-precoding entry points with the oracle (restated dft_fftw.c:297-354,
+float64 DFT), through the C ABI.  Tolerance 1e-4 relative to the output RMS (floor 1), see test_gpu_ofdm."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _oracle(x, n, backward, mirror, dc, norm):
+    y = np.zeros(n, np.complex64)
+    O.orc().orc_dft_c(O.P(np.ascontiguousarray(x, np.complex64)), O.P(y), n, backward, mirror, dc, norm)
+    return y
+
+
+def _err(a, b):
+    return float(np.abs(a - b).max()) / max(1.0, float(np.sqrt(np.mean(np.abs(b) ** 2))))
+
+
+@pytest.mark.parametrize("n", [1, 2, 12, 24, 62, 128, 300, 600, 839, 1200, 1296, 1536, 2048, 3072, 4096])
+def test_run_c_options(hiplib, n):
+    from srslte_amd import capi
+
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for backward in (0, 1):
+        plan = capi.DftPlan()
+        assert hiplib.srsran_dft_plan_c(C.byref(plan), n, backward) == 0
+        assert plan.size == n and plan.init_size == n and plan.forward == (not backward)
+        for mirror, dc, norm in ((0, 0, 0), (1, 0, 0), (1, 1, 1), (0, 0, 1), (0, 1, 0)):
+            hiplib.srsran_dft_plan_set_mirror(C.byref(plan), bool(mirror))
+            hiplib.srsran_dft_plan_set_dc(C.byref(plan), bool(dc))
+            hiplib.srsran_dft_plan_set_norm(C.byref(plan), bool(norm))
+            y = np.zeros(n, np.complex64)
+            hiplib.srsran_dft_run_c(C.byref(plan), O.P(x), O.P(y))
+            ref = _oracle(x, n, backward, mirror, dc, norm)
+            assert _err(y, ref) < TOL, (n, backward, mirror, dc, norm)
+        y = np.zeros(n, np.complex64)
+        hiplib.srsran_dft_run_c_zerocopy(C.byref(plan), O.P(x), O.P(y))
+        assert _err(y, _oracle(x, n, backward, 0, 0, 0)) < TOL
+        hiplib.srsran_dft_plan_free(C.byref(plan))
+        assert plan.size == 0 and not plan.p
+
+
+def test_replan_and_limits(hiplib):
+    from srslte_amd import capi
+
+    plan = capi.DftPlan()
+    assert hiplib.srsran_dft_plan_c(C.byref(plan), 2048, 0) == 0
+    assert hiplib.srsran_dft_replan(C.byref(plan), 4096) == -1  # larger than the initial size (dft_fftw.c:99-104)
+    assert hiplib.srsran_dft_replan(C.byref(plan), 512) == 0 and plan.size == 512 and plan.init_size == 2048
+    x = (np.arange(512) % 7 - 3).astype(np.complex64)
+    y = np.zeros(512, np.complex64)
+    hiplib.srsran_dft_run_c(C.byref(plan), O.P(x), O.P(y))
+    assert _err(y, _oracle(x, 512, 0, 0, 0, 0)) < TOL
+    hiplib.srsran_dft_plan_free(C.byref(plan))
+    assert hiplib.srsran_dft_plan_c(C.byref(plan), 8192, 0) == -1  # beyond the engine's range: loud failure
+    assert hiplib.srsran_dft_plan(C.byref(plan), 64, 0, 1) == -1  # real transforms are not provided
+
+
+def test_guru_strided_batch(hiplib):
+    """the OFDM use of guru plans: 7 transforms, input stride N+cp, output contiguous (ofdm.c:156-184)"""
+    from srslte_amd import capi
+
+    N, cp, how = 128, 9, 7
+    rng = np.random.default_rng(2)
+    buf_in = (rng.standard_normal(how * (N + cp) + 3) + 1j * rng.standard_normal(how * (N + cp) + 3)).astype(np.complex64)
+    buf_out = np.full(how * N + 5, 7 + 7j, np.complex64)
+    plan = capi.DftPlan()
+    assert hiplib.srsran_dft_plan_guru_c(C.byref(plan), N, 0, buf_in.ctypes.data + 8 * cp, buf_out.ctypes.data, 1, 1, how, N + cp, N) == 0
+    assert plan.is_guru
+    hiplib.srsran_dft_run_guru_c(C.byref(plan))
+    for b in range(how):
+        ref = _oracle(buf_in[cp + b * (N + cp):cp + b * (N + cp) + N], N, 0, 0, 0, 0)
+        assert _err(buf_out[b * N:(b + 1) * N], ref) < TOL
+    assert np.all(buf_out[how * N:] == 7 + 7j)
+    hiplib.srsran_dft_plan_free(C.byref(plan))
+    # inverse, contiguous in, strided out with gaps that must be preserved (the tx CP slots)
+    buf_in = (rng.standard_normal(how * N) + 1j * rng.standard_normal(how * N)).astype(np.complex64)
+    buf_out = np.full(how * (N + cp) + 2, -3 - 1j, np.complex64)
+    assert hiplib.srsran_dft_plan_guru_c(C.byref(plan), N, 1, buf_in.ctypes.data, buf_out.ctypes.data + 8 * cp, 1, 1, how, N, N + cp) == 0
+    hiplib.srsran_dft_run_guru_c(C.byref(plan))
+    for b in range(how):
+        o = cp + b * (N + cp)
+        assert _err(buf_out[o:o + N], _oracle(buf_in[b * N:(b + 1) * N], N, 1, 0, 0, 0)) < TOL
+        assert np.all(buf_out[o - cp:o] == -3 - 1j)
+    hiplib.srsran_dft_plan_free(C.byref(plan))
+
+
+def test_transform_precoding(hiplib):
+    """srsran_dft_precoding (pusch.c:337,416): 12 symbols of 12*N_prb points, normalised, for every valid N_prb"""
+    from srslte_amd import capi
+
+    valid = [n for n in range(1, 101) if hiplib.srsran_dft_precoding_valid_prb(n)]
+    assert valid == [n for n in range(1, 101) if all(p in (2, 3, 5) for p in _primes(n))] and len(valid) == 34
+    assert hiplib.srsran_dft_precoding_get_valid_prb(99) == 96 and hiplib.srsran_dft_precoding_get_valid_prb(100) == 100
+    rng = np.random.default_rng(4)
+    for is_tx in (True, False):
+        q = capi.DftPrecoding()
+        assert hiplib.srsran_dft_precoding_init(C.byref(q), 100, is_tx) == 0
+        for n_prb in (1, 2, 6, 25, 45, 81, 96, 100):
+            n = 12 * n_prb
+            x = (rng.standard_normal((12, n)) + 1j * rng.standard_normal((12, n))).astype(np.complex64)
+            y = np.zeros_like(x)
+            assert hiplib.srsran_dft_precoding(C.byref(q), O.P(x), O.P(y), n_prb, 12) == 0
+            ref = np.stack([_oracle(x[i], n, 0 if is_tx else 1, 0, 0, 1) for i in range(12)])
+            assert _err(y, ref) < TOL, (is_tx, n_prb)
+        assert hiplib.srsran_dft_precoding(C.byref(q), O.P(x), O.P(y), 7, 12) == -1
+        hiplib.srsran_dft_precoding_free(C.byref(q))
+        assert q.max_prb == 0
+    assert hiplib.srsran_dft_precoding_init(C.byref(q), 111, True) == capi.SRSRAN_ERROR_INVALID_INPUTS
+
+
+def _primes(n):
+    out, p = [], 2
+    while n > 1:
+        while n % p == 0:
+            out.append(p)
+            n //= p
+        p += 1
+    return out
+
+
+def test_batch_sc_fdma_config4(hiplib):
+    """BASELINE config 4 shape: 64 UEs x 12 symbols x 1200-point IDFT (100 PRB), device resident"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    n, how = 1200, 64 * 12
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((how, n)) + 1j * rng.standard_normal((how, n))).astype(np.complex64)
+    h = C.c_void_p()
+    capi.check(hiplib.srsran_hip_dft_batch_create(C.byref(h), n, capi.DFT_BACKWARD, False, False, True), "create")
+    d_in = S.DeviceBuffer.from_numpy(x)
+    d_out = S.DeviceBuffer(x.nbytes)
+    capi.check(hiplib.srsran_hip_dft_batch_run(h, d_in.ptr, d_out.ptr, how, None), "run")
+    capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+    y = d_out.to_numpy(np.complex64, (how, n))
+    ref = np.fft.ifft(x.astype(np.complex128), axis=1) * np.sqrt(n)
+    assert _err(y, ref.astype(np.complex64)) < TOL
+    for i in (0, 311, how - 1):
+        assert _err(y[i], _oracle(x[i], n, 1, 0, 0, 1)) < TOL
+    hiplib.srsran_hip_dft_batch_free(h)

@@ -1,0 +1,165 @@
+"""CPU-only checks of the product's host layer: the library loads, exports every symbol the public
+headers declare, the struct layouts are those of the reference, and the host-side tables (QPP, base
+graph, sizing helpers) equal the oracle's.  No kernel is launched (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+ROOT = O.ROOT
+INC = os.path.join(ROOT, "include", "srsran_amd")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from srslte_amd import build, capi
+
+    build.build(verbose=False)
+    return capi.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    declared = set()
+    for hdr in os.listdir(INC):
+        txt = open(os.path.join(INC, hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        for m in re.finditer(r"SRSRAN_API[^;{]*?\b(\w+)\s*\(", txt):
+            declared.add(m.group(1))
+        for m in re.finditer(r"SRSRAN_API extern [^;]*?\b(\w+)\s*\[", txt):
+            declared.add(m.group(1))
+    declared -= {"SRSRAN_API", "__attribute__"}
+    assert len(declared) > 60
+    out = subprocess.check_output(["nm", "-D", "--defined-only", L._name], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    missing = sorted(declared - exported)
+    assert not missing, "declared in include/ but not exported: %s" % missing
+
+
+def test_struct_layout_matches_ctypes_mirror(L):
+    """the C compiler's view of include/srsran_amd/phy_abi.h must equal the ctypes mirror (and, in the dev
+    container, the reference headers: see test_struct_layout_matches_reference)"""
+    from srslte_amd import capi
+
+    sizes = _c_sizes(["-I", os.path.join(ROOT, "include")], '#include "srsran_amd/phy_abi.h"')
+    assert sizes["srsran_dft_plan_t"] == C.sizeof(capi.DftPlan)
+    assert sizes["srsran_ofdm_cfg_t"] == C.sizeof(capi.OfdmCfg)
+    assert sizes["srsran_ofdm_t"] == C.sizeof(capi.Ofdm)
+    assert sizes["srsran_tdec_t"] == C.sizeof(capi.Tdec)
+    assert sizes["srsran_ldpc_decoder_t"] == C.sizeof(capi.LdpcDecoder)
+    assert sizes["srsran_crc_t"] == C.sizeof(capi.Crc)
+
+
+# sizeof/offsetof recorded from the reference headers (lib/include/srsran/phy/...) with gcc 11, x86-64
+REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_ofdm_t": 272, "srsran_tdec_t": 18264,
+                    "srsran_ldpc_decoder_t": 88, "srsran_crc_t": 2088, "srsran_tc_interl_t": 24,
+                    "off_ofdm_tmp": 224, "off_tdec_interleaver": 208, "off_tdec_n_iter": 18256, "off_ldpc_decode_c": 80}
+
+
+def _c_sizes(flags, include, extra=""):
+    src = include + """
+#include <stdio.h>
+#include <stddef.h>
+int main(void) {
+  printf("srsran_dft_plan_t %zu\\n", sizeof(srsran_dft_plan_t));
+  printf("srsran_ofdm_cfg_t %zu\\n", sizeof(srsran_ofdm_cfg_t));
+  printf("srsran_ofdm_t %zu\\n", sizeof(srsran_ofdm_t));
+  printf("srsran_tdec_t %zu\\n", sizeof(srsran_tdec_t));
+  printf("srsran_ldpc_decoder_t %zu\\n", sizeof(srsran_ldpc_decoder_t));
+  printf("srsran_crc_t %zu\\n", sizeof(srsran_crc_t));
+  printf("srsran_tc_interl_t %zu\\n", sizeof(srsran_tc_interl_t));
+  printf("off_ofdm_tmp %zu\\n", offsetof(srsran_ofdm_t, tmp));
+  printf("off_tdec_interleaver %zu\\n", offsetof(srsran_tdec_t, interleaver));
+  printf("off_tdec_n_iter %zu\\n", offsetof(srsran_tdec_t, n_iter));
+  printf("off_ldpc_decode_c %zu\\n", offsetof(srsran_ldpc_decoder_t, decode_c));
+  return 0; }
+"""
+    d = os.path.join(ROOT, "build", "scratch")
+    os.makedirs(d, exist_ok=True)
+    cfile, exe = os.path.join(d, "layout.c"), os.path.join(d, "layout")
+    open(cfile, "w").write(src)
+    subprocess.check_call(["gcc", "-std=gnu99"] + flags + [cfile, "-o", exe])
+    return {k: int(v) for k, v in (ln.split() for ln in subprocess.check_output([exe], text=True).splitlines())}
+
+
+def test_struct_layout_matches_recorded_reference(L):
+    ours = _c_sizes(["-I", os.path.join(ROOT, "include")], '#include "srsran_amd/phy_abi.h"')
+    assert ours == REFERENCE_LAYOUT
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/include"), reason="reference headers only exist in the dev container")
+def test_struct_layout_matches_reference():
+    inc = ('#include <complex.h>\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
+           '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n')
+    theirs = _c_sizes(["-I", "/root/reference/lib/include"], inc)
+    assert theirs == REFERENCE_LAYOUT
+
+
+def test_host_tables_match_oracle(L):
+    from srslte_amd import capi
+
+    # K table + QPP (natural and lane-order tables) for every size
+    for idx, K in enumerate(O.tc_sizes()):
+        assert L.srsran_cbsegm_cbsize(idx) == K and L.srsran_cbsegm_cbindex(K) == idx
+        assert L.srsran_tdec_autoimp_get_subblocks(K) == O.orc().orc_tdec_autoimp_subblocks(K)
+        assert L.srsran_tdec_autoimp_get_subblocks_8bit(K) == O.orc().orc_tdec_autoimp_subblocks_8bit(K)
+        for win in (1, 8, 16):
+            if K % win:
+                continue
+            it = capi.TcInterl()
+            assert L.srsran_tc_interl_init(C.byref(it), K) == 0
+            assert L.srsran_tc_interl_LTE_gen_interl(C.byref(it), K, win) == 0
+            f, r = np.zeros(K, np.uint16), np.zeros(K, np.uint16)
+            O.orc().orc_qpp_gen(K, win, O.P(f), O.P(r))
+            assert np.array_equal(np.ctypeslib.as_array(it.forward, shape=(K,)), f)
+            assert np.array_equal(np.ctypeslib.as_array(it.reverse, shape=(K,)), r)
+            L.srsran_tc_interl_free(C.byref(it))
+    assert L.srsran_cbsegm_cbindex(6145) == -1 and L.srsran_cbsegm_cbsize(188) == -1 and L.srsran_cbsegm_cbindex(41) == 1
+    # LSindex + compact PCM
+    ls = (C.c_uint8 * 385).in_dll(L, "LSindex")
+    for z in range(385):
+        want = O.orc().orc_ldpc_ls_index(z)
+        assert ls[z] == (255 if want < 0 else want)
+    pcm = np.zeros(46 * 68, np.uint16)
+    assert L.create_compact_pcm(O.P(pcm), None, 0, 17) == -1
+    # sizing helpers
+    for prb in range(0, 113):
+        assert L.srsran_symbol_sz(prb) == O.orc().orc_symbol_sz(prb)
+        if prb:
+            assert L.srsran_symbol_sz_power2(prb) == O.orc().orc_symbol_sz_power2(prb)
+
+
+def test_no_gpu_means_loud_failure(L):
+    """the product path must not fall back to the CPU: without a device every create/init fails"""
+    from srslte_amd import capi
+
+    if L.srsran_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert L.srsran_hip_tdec_batch_create(C.byref(h), 6144, 8, capi.TDEC_AUTO) == capi.SRSRAN_ERROR
+    assert b"no HIP device" in L.srsran_hip_last_error()
+    assert L.srsran_hip_ldpc_batch_create(C.byref(h), 0, 384, 0.8, 20, 1) == capi.SRSRAN_ERROR
+    cfg = capi.OfdmCfg()
+    cfg.nof_prb = 6
+    assert L.srsran_hip_ofdm_batch_create(C.byref(h), C.byref(cfg), capi.DFT_FORWARD) == capi.SRSRAN_ERROR
+    t = capi.Tdec()
+    assert L.srsran_tdec_init(C.byref(t), 6144) == capi.SRSRAN_ERROR
+
+
+def test_product_never_touches_the_oracle():
+    """nothing under srslte_amd/ or include/ may reference oracle/ (the oracle is the checker, not the product)"""
+    bad = []
+    for base in ("srslte_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"oracle[/_.]|liboracle|orc_", txt) and "oracle" in txt.replace("the oracle", ""):
+                        if re.search(r'import oracle|oracle/lib|liboracle|#include "../oracle|orc_[a-z]+\(', txt):
+                            bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (dev container only: needs /root/reference and
+oracle/_ref/libsrsran_ref.so built by `make -C oracle ref`).
+
+A fixture is DATA: inputs and the outputs the reference produced for them, plus data the reference's
+own tests hold (the K=504 known-answer block of turbodecoder_test.h; rows of examplesBG{1,2}.dat).
+No reference source text is stored.
+
+  tests/golden/turbo_ref.npz   reference srsran_tdec_run_all outputs on seeded noisy LLRs; known-answer
+                               K=504 message/code word; CRC32 of every QPP table the reference builds
+  tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
+  tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
+"""
+import ctypes as C
+import os
+import re
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_api as O  # noqa: E402
+
+REF = "/root/reference/lib"
+OUT = os.path.join(ROOT, "tests", "golden")
+ref = C.CDLL(O.REF_LIB)
+P = O.P
+
+
+class Interl(C.Structure):
+    _fields_ = [("forward", C.POINTER(C.c_uint16)), ("reverse", C.POINTER(C.c_uint16)), ("max_long_cb", C.c_uint32)]
+
+
+def c_array(text, name):
+    m = re.search(name + r"\[[^\]]*\]\s*=\s*\{([^}]*)\}", text, re.S)
+    return np.array([int(x) for x in re.findall(r"-?\d+", m.group(1))], dtype=np.uint8)
+
+
+def turbo():
+    d = {}
+    txt = open(os.path.join(REF, "src/phy/fec/turbo/test/turbodecoder_test.h")).read()
+    d["known_data"] = c_array(txt, "known_data")
+    d["known_data_encoded"] = c_array(txt, "known_data_encoded")
+    assert d["known_data"].size == 504 and d["known_data_encoded"].size == 3 * 504 + 12
+    h = C.create_string_buffer(64 * 1024)
+    assert ref.srsran_tdec_init(h, 6144) == 0
+    ref.srsran_tdec_force_not_sb(h)
+    cases = []
+    for K, n_cb in ((40, 6), (504, 4), (1024, 4), (6144, 3)):
+        for snr in (2.0, -1.0, -4.0):
+            _, llr = O.turbo_llrs(K, n_cb, snr, seed=K * 3 + int(snr * 10))
+            outs = np.zeros((8, n_cb, K // 8), np.uint8)
+            for nit in range(1, 9):
+                for i in range(n_cb):
+                    assert ref.srsran_tdec_run_all(h, P(llr[i]), P(outs[nit - 1, i]), nit, K) == 0
+            key = "K%d_snr%d" % (K, int(snr * 10))
+            d[key + "_llr"] = llr
+            d[key + "_out"] = outs
+            cases.append(key)
+    d["cases"] = np.array(cases)
+    # QPP tables: crc32 of forward|reverse for every K and window 1/8/16 (window only where K % win == 0)
+    crcs = []
+    ref.srsran_cbsegm_cbsize.restype = C.c_int
+    for idx in range(188):
+        K = ref.srsran_cbsegm_cbsize(idx)
+        for win in (1, 8, 16):
+            if K % win:
+                crcs.append((K, win, 0))
+                continue
+            it = Interl()
+            assert ref.srsran_tc_interl_init(C.byref(it), K) == 0
+            assert ref.srsran_tc_interl_LTE_gen_interl(C.byref(it), K, win) == 0
+            f = np.ctypeslib.as_array(it.forward, shape=(K,)).copy()
+            r = np.ctypeslib.as_array(it.reverse, shape=(K,)).copy()
+            crcs.append((K, win, zlib.crc32(f.tobytes() + r.tobytes())))
+            if (K, win) in ((40, 1), (6144, 16)):
+                d["qpp_K%d_w%d_fwd" % (K, win)] = f
+            ref.srsran_tc_interl_free(C.byref(it))
+    d["qpp_crc"] = np.array(crcs, dtype=np.uint32)
+    d["autoimp"] = np.array([[ref.srsran_cbsegm_cbsize(i), ref.srsran_tdec_autoimp_get_subblocks(ref.srsran_cbsegm_cbsize(i)),
+                              ref.srsran_tdec_autoimp_get_subblocks_8bit(ref.srsran_cbsegm_cbsize(i))] for i in range(188)], dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "turbo_ref.npz"), **d)
+    print("turbo_ref.npz", os.path.getsize(os.path.join(OUT, "turbo_ref.npz")))
+
+
+class Args(C.Structure):
+    _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_uint32)]
+
+
+def ldpc():
+    d = {}
+    cases = []
+    for bg, Z in ((0, 384), (1, 384), (0, 2), (1, 9), (0, 112), (1, 208), (0, 15), (0, 24)):
+        for snr, sf, nit in ((2.0, 0.8, 20), (0.0, 0.75, 5)):
+            g = O.ldpc_graph(bg, Z)
+            K, N = g.bgK * Z, g.bgN * Z
+            _, llrs = O.ldpc_llrs(bg, Z, 2, snr, seed=Z + bg * 1000, clip=63 if snr > 1 else 127)
+            rm = N - 2 * Z if nit == 20 else (g.bgK + 9) * Z + 3
+            outs = {}
+            for typ in (2, 4):
+                dec = C.create_string_buffer(4096)
+                a = Args(typ, bg, Z, sf, nit)
+                assert ref.srsran_ldpc_decoder_init(dec, C.byref(a)) == 0
+                o = np.zeros((2, K), np.uint8)
+                for i in range(2):
+                    assert ref.srsran_ldpc_decoder_decode_c(dec, P(llrs[i]), P(o[i]), rm) == nit
+                ref.srsran_ldpc_decoder_free(dec)
+                outs[typ] = o
+            assert np.array_equal(outs[2], outs[4])
+            key = "bg%d_z%d_it%d" % (bg, Z, nit)
+            d[key + "_llr"], d[key + "_out"] = llrs, np.packbits(outs[2], axis=1)
+            d[key + "_par"] = np.array([bg, Z, nit, rm, int(sf * 100)], dtype=np.int32)
+            cases.append(key)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "ldpc_ref.npz"), **d)
+    print("ldpc_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_ref.npz")))
+    # golden examples of the reference's own tests
+    ex = {}
+    for bg in (0, 1):
+        lines = open(os.path.join(REF, "src/phy/fec/ldpc/test/examplesBG%d.dat" % (bg + 1))).read().split("\n")
+        sect = {}
+        cur = None
+        for ln in lines:
+            if ln.startswith("ls"):
+                cur = ln.strip()
+                sect[cur] = []
+            elif ln.strip() and cur:
+                sect[cur].append(ln.strip())
+        for Z in (2, 3, 5, 7, 9, 11, 13, 15, 16, 36, 104, 208, 384):
+            conv = lambda s: np.array([254 if c == "-" else int(c) for c in s], dtype=np.uint8)
+            ex["bg%d_z%d_msgs" % (bg, Z)] = np.packbits(np.stack([conv(s) for s in sect["ls%dmsgs" % Z][:3]]) == 1, axis=1)
+            ex["bg%d_z%d_fill" % (bg, Z)] = np.packbits(np.stack([conv(s) for s in sect["ls%dmsgs" % Z][:3]]) == 254, axis=1)
+            ex["bg%d_z%d_cwds" % (bg, Z)] = np.packbits(np.stack([conv(s) for s in sect["ls%dcwds" % Z][:3]]) == 1, axis=1)
+            ex["bg%d_z%d_cfill" % (bg, Z)] = np.packbits(np.stack([conv(s) for s in sect["ls%dcwds" % Z][:3]]) == 254, axis=1)
+    np.savez_compressed(os.path.join(OUT, "ldpc_examples.npz"), **ex)
+    print("ldpc_examples.npz", os.path.getsize(os.path.join(OUT, "ldpc_examples.npz")))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    turbo()
+    ldpc()

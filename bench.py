@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sf", type=int, default=1024, help="subframes per rank per step")
+    ap.add_argument("--sf", type=int, default=4096, help="subframes per rank per step")
     ap.add_argument("--cpu-sample", type=int, default=48, help="code blocks decoded on the CPU for baseline + parity")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()

@@ -201,16 +201,30 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
   if (nb) {
     const uint32_t lpc = nb / 2, long_sb = K / nb, nblk = (long_sb + 7) / 8;
     h->ws_stride = turbo::win_ws_dwords(K, nb);
+    // Exchange tables, one dword per (step k, destination lane p'), stored blocked [k/8][p'][k%8]:
+    //   bits 0..15  destination row o = PI'(k) mod W  (common to all sub-blocks: QPP is contention free)
+    //   bits 16..19 source sub-block whose output lands in destination sub-block 2p'
+    //   bits 20..23 source sub-block whose output lands in destination sub-block 2p'+1
+    // deint: app2[reverse[n]] = ext1[n]   inter: app1[forward[n]] = ext2[n]   (turbodecoder_iter.h:118,124)
     std::vector<uint32_t> deint(nblk * lpc * 8, 0), inter(nblk * lpc * 8, 0);
-    for (uint32_t k = 0; k < long_sb; k++) {
-      for (uint32_t d = 0; d < (uint32_t)nb; d++) {
-        uint32_t n  = d * long_sb + k;                        // natural position of (step k, sub-block d)
-        uint32_t e  = turbo::win_elem_index(nb, k, d);        // where that element lives
-        uint32_t td = r[n], ti = f[n];                        // app2[rev[n]] = ext1[n]; app1[fwd[n]] = ext2[n]
-        uint32_t ed = turbo::win_elem_index(nb, td % long_sb, td / long_sb);
-        uint32_t ei = turbo::win_elem_index(nb, ti % long_sb, ti / long_sb);
-        deint[e >> 1] |= ed << (16 * (e & 1));
-        inter[e >> 1] |= ei << (16 * (e & 1));
+    for (int dir = 0; dir < 2; dir++) {
+      const std::vector<uint16_t>& tab = dir == 0 ? r : f;
+      std::vector<uint32_t>&       out = dir == 0 ? deint : inter;
+      for (uint32_t k = 0; k < long_sb; k++) {
+        uint32_t src_of[16];
+        uint32_t row = tab[k] % long_sb;
+        for (uint32_t j = 0; j < (uint32_t)nb; j++) {
+          uint32_t t = tab[j * long_sb + k];
+          if (t % long_sb != row) {
+            set_error("QPP interleaver of K=%u is not contention free for %d windows", K, nb);
+            delete h;
+            return SRSRAN_ERROR;
+          }
+          src_of[t / long_sb] = j;
+        }
+        for (uint32_t pp = 0; pp < lpc; pp++) {
+          out[((k >> 3) * lpc + pp) * 8 + (k & 7)] = row | (src_of[2 * pp] << 16) | (src_of[2 * pp + 1] << 20);
+        }
       }
     }
     size_t tb = deint.size() * sizeof(uint32_t);

@@ -200,7 +200,40 @@ __host__ __device__ __forceinline__ uint32_t elem_index(uint32_t k, uint32_t d)
 
 // ------------------------------------------------------------------------------------------------
 // Windowed decoder kernel: one wave per 64/LPC code blocks, whole srsran_tdec_run_all in one launch.
+//
+// Per-code-block workspace (dwords, AW = nblk*8*LPC each):
+//   S, P0, P1 : systematic / parity LLRs, blocked layout [step/8][lane][step%8]   (read only)
+//   A1        : a-priori of decoder 1, ALREADY  app1 - ext1  (turbodecoder_iter.h:108), row layout [step][lane]
+//   E1        : ext1 of decoder 1 (after the subtraction of :115 once n >= 2), row layout
+//   A2        : input of decoder 2 (interleaved ext1), row layout
+//   CK        : backward-recursion check-points, one per 8 steps
+// The QPP interleaver is contention free for both directions: the 16 (8) sub-block outputs of one
+// trellis step land in ONE row of the destination, permuted.  So the extrinsic exchange is, per step,
+// one in-register permutation across the lanes of the code block (ds_bpermute) and one full 32-byte
+// row store -- never a 2-byte scatter.
 // ------------------------------------------------------------------------------------------------
+template <int LPC>
+__device__ __forceinline__ void load_rows(const uint32_t* arr, uint32_t b, int pl, uint32_t (&r)[8])
+{
+  const uint32_t* q = arr + (size_t)(b * 8) * LPC + pl;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    r[j] = q[j * LPC];
+  }
+}
+
+// value for this lane's two destination sub-blocks, fetched from the lanes holding the source sub-blocks
+template <int LPC>
+__device__ __forceinline__ uint32_t permute_pair(uint32_t v, uint32_t sel)
+{
+  const uint32_t jlo = sel & 15u, jhi = (sel >> 4) & 15u;
+  const uint32_t a   = __shfl(v, (int)(jlo >> 1), LPC);
+  const uint32_t c   = __shfl(v, (int)(jhi >> 1), LPC);
+  const uint32_t lo  = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
+  const uint32_t hi  = (jhi & 1u) ? (c >> 16) : (c & 0xffffu);
+  return lo | (hi << 16);
+}
+
 template <int LPC>
 __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 {
@@ -282,10 +315,33 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   for (uint32_t n = p.n_begin; n < p.n_end; n++) {
     const bool      dec1    = !(n & 1);
     const bool      has_app = dec1 && n > 0;
-    const uint32_t* X       = dec1 ? S : A2;
     const uint32_t* Y       = dec1 ? P0 : P1;
     const short*    xt      = dec1 ? TL : TL + 6;
     const short*    yt      = dec1 ? TL + 3 : TL + 9;
+
+    // operands of 8 consecutive steps of this lane's two sub-blocks: x (systematic + a-priori), y (parity)
+    auto load_xy = [&](uint32_t b, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
+      uint32_t xr[8], yr[8], ar[8];
+      if (dec1) {
+        load_block(S, b * LPC + pl, xr);
+      } else {
+        load_rows<LPC>(A2, b, pl, xr);
+      }
+      load_block(Y, b * LPC + pl, yr);
+      if (has_app) {
+        load_rows<LPC>(A1, b, pl, ar);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        xs[j] = from_u(xr[j]);
+        ys[j] = from_u(yr[j]);
+        ap[j] = splat(0);
+        if (has_app) {
+          ap[j] = from_u(ar[j]);
+          xs[j] = adds(ap[j], xs[j]);
+        }
+      }
+    };
 
     s2 o[8];
     // ================= backward recursion (turbodecoder_win.h:551-681)
@@ -295,20 +351,11 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     }
     // pass 0: 40 steps on the head of every sub-block, all states unknown
     for (int b = TD_WIN_OVERLAP / 8 - 1; b >= 0; b--) {
-      uint32_t xr[8], yr[8], ar[8], er[8];
-      load_block(X, b * LPC + pl, xr);
-      load_block(Y, b * LPC + pl, yr);
-      if (has_app) {
-        load_block(A1, b * LPC + pl, ar);
-        load_block(E1, b * LPC + pl, er);
-      }
+      s2 xs[8], ys[8], ap[8];
+      load_xy(b, xs, ys, ap);
 #pragma unroll
       for (int j = 7; j >= 0; j--) {
-        s2 x = from_u(xr[j]);
-        if (has_app) {
-          x = adds(from_u(ar[j]) - from_u(er[j]), x);
-        }
-        beta_step(o, x, from_u(yr[j]));
+        beta_step(o, xs[j], ys[j]);
         uint32_t k = b * 8 + j;
         if ((k & 1) == 0 && k != 0) {
           normalize(o);
@@ -336,22 +383,13 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
     for (int b = (int)nblk - 1; b >= 0; b--) {
-      uint32_t xr[8], yr[8], ar[8], er[8];
-      load_block(X, b * LPC + pl, xr);
-      load_block(Y, b * LPC + pl, yr);
-      if (has_app) {
-        load_block(A1, b * LPC + pl, ar);
-        load_block(E1, b * LPC + pl, er);
-      }
+      s2 xs[8], ys[8], ap[8];
+      load_xy(b, xs, ys, ap);
 #pragma unroll
       for (int j = 7; j >= 0; j--) {
         uint32_t k = b * 8 + j;
         if (k < long_sb) {
-          s2 x = from_u(xr[j]);
-          if (has_app) {
-            x = adds(from_u(ar[j]) - from_u(er[j]), x);
-          }
-          beta_step(o, x, from_u(yr[j]));
+          beta_step(o, xs[j], ys[j]);
           if (j == 0 && b > 0) {
             uint32_t ck[8];
 #pragma unroll
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         }
       }
     }
-    __syncthreads(); // check-points visible (same wave wrote them; orders the stores before the loads)
+    __syncthreads(); // orders this lane's check-point stores before its loads below
 
     // ================= forward recursion + LLR (turbodecoder_win.h:684-832)
 #pragma unroll
@@ -376,22 +414,13 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     {
       const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
       for (uint32_t b = w0 >> 3; b <= (long_sb - 1) >> 3; b++) {
-        uint32_t xr[8], yr[8], ar[8], er[8];
-        load_block(X, b * LPC + pl, xr);
-        load_block(Y, b * LPC + pl, yr);
-        if (has_app) {
-          load_block(A1, b * LPC + pl, ar);
-          load_block(E1, b * LPC + pl, er);
-        }
+        s2 xs[8], ys[8], ap[8];
+        load_xy(b, xs, ys, ap);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           uint32_t k = b * 8 + j;
           if (k >= w0 && k < long_sb) {
-            s2 x = from_u(xr[j]);
-            if (has_app) {
-              x = adds(from_u(ar[j]) - from_u(er[j]), x);
-            }
-            alpha_step<false>(o, o, x, from_u(yr[j]));
+            alpha_step<false>(o, o, xs[j], ys[j]);
             uint32_t kk = k - w0;
             if ((kk & 1) == 0 && kk != 0) {
               normalize(o);
@@ -410,31 +439,25 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       o[i]         = from_u(lo | (hi << 16));
     }
 
-    const uint32_t* lut  = dec1 ? p.deint : p.inter;   // blocked-layout scatter tables
-    short*          dsts = reinterpret_cast<short*>(dec1 ? A2 : A1);
+    const uint32_t* lut = dec1 ? p.deint : p.inter; // per (step, destination lane): row | source sub-blocks
+    uint32_t*       dst = dec1 ? A2 : A1;
     // ext1 -= app1 of the next half iteration (turbodecoder_iter.h:115) is applied here, always: the
-    // kernel is resumable and cannot know whether another half iteration follows.  The raw LLR the
-    // decision needs after an odd number of half iterations is recovered as E1 + A1 (exact, wrapping).
-    const bool      fuse = dec1 && n >= 2;
+    // kernel is resumable and cannot know whether another half iteration follows; the raw LLRs the
+    // decision needs are recovered as E1 + A1 (exact, wrapping).
+    const bool fuse = dec1 && n >= 2;
 
     for (uint32_t b = 0; b < nblk; b++) {
       const int len = (long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
-      uint32_t  xr[8], yr[8], ar[8], er[8], ck[8];
-      load_block(X, b * LPC + pl, xr);
-      load_block(Y, b * LPC + pl, yr);
-      if (has_app) {
-        load_block(A1, b * LPC + pl, ar);
-        load_block(E1, b * LPC + pl, er);
-      }
+      s2        xs[8], ys[8], ap[8];
+      uint32_t  ck[8], tr[8], eg[8];
+      load_xy(b, xs, ys, ap);
       load_block(CK, (b + 1) * LPC + pl, ck);
-      s2 xs[8], ap[8];
+      load_block(lut, b * LPC + pl, tr);
+      if (!dec1) {
+        // decoder 2 hands app1 - ext1 to decoder 1: fetch the ext1 rows its outputs will land on
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        xs[j] = from_u(xr[j]);
-        ap[j] = splat(0);
-        if (has_app) {
-          ap[j] = from_u(ar[j]) - from_u(er[j]); // srsran_vec_sub_sss: wrapping
-          xs[j] = adds(ap[j], xs[j]);
+        for (int j = 0; j < 8; j++) {
+          eg[j] = (j < len) ? E1[(size_t)(tr[j] & 0xffffu) * LPC + pl] : 0u;
         }
       }
       // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point
@@ -460,7 +483,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           if (idx != long_sb && (idx & 1) == 0) {
             normalize(st);
           }
-          beta_step(st, xs[j + 1], from_u(yr[j + 1]));
+          beta_step(st, xs[j + 1], ys[j + 1]);
 #pragma unroll
           for (int i = 0; i < 8; i++) {
             B[j][i] = st[i];
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       for (int j = 0; j < 8; j++) {
         outv[j] = 0;
         if (j < len) {
-          s2       llr = alpha_step<true>(o, B[j], xs[j], from_u(yr[j]));
+          s2       llr = alpha_step<true>(o, B[j], xs[j], ys[j]);
           uint32_t k   = b * 8 + j;
           if ((k & 1) == 0 && k != 0) {
             normalize(o);
@@ -483,26 +506,17 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           outv[j] = to_u(llr);
         }
       }
-      if (dec1) {
-        if (has_app) {
-          uint32_t aw[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            aw[j] = to_u(ap[j]);
+      for (int j = 0; j < 8; j++) {
+        if (j < len) {
+          if (dec1) {
+            E1[(size_t)(b * 8 + j) * LPC + pl] = outv[j];
           }
-          store_block(A1, b * LPC + pl, aw); // app1 -= ext1 persists (turbodecoder_iter.h:108)
-        }
-        store_block(E1, b * LPC + pl, outv);
-      }
-      {
-        uint32_t lr[8];
-        load_block(lut, b * LPC + pl, lr);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          if (j < len) {
-            dsts[lr[j] & 0xffffu] = (short)(outv[j] & 0xffffu);
-            dsts[lr[j] >> 16]     = (short)(outv[j] >> 16);
+          uint32_t w = permute_pair<LPC>(outv[j], tr[j] >> 16);
+          if (!dec1) {
+            w = to_u(from_u(w) - from_u(eg[j])); // app1 - ext1 (srsran_vec_sub_sss: wrapping)
           }
+          dst[(size_t)(tr[j] & 0xffffu) * LPC + pl] = w;
         }
       }
     }
@@ -510,26 +524,25 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   }
 
   // ---- hard decision (turbodecoder.c:370-378 + turbodecoder_win.h:973-993): bit = LLR > 0, MSB first.
-  // Source: app1 after an even number of half iterations, else ext1.  After >= 3 half iterations E1
-  // holds ext1 - app1 (fused above) and A1 holds that app1, so the raw ext1 is E1 + A1 (wrapping).
+  // Source: app1 after an even number of half iterations, else ext1.  With the fused subtractions both
+  // are E1 + A1 (wrapping) once two half iterations have run; after a single one it is E1.
   {
-    const bool odd  = p.n_end & 1;
-    const bool unfz = odd && p.n_end >= 3;
+    const bool both = p.n_end >= 2;
     uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
     short*     o16  = p.dec_llr ? p.dec_llr + (size_t)cb * K : nullptr;
     if ((long_sb & 7) == 0) {
       const uint32_t bps = long_sb >> 3; // bytes per sub-block
       for (uint32_t b = 0; b < nblk; b++) {
         uint32_t r[8], r2[8];
-        load_block(odd ? E1 : A1, b * LPC + pl, r);
-        if (unfz) {
-          load_block(A1, b * LPC + pl, r2);
+        load_rows<LPC>(E1, b, pl, r);
+        if (both) {
+          load_rows<LPC>(A1, b, pl, r2);
         }
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           s2 v = from_u(r[j]);
-          if (unfz) {
+          if (both) {
             v = v + from_u(r2[j]);
           }
           b0 |= (v.x > 0 ? 0x80u : 0u) >> j;
@@ -543,16 +556,16 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
       }
     } else {
-      const short* s  = reinterpret_cast<const short*>(odd ? E1 : A1);
+      const short* se = reinterpret_cast<const short*>(E1);
       const short* sa = reinterpret_cast<const short*>(A1);
       for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
         uint32_t byte = 0;
         for (int t = 0; t < 8; t++) {
           uint32_t nn = jb * 8 + t;
           uint32_t d = nn / long_sb, k = nn % long_sb;
-          uint32_t e = elem_index<LPC>(k, d);
-          short    v = s[e];
-          if (unfz) {
+          uint32_t e = (k * LPC + (d >> 1)) * 2 + (d & 1);
+          short    v = se[e];
+          if (both) {
             v = wrap16(v + sa[e]);
           }
           byte |= (v > 0 ? 0x80u : 0u) >> t;

@@ -43,7 +43,7 @@ struct GenParams {
 static inline uint32_t win_ws_dwords(uint32_t K, int nb)
 {
   uint32_t lpc = nb / 2, long_sb = K / nb, nblk = (long_sb + 7) / 8;
-  return 6 * nblk * lpc * 8 + (nblk + 1) * lpc * 8 + 8;
+  return 6 * nblk * lpc * 8 + (nblk + 1) * lpc * 8 + 8 * lpc; // (+ tail LLRs); per code block, the kernel interleaves a wave's blocks
 }
 // int16 of workspace per wave (64 code blocks) for the scalar decoder
 static inline size_t gen_ws_shorts(uint32_t K)

@@ -228,7 +228,9 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
       }
     }
     size_t tb = deint.size() * sizeof(uint32_t);
-    PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * max_nof_cb * sizeof(uint32_t)), SRSRAN_ERROR);
+    // one slab per wave (64/lpc code blocks); round the block count up to whole waves
+    const uint32_t cpw = 64 / lpc;
+    PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * ceil_div(max_nof_cb, cpw) * cpw * sizeof(uint32_t)), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_deint, tb), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_inter, tb), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMemcpy(h->d_deint, deint.data(), tb, hipMemcpyHostToDevice), SRSRAN_ERROR);

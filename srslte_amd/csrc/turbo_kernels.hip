@@ -212,13 +212,13 @@ __host__ __device__ __forceinline__ uint32_t elem_index(uint32_t k, uint32_t d)
 // one in-register permutation across the lanes of the code block (ds_bpermute) and one full 32-byte
 // row store -- never a 2-byte scatter.
 // ------------------------------------------------------------------------------------------------
-template <int LPC>
-__device__ __forceinline__ void load_rows(const uint32_t* arr, uint32_t b, int pl, uint32_t (&r)[8])
+// rows of the 64/LPC code blocks of a wave are interleaved: row k of the wave is 64 contiguous dwords
+__device__ __forceinline__ void load_rows(const uint32_t* arr, uint32_t b, int lane, uint32_t (&r)[8])
 {
-  const uint32_t* q = arr + (size_t)(b * 8) * LPC + pl;
+  const uint32_t* q = arr + (size_t)(b * 8) * 64 + lane;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    r[j] = q[j * LPC];
+    r[j] = q[j * 64];
   }
 }
 
@@ -250,15 +250,19 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   const uint32_t nblk    = (long_sb + 7) >> 3;
   const uint32_t AW      = nblk * LPC * 8;
 
-  uint32_t* ws  = p.ws + (size_t)cb * p.ws_stride;
+  // The workspace of the 64/LPC code blocks of this wave is ONE slab with the blocks interleaved at lane
+  // granularity: every wave-level load/store touches one contiguous 256 B (dword) or 1 KB (dwordx4) run,
+  // and the per-step row exchange of all the wave's code blocks is a single contiguous 256 B store.
+  const uint32_t AWG = AW * CPW; // dwords per array per wave
+  uint32_t* ws  = p.ws + (size_t)blockIdx.x * p.ws_stride * CPW;
   uint32_t* S   = ws;
-  uint32_t* P0  = ws + AW;
-  uint32_t* P1  = ws + 2 * AW;
-  uint32_t* A1  = ws + 3 * AW;
-  uint32_t* E1  = ws + 4 * AW;
-  uint32_t* A2  = ws + 5 * AW;
-  uint32_t* CK  = ws + 6 * AW;
-  short*    TL  = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * LPC * 8); // 12 tail LLRs
+  uint32_t* P0  = ws + AWG;
+  uint32_t* P1  = ws + 2 * AWG;
+  uint32_t* A1  = ws + 3 * AWG;
+  uint32_t* E1  = ws + 4 * AWG;
+  uint32_t* A2  = ws + 5 * AWG;
+  uint32_t* CK  = ws + 6 * AWG;
+  short*    TL  = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * 64 * 8) + 16 * (lane / LPC); // 12 tail LLRs per block
 
   // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102)
   if (p.n_begin == 0) {
@@ -294,9 +298,9 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         y0[j] = v0;
         y1[j] = v1;
       }
-      store_block(S, b * LPC + pl, s);
-      store_block(P0, b * LPC + pl, y0);
-      store_block(P1, b * LPC + pl, y1);
+      store_block(S, b * 64 + lane, s);
+      store_block(P0, b * 64 + lane, y0);
+      store_block(P1, b * 64 + lane, y1);
     }
     if (pl == 0) {
       const uint32_t tb = p.sb_layout ? 3 * (K + 32) : 3 * K;
@@ -323,13 +327,13 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     auto load_xy = [&](uint32_t b, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
       uint32_t xr[8], yr[8], ar[8];
       if (dec1) {
-        load_block(S, b * LPC + pl, xr);
+        load_block(S, b * 64 + lane, xr);
       } else {
-        load_rows<LPC>(A2, b, pl, xr);
+        load_rows(A2, b, lane, xr);
       }
-      load_block(Y, b * LPC + pl, yr);
+      load_block(Y, b * 64 + lane, yr);
       if (has_app) {
-        load_rows<LPC>(A1, b, pl, ar);
+        load_rows(A1, b, lane, ar);
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       for (int i = 0; i < 8; i++) {
         ck[i] = to_u(o[i]);
       }
-      store_block(CK, nblk * LPC + pl, ck);
+      store_block(CK, nblk * 64 + lane, ck);
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
     for (int b = (int)nblk - 1; b >= 0; b--) {
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
             for (int i = 0; i < 8; i++) {
               ck[i] = to_u(o[i]);
             }
-            store_block(CK, b * LPC + pl, ck);
+            store_block(CK, b * 64 + lane, ck);
           }
           if ((k & 1) == 0 && k != 0) {
             normalize(o);
@@ -451,13 +455,13 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       s2        xs[8], ys[8], ap[8];
       uint32_t  ck[8], tr[8], eg[8];
       load_xy(b, xs, ys, ap);
-      load_block(CK, (b + 1) * LPC + pl, ck);
+      load_block(CK, (b + 1) * 64 + lane, ck);
       load_block(lut, b * LPC + pl, tr);
       if (!dec1) {
         // decoder 2 hands app1 - ext1 to decoder 1: fetch the ext1 rows its outputs will land on
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          eg[j] = (j < len) ? E1[(size_t)(tr[j] & 0xffffu) * LPC + pl] : 0u;
+          eg[j] = (j < len) ? E1[(size_t)(tr[j] & 0xffffu) * 64 + lane] : 0u;
         }
       }
       // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point
@@ -510,13 +514,13 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       for (int j = 0; j < 8; j++) {
         if (j < len) {
           if (dec1) {
-            E1[(size_t)(b * 8 + j) * LPC + pl] = outv[j];
+            E1[(size_t)(b * 8 + j) * 64 + lane] = outv[j];
           }
           uint32_t w = permute_pair<LPC>(outv[j], tr[j] >> 16);
           if (!dec1) {
             w = to_u(from_u(w) - from_u(eg[j])); // app1 - ext1 (srsran_vec_sub_sss: wrapping)
           }
-          dst[(size_t)(tr[j] & 0xffffu) * LPC + pl] = w;
+          dst[(size_t)(tr[j] & 0xffffu) * 64 + lane] = w;
         }
       }
     }
@@ -534,9 +538,9 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       const uint32_t bps = long_sb >> 3; // bytes per sub-block
       for (uint32_t b = 0; b < nblk; b++) {
         uint32_t r[8], r2[8];
-        load_rows<LPC>(E1, b, pl, r);
+        load_rows(E1, b, lane, r);
         if (both) {
-          load_rows<LPC>(A1, b, pl, r2);
+          load_rows(A1, b, lane, r2);
         }
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         for (int t = 0; t < 8; t++) {
           uint32_t nn = jb * 8 + t;
           uint32_t d = nn / long_sb, k = nn % long_sb;
-          uint32_t e = (k * LPC + (d >> 1)) * 2 + (d & 1);
+          uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
           short    v = se[e];
           if (both) {
             v = wrap16(v + sa[e]);

@@ -239,6 +239,8 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 {
   constexpr int NB  = 2 * LPC;
   constexpr int CPW = 64 / LPC;
+  // re-derived backward metrics of the current 8-step block: 8 steps x 8 states x int16x2 per lane
+  __shared__ uint4 Bl[8][2][64];
   const int     lane = threadIdx.x;
   const int     pl   = lane % LPC;
   const int     cb   = blockIdx.x * CPW + lane / LPC;
@@ -323,29 +325,36 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     const short*    xt      = dec1 ? TL : TL + 6;
     const short*    yt      = dec1 ? TL + 3 : TL + 9;
 
-    // operands of 8 consecutive steps of this lane's two sub-blocks: x (systematic + a-priori), y (parity)
-    auto load_xy = [&](uint32_t b, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
-      uint32_t xr[8], yr[8], ar[8];
+    // operands of 8 consecutive steps of this lane's two sub-blocks: x (systematic + a-priori), y (parity).
+    // issue() only starts the loads (software pipelining: the next block is requested before the current
+    // one is computed, so HBM latency hides behind a few hundred VALU instructions); prep() consumes them.
+    struct Ops {
+      uint32_t x[8], y[8], a[8];
+    };
+    auto issue = [&](uint32_t b, Ops& q) {
       if (dec1) {
-        load_block(S, b * 64 + lane, xr);
+        load_block(S, b * 64 + lane, q.x);
       } else {
-        load_rows(A2, b, lane, xr);
+        load_rows(A2, b, lane, q.x);
       }
-      load_block(Y, b * 64 + lane, yr);
+      load_block(Y, b * 64 + lane, q.y);
       if (has_app) {
-        load_rows(A1, b, lane, ar);
+        load_rows(A1, b, lane, q.a);
       }
+    };
+    auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        xs[j] = from_u(xr[j]);
-        ys[j] = from_u(yr[j]);
+        xs[j] = from_u(q.x[j]);
+        ys[j] = from_u(q.y[j]);
         ap[j] = splat(0);
         if (has_app) {
-          ap[j] = from_u(ar[j]);
+          ap[j] = from_u(q.a[j]);
           xs[j] = adds(ap[j], xs[j]);
         }
       }
     };
+    Ops cur, nxt;
 
     s2 o[8];
     // ================= backward recursion (turbodecoder_win.h:551-681)
@@ -354,9 +363,11 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       o[i] = splat(-TD_INF);
     }
     // pass 0: 40 steps on the head of every sub-block, all states unknown
+    issue(TD_WIN_OVERLAP / 8 - 1, cur);
     for (int b = TD_WIN_OVERLAP / 8 - 1; b >= 0; b--) {
+      issue(b > 0 ? b - 1 : nblk - 1, nxt); // after the warm-up, pass 1 starts at the last block
       s2 xs[8], ys[8], ap[8];
-      load_xy(b, xs, ys, ap);
+      prep(cur, xs, ys, ap);
 #pragma unroll
       for (int j = 7; j >= 0; j--) {
         beta_step(o, xs[j], ys[j]);
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           normalize(o);
         }
       }
+      cur = nxt;
     }
     // hand every estimate to the previous sub-block; the last one starts from the tail trellis
     {
@@ -387,8 +399,11 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
     for (int b = (int)nblk - 1; b >= 0; b--) {
+      if (b > 0) {
+        issue(b - 1, nxt);
+      }
       s2 xs[8], ys[8], ap[8];
-      load_xy(b, xs, ys, ap);
+      prep(cur, xs, ys, ap);
 #pragma unroll
       for (int j = 7; j >= 0; j--) {
         uint32_t k = b * 8 + j;
@@ -407,6 +422,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           }
         }
       }
+      cur = nxt;
     }
     __syncthreads(); // orders this lane's check-point stores before its loads below
 
@@ -417,9 +433,12 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     }
     {
       const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
-      for (uint32_t b = w0 >> 3; b <= (long_sb - 1) >> 3; b++) {
+      const uint32_t bl = (long_sb - 1) >> 3;
+      issue(w0 >> 3, cur);
+      for (uint32_t b = w0 >> 3; b <= bl; b++) {
+        issue(b < bl ? b + 1 : 0, nxt); // after the warm-up the main pass starts at block 0
         s2 xs[8], ys[8], ap[8];
-        load_xy(b, xs, ys, ap);
+        prep(cur, xs, ys, ap);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           uint32_t k = b * 8 + j;
@@ -431,6 +450,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
             }
           }
         }
+        cur = nxt;
       }
     }
     // hand every estimate to the next sub-block; the first one starts in state 0
@@ -450,13 +470,19 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     // decision needs are recovered as E1 + A1 (exact, wrapping).
     const bool fuse = dec1 && n >= 2;
 
+    uint32_t ck[8], tr[8], ckn[8], trn[8];
+    load_block(CK, 64 + lane, ck);
+    load_block(lut, pl, tr);
     for (uint32_t b = 0; b < nblk; b++) {
       const int len = (long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
       s2        xs[8], ys[8], ap[8];
-      uint32_t  ck[8], tr[8], eg[8];
-      load_xy(b, xs, ys, ap);
-      load_block(CK, (b + 1) * 64 + lane, ck);
-      load_block(lut, b * LPC + pl, tr);
+      uint32_t  eg[8];
+      if (b + 1 < nblk) {
+        issue(b + 1, nxt);
+        load_block(CK, (b + 2) * 64 + lane, ckn);
+        load_block(lut, (b + 1) * LPC + pl, trn);
+      }
+      prep(cur, xs, ys, ap);
       if (!dec1) {
         // decoder 2 hands app1 - ext1 to decoder 1: fetch the ext1 rows its outputs will land on
 #pragma unroll
@@ -464,33 +490,26 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           eg[j] = (j < len) ? E1[(size_t)(tr[j] & 0xffffu) * 64 + lane] : 0u;
         }
       }
-      // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point
-      s2 B[8][8];
+      // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point into
+      // this lane's private LDS slots (registers are needed for the prefetched operands)
+      {
+        s2 st[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if (j == len - 1) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            B[j][i] = from_u(ck[i]);
-          }
+        for (int i = 0; i < 8; i++) {
+          st[i] = from_u(ck[i]);
         }
-      }
+        Bl[len - 1][0][lane] = make_uint4(ck[0], ck[1], ck[2], ck[3]);
+        Bl[len - 1][1][lane] = make_uint4(ck[4], ck[5], ck[6], ck[7]);
 #pragma unroll
-      for (int j = 6; j >= 0; j--) {
-        if (j <= len - 2) {
-          s2 st[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            st[i] = B[j + 1][i];
-          }
-          uint32_t idx = b * 8 + j + 2; // index of the stored value we start from
-          if (idx != long_sb && (idx & 1) == 0) {
-            normalize(st);
-          }
-          beta_step(st, xs[j + 1], ys[j + 1]);
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            B[j][i] = st[i];
+        for (int j = 6; j >= 0; j--) {
+          if (j <= len - 2) {
+            uint32_t idx = b * 8 + j + 2; // index of the stored value we start from
+            if (idx != long_sb && (idx & 1) == 0) {
+              normalize(st);
+            }
+            beta_step(st, xs[j + 1], ys[j + 1]);
+            Bl[j][0][lane] = make_uint4(to_u(st[0]), to_u(st[1]), to_u(st[2]), to_u(st[3]));
+            Bl[j][1][lane] = make_uint4(to_u(st[4]), to_u(st[5]), to_u(st[6]), to_u(st[7]));
           }
         }
       }
@@ -499,7 +518,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       for (int j = 0; j < 8; j++) {
         outv[j] = 0;
         if (j < len) {
-          s2       llr = alpha_step<true>(o, B[j], xs[j], ys[j]);
+          const uint4 b0 = Bl[j][0][lane], b1 = Bl[j][1][lane];
+          const s2    B[8] = {from_u(b0.x), from_u(b0.y), from_u(b0.z), from_u(b0.w),
+                              from_u(b1.x), from_u(b1.y), from_u(b1.z), from_u(b1.w)};
+          s2       llr = alpha_step<true>(o, B, xs[j], ys[j]);
           uint32_t k   = b * 8 + j;
           if ((k & 1) == 0 && k != 0) {
             normalize(o);
@@ -522,6 +544,12 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           }
           dst[(size_t)(tr[j] & 0xffffu) * 64 + lane] = w;
         }
+      }
+      cur = nxt;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ck[i] = ckn[i];
+        tr[i] = trn[i];
       }
     }
     __syncthreads();

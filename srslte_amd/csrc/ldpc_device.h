@@ -10,9 +10,8 @@ struct Params {
   const int8_t*   llrs;      // n_cw x (N-2Z) int8, llr_stride bytes apart
   uint8_t*        msg;       // n_cw x K*Z bytes (bit per byte), msg_stride apart
   uint8_t*        iter_msgs; // optional: n_cw x max_iter x ceil(K*Z/8) packed hard decisions per iteration
-  const uint16_t* row_start; // bgM+1 : first edge of every base-graph row
-  const uint8_t*  col;       // per edge: variable node
-  const uint16_t* shift;     // per edge: circular shift (V mod Z)
+  const int*      row_start; // bgM+1 : first edge of every base-graph row
+  const int*      edges;     // per edge: (variable node * Z) | (circular shift V mod Z) << 16
   uint32_t        llr_stride;
   uint32_t        msg_stride;
   int             Z;

@@ -88,9 +88,8 @@ struct srsran_hip_ldpc_batch {
   int      sf       = 0;
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
-  uint16_t* d_row_start = nullptr;
-  uint8_t*  d_col       = nullptr;
-  uint16_t* d_shift     = nullptr;
+  int* d_row_start = nullptr;
+  int* d_edges     = nullptr;
 };
 
 extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran_basegraph_t bg, uint16_t ls,
@@ -137,12 +136,14 @@ extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran
   while (row < d.M) {
     h->row_start[++row] = (uint16_t)d.E;
   }
-  PHY_HIP_CHECK(hipMalloc(&h->d_row_start, (d.M + 1) * sizeof(uint16_t)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMalloc(&h->d_col, d.E), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMalloc(&h->d_shift, d.E * sizeof(uint16_t)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_row_start, h->row_start.data(), (d.M + 1) * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_col, col.data(), d.E, hipMemcpyHostToDevice), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_shift, shift.data(), d.E * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  std::vector<int> rs(h->row_start.begin(), h->row_start.end()), ed(d.E);
+  for (int e = 0; e < d.E; e++) {
+    ed[e] = (int)col[e] * (int)ls | ((int)shift[e] << 16);
+  }
+  PHY_HIP_CHECK(hipMalloc(&h->d_row_start, (d.M + 1) * sizeof(int)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMalloc(&h->d_edges, d.E * sizeof(int)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(h->d_edges, ed.data(), d.E * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
   *hh = h;
   return SRSRAN_SUCCESS;
 }
@@ -153,8 +154,7 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
     return;
   }
   hipFree(h->d_row_start);
-  hipFree(h->d_col);
-  hipFree(h->d_shift);
+  hipFree(h->d_edges);
   delete h;
 }
 
@@ -187,8 +187,7 @@ extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_
   p.msg        = d_message;
   p.iter_msgs  = d_iter_msgs;
   p.row_start  = h->d_row_start;
-  p.col        = h->d_col;
-  p.shift      = h->d_shift;
+  p.edges      = h->d_edges;
   p.llr_stride = llr_stride;
   p.msg_stride = msg_stride;
   p.Z          = Z;

@@ -23,6 +23,66 @@ namespace ldpc {
 
 #define LDPC_MAX_DEG 19 // BG1 rows 0-3; BG2 max is 10
 
+// One layer (base-graph row) for one lifted check node: all operand loads are issued before the first use
+// so that a layer costs two LDS round trips, not two per edge.
+template <int DEG>
+__device__ __forceinline__ void layer(int8_t* soft, int8_t* c2v, int my_edge, int e0, int c, int Z, int sf, bool active)
+{
+  int ed[DEG], idx[DEG], sb[DEG], co[DEG], v[DEG];
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    ed[i] = __builtin_amdgcn_readlane(my_edge, i);
+  }
+  if (!active) {
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    int j  = c + (ed[i] >> 16);
+    j      = j >= Z ? j - Z : j;
+    idx[i] = (ed[i] & 0xffff) + j;
+    sb[i]  = soft[idx[i]];
+    co[i]  = c2v[(e0 + i) * Z + c];
+  }
+  int min0 = 127, min1 = 127, pos = -1, neg = 0;
+  // var->check (ldpc_dec_c.c:338-363) fused with the check-node scan (:245-262)
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    int x;
+    if (sb[i] >= 127) {
+      x = 127;
+    } else if (sb[i] <= -127) {
+      x = -127;
+    } else {
+      x = sb[i] - co[i];
+      x = x > 63 ? 63 : (x < -63 ? -63 : x);
+    }
+    v[i]        = x;
+    const int a = x < 0 ? -x : x;
+    if (a < min0) {
+      min1 = min0;
+      min0 = a;
+      pos  = i;
+    } else if (a < min1) {
+      min1 = a;
+    }
+    neg ^= (x < 0);
+  }
+  // check->var (:265-281) and soft-bit update (:286-321)
+  const int s0 = min0 * sf / 100;
+  const int s1 = min1 * sf / 100;
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    const int mag  = (i == pos) ? s1 : s0;
+    const int sneg = neg ^ (v[i] < 0); // sign = product of all signs * own sign (v >= 0 counts as +)
+    const int cn   = sneg ? -mag : mag;
+    c2v[(e0 + i) * Z + c] = (int8_t)cn;
+    int tt = cn + v[i];
+    tt     = tt > 63 ? 127 : (tt < -63 ? -127 : tt);
+    soft[idx[i]] = (int8_t)tt;
+  }
+}
+
 __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
 {
   extern __shared__ int8_t lds[];
@@ -37,6 +97,10 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
   const int liftK = p.bgK * Z;
   int8_t*   soft  = lds + (size_t)cwl * (liftN + p.n_edges * Z);
   int8_t*   c2v   = soft + liftN;
+  int*      graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * (liftN + p.n_edges * Z) + 15) & ~(size_t)15));
+  for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
+    graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
+  }
 
   // init_ldpc_dec_c (ldpc_dec_c.c:170-188): punctured nodes 0,1 start at 0, all c2v at 0
   if (active) {
@@ -54,67 +118,38 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
 
   const int      sf        = p.sf;
   const int      msg_bytes = (liftK + 7) >> 3;
-  const uint16_t* __restrict__ row_start = p.row_start;
-  const uint8_t* __restrict__  col       = p.col;
-  const uint16_t* __restrict__ shift     = p.shift;
+  // the graph description lives in LDS behind the code-word state (wave-uniform broadcast reads):
+  //   row_start[l] : first edge of layer l ;  edges[e] = (col * Z) | shift << 16
+  const int* row_start = graph;
+  const int* edges     = graph + 48;
 
   for (int it = 0; it < p.max_iter; it++) {
     for (int l = 0; l < p.n_layers; l++) {
-      const int e0  = row_start[l];
-      const int deg = row_start[l + 1] - e0;
-      if (active) {
-        int v[LDPC_MAX_DEG];
-        int min0 = 127, min1 = 127, pos = -1, neg = 0;
-        // var->check (ldpc_dec_c.c:338-363) fused with the check-node scan (:245-262)
-#pragma unroll
-        for (int i = 0; i < LDPC_MAX_DEG; i++) {
-          v[i] = 0;
-          if (i < deg) {
-            const int e = e0 + i;
-            int       j = c + shift[e];
-            j           = j >= Z ? j - Z : j;
-            const int sb = soft[col[e] * Z + j];
-            const int co = c2v[e * Z + c];
-            int       x;
-            if (sb >= 127) {
-              x = 127;
-            } else if (sb <= -127) {
-              x = -127;
-            } else {
-              x = sb - co;
-              x = x > 63 ? 63 : (x < -63 ? -63 : x);
-            }
-            v[i]        = x;
-            const int a = x < 0 ? -x : x;
-            if (a < min0) {
-              min1 = min0;
-              min0 = a;
-              pos  = i;
-            } else if (a < min1) {
-              min1 = a;
-            }
-            neg ^= (x < 0);
-          }
-        }
-        // check->var (:265-281) and soft-bit update (:286-321)
-        const int s0 = min0 * sf / 100;
-        const int s1 = min1 * sf / 100;
-#pragma unroll
-        for (int i = 0; i < LDPC_MAX_DEG; i++) {
-          if (i < deg) {
-            const int e = e0 + i;
-            int       j = c + shift[e];
-            j           = j >= Z ? j - Z : j;
-            int mag     = (i == pos) ? s1 : s0;
-            // sign = prod of all signs * own sign  (v >= 0 counts as +)
-            const int sneg = neg ^ (v[i] < 0);
-            const int cn   = sneg ? -mag : mag;
-            c2v[e * Z + c] = (int8_t)cn;
-            int tt         = cn + v[i];
-            tt             = tt > 63 ? 127 : (tt < -63 ? -127 : tt);
-            soft[col[e] * Z + j] = (int8_t)tt;
-          }
-        }
+      // wave-uniform by construction; readfirstlane tells the compiler so (scalar switch, scalar addressing)
+      const int e0  = __builtin_amdgcn_readfirstlane(row_start[l]);
+      const int deg = __builtin_amdgcn_readfirstlane(row_start[l + 1]) - e0;
+      // one LDS read per wave fetches the whole row description; v_readlane broadcasts it into SGPRs
+      const int lane   = t & 63;
+      const int my_edge = edges[e0 + (lane < deg ? lane : 0)];
+      switch (deg) {
+#define LDPC_CASE(D)                                                                                                   \
+  case D:                                                                                                              \
+    layer<D>(soft, c2v, my_edge, e0, c, Z, sf, active);                                                                \
+    break;
+        LDPC_CASE(1)
+        LDPC_CASE(2)
+        LDPC_CASE(3)
+        LDPC_CASE(4)
+        LDPC_CASE(5)
+        LDPC_CASE(6)
+        LDPC_CASE(7)
+        LDPC_CASE(8)
+        LDPC_CASE(9)
+        LDPC_CASE(10)
+        LDPC_CASE(19)
+#undef LDPC_CASE
+        default:
+          break; // no such row degree in BG1/BG2 (host checks)
       }
       __syncthreads();
     }
@@ -149,7 +184,7 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
 
 size_t lds_bytes(const Params& p)
 {
-  return (size_t)p.cpb * (size_t)(p.bgN + p.n_edges) * p.Z;
+  return (((size_t)p.cpb * (size_t)(p.bgN + p.n_edges) * p.Z + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges) * sizeof(int);
 }
 
 hipError_t launch(const Params& p, hipStream_t stream)

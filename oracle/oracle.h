@@ -127,6 +127,9 @@ int  orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, ui
 /* find_sss.c:99-192 partial + sss.c:128-156; input points at the start of the SSS symbol (N samples) */
 int  orc_sss_m0m1_partial(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, uint32_t* m0,
                           uint32_t* m1, int* n_id_1, int* sf_idx);
+/* general form: M = 1 (full), 3 (partial) as srsran_sss_m0m1_partial; M = 0: srsran_sss_m0m1_diff */
+int  orc_sss_m0m1(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, uint32_t M, uint32_t* m0,
+                  float* m0_value, uint32_t* m1, float* m1_value, int* n_id_1, int* sf_idx);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,44 @@ class DftPrecoding(C.Structure):
     _fields_ = [("max_prb", C.c_uint32), ("dft_plan", DftPlan * 111)]
 
 
+class ConvFftCc(C.Structure):
+    _fields_ = [("input_fft", C.c_void_p), ("filter_fft", C.c_void_p), ("output_fft", C.c_void_p), ("output_fft2", C.c_void_p),
+                ("input_len", C.c_uint32), ("filter_len", C.c_uint32), ("output_len", C.c_uint32), ("max_input_len", C.c_uint32),
+                ("max_filter_len", C.c_uint32), ("input_plan", DftPlan), ("filter_plan", DftPlan), ("output_plan", DftPlan)]
+
+
+class FiltCc(C.Structure):
+    _fields_ = [("filter_input", C.c_void_p), ("downsampled_input", C.c_void_p), ("filter_output", C.c_void_p),
+                ("is_decimator", C.c_bool), ("factor", C.c_int), ("num_taps", C.c_int), ("taps", C.c_void_p)]
+
+
+class Pss(C.Structure):
+    _fields_ = [("conv_fft", ConvFftCc), ("filter", FiltCc), ("decimate", C.c_int), ("max_frame_size", C.c_uint32),
+                ("max_fft_size", C.c_uint32), ("frame_size", C.c_uint32), ("N_id_2", C.c_uint32), ("fft_size", C.c_uint32),
+                ("pss_signal_freq_full", C.c_void_p * 3), ("pss_signal_time", C.c_void_p * 3),
+                ("pss_signal_time_scale", C.c_void_p * 3), ("pss_signal_freq", (C.c_float * 124) * 3), ("tmp_input", C.c_void_p),
+                ("conv_output", C.c_void_p), ("conv_output_abs", C.c_void_p), ("ema_alpha", C.c_float),
+                ("conv_output_avg", C.POINTER(C.c_float)), ("peak_value", C.c_float), ("filter_pss_enable", C.c_bool),
+                ("dftp_input", DftPlan), ("idftp_input", DftPlan), ("tmp_fft", C.c_float * 4096), ("tmp_fft2", C.c_float * 4096),
+                ("tmp_ce", C.c_float * 124), ("chest_on_filter", C.c_bool)]
+
+
+class SssFcTables(C.Structure):
+    _fields_ = [("z1", (C.c_float * 31) * 31), ("c", (C.c_float * 31) * 2), ("s", (C.c_float * 31) * 31), ("sd", (C.c_float * 30) * 31)]
+
+
+class Sss(C.Structure):
+    _fields_ = [("dftp_input", DftPlan), ("fft_size", C.c_uint32), ("max_fft_size", C.c_uint32), ("corr_peak_threshold", C.c_float),
+                ("symbol_sz", C.c_uint32), ("subframe_sz", C.c_uint32), ("N_id_2", C.c_uint32), ("N_id_1_table", (C.c_uint32 * 30) * 30),
+                ("fc_tables", SssFcTables * 3), ("corr_output_m0", C.c_float * 31), ("corr_output_m1", C.c_float * 31)]
+
+
+class HipCell(C.Structure):
+    _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
+                ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
+                ("sf_idx", C.c_uint32)]
+
+
 class OfdmCfg(C.Structure):
     _fields_ = [("nof_prb", C.c_uint32), ("in_buffer", C.c_void_p), ("out_buffer", C.c_void_p), ("cp", C.c_int),
                 ("sf_type", C.c_int), ("normalize", C.c_bool), ("freq_shift_f", C.c_float),
@@ -173,6 +211,35 @@ def lib():
             "srsran_hip_dft_batch_create": (i32, [C.POINTER(vp), i32, i32, C.c_bool, C.c_bool, C.c_bool]),
             "srsran_hip_dft_batch_free": (None, [vp]),
             "srsran_hip_dft_batch_run": (i32, [vp, vp, vp, u32, vp]),
+            "srsran_pss_init_fft": (i32, [C.POINTER(Pss), u32, u32]),
+            "srsran_pss_init_fft_offset": (i32, [C.POINTER(Pss), u32, u32, i32]),
+            "srsran_pss_init_fft_offset_decim": (i32, [C.POINTER(Pss), u32, u32, i32, i32]),
+            "srsran_pss_init": (i32, [C.POINTER(Pss), u32]),
+            "srsran_pss_resize": (i32, [C.POINTER(Pss), u32, u32, i32]),
+            "srsran_pss_free": (None, [C.POINTER(Pss)]),
+            "srsran_pss_reset": (None, [C.POINTER(Pss)]),
+            "srsran_pss_generate": (i32, [vp, u32]),
+            "srsran_pss_put_slot": (None, [vp, vp, u32, i32]),
+            "srsran_pss_get_slot": (None, [vp, vp, u32, i32]),
+            "srsran_pss_set_ema_alpha": (None, [C.POINTER(Pss), C.c_float]),
+            "srsran_pss_set_N_id_2": (i32, [C.POINTER(Pss), u32]),
+            "srsran_pss_find_pss": (i32, [C.POINTER(Pss), vp, C.POINTER(C.c_float)]),
+            "srsran_sss_init": (i32, [C.POINTER(Sss), u32]),
+            "srsran_sss_resize": (i32, [C.POINTER(Sss), u32]),
+            "srsran_sss_free": (None, [C.POINTER(Sss)]),
+            "srsran_sss_generate": (None, [vp, vp, u32]),
+            "srsran_sss_put_slot": (None, [vp, vp, u32, i32]),
+            "srsran_sss_set_N_id_2": (i32, [C.POINTER(Sss), u32]),
+            "srsran_sss_set_threshold": (None, [C.POINTER(Sss), C.c_float]),
+            "srsran_sss_m0m1_partial": (i32, [C.POINTER(Sss), vp, u32, vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(C.c_float)]),
+            "srsran_sss_m0m1_diff": (i32, [C.POINTER(Sss), vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(C.c_float)]),
+            "srsran_sss_m0m1_diff_coh": (i32, [C.POINTER(Sss), vp, vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(C.c_float)]),
+            "srsran_sss_subframe": (u32, [u32, u32]),
+            "srsran_sss_N_id_1": (i32, [C.POINTER(Sss), u32, u32, C.c_float]),
+            "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
+            "srsran_hip_cellsearch_free": (None, [vp]),
+            "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),
+            "srsran_hip_cellsearch_corr": (vp, [vp, u32, u32]),
             "srsran_symbol_sz": (i32, [u32]),
             "srsran_symbol_sz_power2": (i32, [u32]),
             "srsran_use_standard_symbol_size": (None, [C.c_bool]),

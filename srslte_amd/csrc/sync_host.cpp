@@ -1,0 +1,817 @@
+// sync_host.cpp -- host side of the PSS / SSS search: replica + table generation, engines, handle ABI,
+// batched cell search.
+//
+// Mirrors (interface + behaviour) lib/src/phy/sync/pss.c, sss.c, find_sss.c, gen_sss.c and the default
+// path of srsran_sync_find (sync.c:629-843) of the reference.
+#include "hip_common.h"
+#include "srsran_amd/phy_sync_abi.h"
+#include "sync_device.h"
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+using namespace phyhip;
+typedef std::complex<double> cd;
+
+static int cp_len_of(uint32_t symbol_sz, int c)
+{
+  return (int)ceilf((((float)(c) * (symbol_sz)) / 2048.0f)); // SRSRAN_CP_LEN, phy_common.h:125
+}
+
+// ------------------------------------------------------------------------------------------------ sequences
+
+extern "C" int srsran_pss_generate(cf_t* signal, uint32_t N_id_2)
+{
+  // pss.c:341-368: Zadoff-Chu roots 25/29/34, length 63 with the DC element punctured, float arithmetic
+  const float root_value[] = {25.0, 29.0, 34.0};
+  if (N_id_2 > 2) {
+    fprintf(stderr, "Invalid N_id_2 %d\n", N_id_2);
+    return -1;
+  }
+  const int sign = -1;
+  for (int i = 0; i < SRSRAN_PSS_LEN / 2; i++) {
+    float arg = (float)sign * M_PI * root_value[N_id_2] * ((float)i * ((float)i + 1.0)) / 63.0;
+    signal[i] = cf_t(cosf(arg), sinf(arg));
+  }
+  for (int i = SRSRAN_PSS_LEN / 2; i < SRSRAN_PSS_LEN; i++) {
+    float arg = (float)sign * M_PI * root_value[N_id_2] * (((float)i + 2.0) * ((float)i + 1.0)) / 63.0;
+    signal[i] = cf_t(cosf(arg), sinf(arg));
+  }
+  return 0;
+}
+
+extern "C" void srsran_pss_put_slot(cf_t* pss_signal, cf_t* slot, uint32_t nof_prb, srsran_cp_t cp)
+{
+  const int nsym = cp == SRSRAN_CP_NORM ? 7 : 6;
+  int       k    = (nsym - 1) * nof_prb * 12 + nof_prb * 12 / 2 - 31;
+  memset((void*)&slot[k - 5], 0, 5 * sizeof(cf_t));
+  memcpy((void*)&slot[k], pss_signal, SRSRAN_PSS_LEN * sizeof(cf_t));
+  memset((void*)&slot[k + SRSRAN_PSS_LEN], 0, 5 * sizeof(cf_t));
+}
+
+extern "C" void srsran_pss_get_slot(cf_t* slot, cf_t* pss_signal, uint32_t nof_prb, srsran_cp_t cp)
+{
+  const int nsym = cp == SRSRAN_CP_NORM ? 7 : 6;
+  int       k    = (nsym - 1) * nof_prb * 12 + nof_prb * 12 / 2 - 31;
+  memcpy((void*)pss_signal, &slot[k], SRSRAN_PSS_LEN * sizeof(cf_t));
+}
+
+namespace {
+
+// gen_sss.c:31-53: the three m-sequences
+void zsc_tilde(int* z_tilde, int* s_tilde, int* c_tilde)
+{
+  int x[SRSRAN_SSS_N];
+  memset(x, 0, sizeof(x));
+  x[4] = 1;
+  for (int i = 0; i < 26; i++) {
+    x[i + 5] = (x[i + 2] + x[i]) % 2;
+  }
+  for (int i = 0; i < SRSRAN_SSS_N; i++) {
+    s_tilde[i] = 1 - 2 * x[i];
+  }
+  for (int i = 0; i < 26; i++) {
+    x[i + 5] = (x[i + 3] + x[i]) % 2;
+  }
+  for (int i = 0; i < SRSRAN_SSS_N; i++) {
+    c_tilde[i] = 1 - 2 * x[i];
+  }
+  for (int i = 0; i < 26; i++) {
+    x[i + 5] = (x[i + 4] + x[i + 2] + x[i + 1] + x[i]) % 2;
+  }
+  for (int i = 0; i < SRSRAN_SSS_N; i++) {
+    z_tilde[i] = 1 - 2 * x[i];
+  }
+}
+
+void m0m1_of(uint32_t N_id_1, uint32_t* m0, uint32_t* m1)
+{
+  uint32_t q_prime = N_id_1 / (SRSRAN_SSS_N - 1);
+  uint32_t q       = (N_id_1 + (q_prime * (q_prime + 1) / 2)) / (SRSRAN_SSS_N - 1);
+  uint32_t m_prime = N_id_1 + (q * (q + 1) / 2);
+  *m0              = m_prime % SRSRAN_SSS_N;
+  *m1              = (*m0 + m_prime / SRSRAN_SSS_N + 1) % SRSRAN_SSS_N;
+}
+
+// time-domain replica of pss.c:31-62 evaluated in double: conj(IDFT_{mirror,dc,norm}(padded ZC)) / 62
+void pss_time_replica(uint32_t N_id_2, uint32_t N, int cfo_i, cf_t* freq62, std::vector<cf_t>& time)
+{
+  srsran_pss_generate(freq62, N_id_2);
+  std::vector<cd> pad(N, cd(0, 0)), dst(N, cd(0, 0));
+  for (int j = 0; j < SRSRAN_PSS_LEN; j++) {
+    pad[(N - SRSRAN_PSS_LEN) / 2 + cfo_i + j] = cd(freq62[j].real(), freq62[j].imag());
+  }
+  // copy_pre for a backward transform with mirror + dc (dft_fftw.c:297-308)
+  const uint32_t hlen = N / 2;
+  for (uint32_t i = 0; i + hlen + 1 < N + 0 && i < N - hlen - 1; i++) {
+    dst[1 + i] = pad[hlen + i];
+  }
+  for (uint32_t i = 0; i < hlen; i++) {
+    dst[N - hlen + i] = pad[i];
+  }
+  time.assign(N, cf_t(0, 0));
+  const double norm = 1.0 / sqrt((double)N);
+  // only <= 63 bins are non-zero: direct sum
+  std::vector<uint32_t> nz;
+  for (uint32_t k = 0; k < N; k++) {
+    if (dst[k] != cd(0, 0)) {
+      nz.push_back(k);
+    }
+  }
+  for (uint32_t n = 0; n < N; n++) {
+    cd acc(0, 0);
+    for (uint32_t k : nz) {
+      double a = 2.0 * M_PI * (double)((uint64_t)k * n % N) / (double)N;
+      acc += dst[k] * cd(cos(a), sin(a));
+    }
+    acc *= norm;
+    // conj, then * (float)(1/62) as srsran_vec_sc_prod_cfc
+    float re = (float)acc.real(), im = -(float)acc.imag();
+    float sc = (float)(1.0 / SRSRAN_PSS_LEN);
+    time[n]  = cf_t(re * sc, im * sc);
+  }
+}
+
+struct PssEngine {
+  uint32_t frame_size = 0, fft_size = 0, max_caps = 0;
+  int      n_blocks = 0, hop = 0, n_out = 0;
+  size_t   corr_stride = 0;
+  float2*  d_tw = nullptr;
+  float2*  d_filt = nullptr;
+  float*   d_corr = nullptr;
+  float*   d_part_val = nullptr;
+  int*     d_part_idx = nullptr;
+  sync::PssResult* d_res = nullptr;
+  cf_t     freq[3][SRSRAN_PSS_LEN];
+  std::vector<cf_t> time[3];
+};
+
+void pss_engine_free(PssEngine* e)
+{
+  if (!e) {
+    return;
+  }
+  (void)hipFree(e->d_tw);
+  (void)hipFree(e->d_filt);
+  (void)hipFree(e->d_corr);
+  (void)hipFree(e->d_part_val);
+  (void)hipFree(e->d_part_idx);
+  (void)hipFree(e->d_res);
+  delete e;
+}
+
+PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uint32_t max_caps)
+{
+  if (!device_available()) {
+    return nullptr;
+  }
+  if (fft_size > 2048 || fft_size < 64 || frame_size < fft_size) {
+    set_error("PSS: unsupported sizes frame=%u fft=%u (fft <= 2048, frame >= fft)", frame_size, fft_size);
+    return nullptr;
+  }
+  auto* e        = new PssEngine;
+  e->frame_size  = frame_size;
+  e->fft_size    = fft_size;
+  e->max_caps    = max_caps;
+  e->hop         = 4096 - (int)fft_size;
+  e->n_out       = (int)(frame_size + fft_size) - 2; // pss.c:493: |.|^2 over conv_output_len - 1 entries
+  e->n_blocks    = (e->n_out + e->hop - 1) / e->hop;
+  e->corr_stride = ((size_t)frame_size + fft_size + 2 + 3) & ~(size_t)3;
+  std::vector<std::complex<float>> tw(4096), filt(3 * 4096);
+  for (int i = 0; i < 4096; i++) {
+    double a = -2.0 * M_PI * (double)i / 4096.0;
+    tw[i]    = std::complex<float>((float)cos(a), (float)sin(a));
+  }
+  for (uint32_t h = 0; h < 3; h++) {
+    pss_time_replica(h, fft_size, cfo_i, e->freq[h], e->time[h]);
+    for (int k = 0; k < 4096; k++) {
+      cd acc(0, 0);
+      for (uint32_t n = 0; n < fft_size; n++) {
+        double a = -2.0 * M_PI * (double)(((uint64_t)k * n) & 4095) / 4096.0;
+        acc += cd(e->time[h][n].real(), e->time[h][n].imag()) * cd(cos(a), sin(a));
+      }
+      acc /= 4096.0;
+      filt[h * 4096 + k] = std::complex<float>((float)acc.real(), (float)acc.imag());
+    }
+  }
+  bool ok = hipMalloc(&e->d_tw, 4096 * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&e->d_filt, 3 * 4096 * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&e->d_corr, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess &&
+            hipMalloc(&e->d_part_val, (size_t)max_caps * 3 * e->n_blocks * sizeof(float)) == hipSuccess &&
+            hipMalloc(&e->d_part_idx, (size_t)max_caps * 3 * e->n_blocks * sizeof(int)) == hipSuccess &&
+            hipMalloc(&e->d_res, (size_t)max_caps * 3 * sizeof(sync::PssResult)) == hipSuccess &&
+            hipMemcpy(e->d_tw, tw.data(), 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(e->d_filt, filt.data(), 3 * 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemset(e->d_corr, 0, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess;
+  if (!ok) {
+    set_error("PSS: device allocation failed");
+    pss_engine_free(e);
+    return nullptr;
+  }
+  return e;
+}
+
+// hypothesis slot 0 of the launch is bound to filter `first_filter` (the handle API searches ONE N_id_2 and
+// shares one averaging buffer between them, like the reference)
+int pss_engine_run(PssEngine* e, const void* d_in, uint32_t n_cap, int mask, int first_filter, float ema_alpha, hipStream_t st)
+{
+  sync::PssParams p;
+  p.in          = d_in;
+  p.twiddle     = e->d_tw;
+  p.filt        = e->d_filt + (size_t)first_filter * 4096;
+  p.corr        = e->d_corr;
+  p.part_val    = e->d_part_val;
+  p.part_idx    = e->d_part_idx;
+  p.in_stride   = e->frame_size;
+  p.corr_stride = e->corr_stride;
+  p.n_cap       = (int)n_cap;
+  p.n_blocks    = e->n_blocks;
+  p.hop         = e->hop;
+  p.fft_size    = (int)e->fft_size;
+  p.frame_size  = (int)e->frame_size;
+  p.n_out       = e->n_out;
+  p.n_id_2_mask = mask;
+  p.ema_alpha   = ema_alpha;
+  PHY_HIP_CHECK(sync::launch_pss(p, e->d_res, st), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+struct SssEngine {
+  uint32_t fft_size = 0;
+  float2*  d_tw = nullptr;
+  float*   d_seq = nullptr; // s_tilde, c_tilde, z_tilde (3 x 31)
+};
+
+void sss_engine_free(SssEngine* e)
+{
+  if (!e) {
+    return;
+  }
+  (void)hipFree(e->d_tw);
+  (void)hipFree(e->d_seq);
+  delete e;
+}
+
+SssEngine* sss_engine_new(uint32_t fft_size)
+{
+  if (!device_available()) {
+    return nullptr;
+  }
+  auto* e     = new SssEngine;
+  e->fft_size = fft_size;
+  std::vector<std::complex<float>> tw(fft_size);
+  for (uint32_t i = 0; i < fft_size; i++) {
+    double a = -2.0 * M_PI * (double)i / (double)fft_size;
+    tw[i]    = std::complex<float>((float)cos(a), (float)sin(a));
+  }
+  int   zt[31], st[31], ct[31];
+  float seq[93];
+  zsc_tilde(zt, st, ct);
+  for (int i = 0; i < 31; i++) {
+    seq[i]      = (float)st[i];
+    seq[31 + i] = (float)ct[i];
+    seq[62 + i] = (float)zt[i];
+  }
+  bool ok = hipMalloc(&e->d_tw, fft_size * sizeof(float2)) == hipSuccess && hipMalloc(&e->d_seq, sizeof(seq)) == hipSuccess &&
+            hipMemcpy(e->d_tw, tw.data(), fft_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(e->d_seq, seq, sizeof(seq), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    set_error("SSS: device allocation failed");
+    sss_engine_free(e);
+    return nullptr;
+  }
+  return e;
+}
+
+void sss_params(sync::SssParams* p, const SssEngine* e, const void* d_in, size_t in_stride, uint32_t n_cap, uint32_t frame_size,
+                srsran_cp_t cp, int M, int mask, float threshold, const int* d_pos, const void* d_ce)
+{
+  p->in          = d_in;
+  p->twiddle     = e->d_tw;
+  p->s_tilde     = e->d_seq;
+  p->c_tilde     = e->d_seq + 31;
+  p->z_tilde     = e->d_seq + 62;
+  p->sss_pos     = d_pos;
+  p->ce          = d_ce;
+  p->in_stride   = in_stride;
+  p->n_cap       = (int)n_cap;
+  p->fft_size    = (int)e->fft_size;
+  p->frame_size  = (int)frame_size;
+  p->cp_len      = cp == SRSRAN_CP_NORM ? cp_len_of(e->fft_size, 144) : cp_len_of(e->fft_size, 512);
+  p->cp_ext_len  = cp_len_of(e->fft_size, 512);
+  p->M           = M;
+  p->n_id_2_mask = mask;
+  p->threshold   = threshold;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ PSS handle ABI
+
+namespace {
+struct PssCtx {
+  PssEngine*  e = nullptr;
+  hipStream_t stream = nullptr;
+  float2*     d_in = nullptr;
+  cf_t*       h_in = nullptr;
+  float*      h_avg = nullptr;
+  sync::PssResult* h_res = nullptr;
+  int         cfo_i = 0;
+};
+PssCtx* pctx(srsran_pss_t* q)
+{
+  return reinterpret_cast<PssCtx*>(q->conv_fft.input_fft);
+}
+void pctx_free(PssCtx* c)
+{
+  if (!c) {
+    return;
+  }
+  pss_engine_free(c->e);
+  (void)hipFree(c->d_in);
+  (void)hipHostFree(c->h_in);
+  (void)hipHostFree(c->h_avg);
+  (void)hipHostFree(c->h_res);
+  if (c->stream) {
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+int pss_setup(srsran_pss_t* q, uint32_t frame_size, uint32_t fft_size, int offset)
+{
+  PssCtx* c = pctx(q);
+  if (c->e) {
+    pss_engine_free(c->e);
+    c->e = nullptr;
+  }
+  c->e = pss_engine_new(frame_size, fft_size, offset, 1);
+  if (!c->e) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  c->cfo_i = offset;
+  for (int h = 0; h < 3; h++) {
+    memcpy((void*)q->pss_signal_freq[h], c->e->freq[h], sizeof(c->e->freq[h]));
+    memset((void*)q->pss_signal_time[h], 0, sizeof(cf_t) * (q->max_fft_size + q->max_frame_size + 1));
+    memcpy((void*)q->pss_signal_time[h], c->e->time[h].data(), sizeof(cf_t) * fft_size);
+  }
+  memset(q->conv_output_avg, 0, sizeof(float) * (q->max_fft_size + q->max_frame_size + 1));
+  return SRSRAN_SUCCESS;
+}
+} // namespace
+
+extern "C" int srsran_pss_init_fft_offset_decim(srsran_pss_t* q, uint32_t max_frame_size, uint32_t max_fft_size, int offset, int decimate)
+{
+  if (q == NULL) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  memset(q, 0, sizeof(srsran_pss_t));
+  if (decimate > 1) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss: decimated PSS search is not implemented in the HIP engine\n");
+    return SRSRAN_ERROR;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  q->N_id_2         = 10;
+  q->ema_alpha      = 0.2;
+  q->max_fft_size   = max_fft_size;
+  q->max_frame_size = max_frame_size;
+  q->decimate       = decimate;
+  q->fft_size       = max_fft_size;
+  q->frame_size     = max_frame_size;
+  const size_t buffer_size = (size_t)max_fft_size + max_frame_size + 1;
+  auto* c = new PssCtx;
+  q->conv_fft.input_fft = reinterpret_cast<cf_t*>(c);
+  q->conv_output_avg    = (float*)calloc(buffer_size, sizeof(float));
+  q->conv_output_abs    = (float*)calloc(buffer_size, sizeof(float));
+  for (int h = 0; h < 3; h++) {
+    q->pss_signal_time[h] = (cf_t*)calloc(buffer_size, sizeof(cf_t));
+  }
+  bool ok = q->conv_output_avg && q->conv_output_abs && q->pss_signal_time[0] && q->pss_signal_time[1] && q->pss_signal_time[2] &&
+            hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&c->d_in, (size_t)max_frame_size * sizeof(float2)) == hipSuccess &&
+            hipHostMalloc(&c->h_in, (size_t)max_frame_size * sizeof(cf_t)) == hipSuccess &&
+            hipHostMalloc(&c->h_avg, buffer_size * sizeof(float)) == hipSuccess &&
+            hipHostMalloc(&c->h_res, 3 * sizeof(sync::PssResult)) == hipSuccess;
+  if (!ok || pss_setup(q, max_frame_size, max_fft_size, offset)) {
+    srsran_pss_free(q);
+    return SRSRAN_ERROR;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_pss_init_fft_offset(srsran_pss_t* q, uint32_t frame_size, uint32_t fft_size, int offset)
+{
+  return srsran_pss_init_fft_offset_decim(q, frame_size, fft_size, offset, 1);
+}
+
+extern "C" int srsran_pss_init_fft(srsran_pss_t* q, uint32_t frame_size, uint32_t fft_size)
+{
+  return srsran_pss_init_fft_offset(q, frame_size, fft_size, 0);
+}
+
+extern "C" int srsran_pss_init(srsran_pss_t* q, uint32_t frame_size)
+{
+  return srsran_pss_init_fft(q, frame_size, 128);
+}
+
+extern "C" int srsran_pss_resize(srsran_pss_t* q, uint32_t frame_size, uint32_t fft_size, int offset)
+{
+  if (q == NULL) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (fft_size > q->max_fft_size || frame_size > q->max_frame_size) {
+    fprintf(stderr, "Error in pss_config(): fft_size and frame_size must be lower than initialized\n");
+    return SRSRAN_ERROR;
+  }
+  q->N_id_2     = 10;
+  q->ema_alpha  = 0.2;
+  q->fft_size   = fft_size;
+  q->frame_size = frame_size;
+  return pss_setup(q, frame_size, fft_size, offset);
+}
+
+extern "C" void srsran_pss_free(srsran_pss_t* q)
+{
+  if (!q) {
+    return;
+  }
+  pctx_free(pctx(q));
+  for (int h = 0; h < 3; h++) {
+    free(q->pss_signal_time[h]);
+  }
+  free(q->conv_output_avg);
+  free(q->conv_output_abs);
+  memset(q, 0, sizeof(srsran_pss_t));
+}
+
+extern "C" void srsran_pss_reset(srsran_pss_t* q)
+{
+  PssCtx* c = pctx(q);
+  memset(q->conv_output_avg, 0, sizeof(float) * (q->fft_size + q->frame_size + 1));
+  if (c && c->e) {
+    (void)hipMemsetAsync(c->e->d_corr, 0, c->e->corr_stride * sizeof(float), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+  }
+}
+
+extern "C" int srsran_pss_set_N_id_2(srsran_pss_t* q, uint32_t N_id_2)
+{
+  if (N_id_2 > 2) {
+    fprintf(stderr, "Invalid N_id_2 %d\n", N_id_2);
+    return -1;
+  }
+  q->N_id_2 = N_id_2;
+  return 0;
+}
+
+extern "C" void srsran_pss_set_ema_alpha(srsran_pss_t* q, float alpha)
+{
+  q->ema_alpha = alpha;
+}
+
+extern "C" int srsran_pss_find_pss(srsran_pss_t* q, const cf_t* input, float* corr_peak_value)
+{
+  if (q == NULL || input == NULL) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (q->N_id_2 > 2) {
+    fprintf(stderr, "Error finding PSS peak, Must set N_id_2 first\n");
+    return SRSRAN_ERROR;
+  }
+  PssCtx* c = pctx(q);
+  if (!c || !c->e) {
+    return SRSRAN_ERROR;
+  }
+  if (q->frame_size < q->fft_size) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss_find_pss: frame_size < fft_size (sliding dot-product mode) is not implemented\n");
+    return SRSRAN_ERROR;
+  }
+  const size_t nb = (size_t)q->frame_size * sizeof(cf_t);
+  memcpy(c->h_in, input, nb);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, nb, hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
+  if (pss_engine_run(c->e, c->d_in, 1, 1, (int)q->N_id_2, q->ema_alpha, c->stream)) {
+    return SRSRAN_ERROR;
+  }
+  const size_t n_avg = (size_t)c->e->n_out;
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_res, c->e->d_res, sizeof(sync::PssResult), hipMemcpyDeviceToHost, c->stream), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_avg, c->e->d_corr, n_avg * sizeof(float), hipMemcpyDeviceToHost, c->stream), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(c->stream), SRSRAN_ERROR);
+  memcpy(q->conv_output_avg, c->h_avg, n_avg * sizeof(float));
+  q->peak_value = c->h_res->peak_value;
+  if (corr_peak_value) {
+    *corr_peak_value = c->h_res->psr; // SRSRAN_PSS_RETURN_PSR (pss.h:61)
+  }
+  return c->h_res->peak_pos;
+}
+
+// ------------------------------------------------------------------------------------------------ SSS handle ABI
+
+namespace {
+struct SssCtx {
+  SssEngine*  e = nullptr;
+  hipStream_t stream = nullptr;
+  float2*     d_in = nullptr;
+  float2*     d_ce = nullptr;
+  int*        d_pos = nullptr;
+  sync::SssResult* d_res = nullptr;
+  cf_t*       h_in = nullptr;
+  sync::SssResult* h_res = nullptr;
+};
+SssCtx* sctx(srsran_sss_t* q)
+{
+  return reinterpret_cast<SssCtx*>(q->dftp_input.p);
+}
+} // namespace
+
+extern "C" void srsran_sss_generate(float* signal0, float* signal5, uint32_t cell_id)
+{
+  // gen_sss.c:125-163
+  uint32_t id1 = cell_id / 3, id2 = cell_id % 3, m0, m1;
+  int      s_t[SRSRAN_SSS_N], c_t[SRSRAN_SSS_N], z_t[SRSRAN_SSS_N];
+  m0m1_of(id1, &m0, &m1);
+  zsc_tilde(z_t, s_t, c_t);
+  for (int i = 0; i < SRSRAN_SSS_N; i++) {
+    int s0 = s_t[(i + m0) % 31], s1 = s_t[(i + m1) % 31];
+    int c0 = c_t[(i + id2) % 31], c1 = c_t[(i + id2 + 3) % 31];
+    int z10 = z_t[(i + (m0 % 8)) % 31], z11 = z_t[(i + (m1 % 8)) % 31];
+    signal0[2 * i]     = (float)(s0 * c0);
+    signal0[2 * i + 1] = (float)(s1 * c1 * z10);
+    signal5[2 * i]     = (float)(s1 * c0);
+    signal5[2 * i + 1] = (float)(s0 * c1 * z11);
+  }
+}
+
+extern "C" void srsran_sss_put_slot(float* sss, cf_t* slot, uint32_t nof_prb, srsran_cp_t cp)
+{
+  const uint32_t nsym = cp == SRSRAN_CP_NORM ? 7 : 6;
+  uint32_t       k    = (nsym - 2) * nof_prb * 12 + nof_prb * 12 / 2 - 31;
+  if (k > 5) {
+    memset((void*)&slot[k - 5], 0, 5 * sizeof(cf_t));
+    for (uint32_t i = 0; i < SRSRAN_SSS_LEN; i++) {
+      slot[k + i] = cf_t(sss[i], 0);
+    }
+    memset((void*)&slot[k + SRSRAN_SSS_LEN], 0, 5 * sizeof(cf_t));
+  }
+}
+
+extern "C" void srsran_sss_free(srsran_sss_t* q)
+{
+  SssCtx* c = sctx(q);
+  if (c) {
+    sss_engine_free(c->e);
+    (void)hipFree(c->d_in);
+    (void)hipFree(c->d_ce);
+    (void)hipFree(c->d_pos);
+    (void)hipFree(c->d_res);
+    (void)hipHostFree(c->h_in);
+    (void)hipHostFree(c->h_res);
+    if (c->stream) {
+      (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+  }
+  memset(q, 0, sizeof(srsran_sss_t));
+}
+
+extern "C" int srsran_sss_init(srsran_sss_t* q, uint32_t fft_size)
+{
+  if (q == NULL || fft_size > 2048) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  memset(q, 0, sizeof(srsran_sss_t));
+  auto* c = new SssCtx;
+  q->dftp_input.p = c;
+  c->e            = sss_engine_new(fft_size);
+  int zero        = 0;
+  bool ok = c->e && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc(&c->d_in, (size_t)fft_size * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&c->d_ce, 3 * 62 * sizeof(float2)) == hipSuccess && hipMalloc(&c->d_pos, 3 * sizeof(int)) == hipSuccess &&
+            hipMalloc(&c->d_res, 3 * sizeof(sync::SssResult)) == hipSuccess &&
+            hipHostMalloc(&c->h_in, ((size_t)fft_size + 62) * sizeof(cf_t)) == hipSuccess &&
+            hipHostMalloc(&c->h_res, 3 * sizeof(sync::SssResult)) == hipSuccess &&
+            hipMemset(c->d_pos, 0, 3 * sizeof(int)) == hipSuccess;
+  (void)zero;
+  if (!ok) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_sss_init: %s\n", get_error());
+    srsran_sss_free(q);
+    return SRSRAN_ERROR;
+  }
+  q->dftp_input.size      = (int)fft_size;
+  q->dftp_input.init_size = (int)fft_size;
+  q->dftp_input.forward   = true;
+  q->dftp_input.mirror    = true;
+  q->dftp_input.dc        = true;
+  q->fft_size             = fft_size;
+  q->max_fft_size         = fft_size;
+  // gen_sss.c:64-73 and find_sss.c:194-225
+  for (uint32_t id = 0; id < 168; id++) {
+    uint32_t m0, m1;
+    m0m1_of(id, &m0, &m1);
+    q->N_id_1_table[m0][m1 - 1] = id;
+  }
+  int zt[31], st[31], ct[31];
+  zsc_tilde(zt, st, ct);
+  for (uint32_t h = 0; h < 3; h++) {
+    srsran_sss_fc_tables_t* t = &q->fc_tables[h];
+    for (int i = 0; i < 31; i++) {
+      for (int j = 0; j < 31; j++) {
+        t->z1[i][j] = (float)zt[(j + (i % 8)) % 31];
+        t->s[i][j]  = (float)st[(j + i) % 31];
+      }
+      for (int j = 0; j < 30; j++) {
+        t->sd[i][j] = (float)(st[(j + 1 + i) % 31] * st[(j + i) % 31]);
+      }
+      t->c[0][i] = (float)ct[(i + h) % 31];
+      t->c[1][i] = (float)ct[(i + h + 3) % 31];
+    }
+  }
+  q->N_id_2 = 0;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_sss_resize(srsran_sss_t* q, uint32_t fft_size)
+{
+  if (q == NULL || fft_size > 2048) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (fft_size > q->max_fft_size) {
+    fprintf(stderr, "Error in sss_synch_resize(): fft_size must be lower than initialized\n");
+    return SRSRAN_ERROR;
+  }
+  SssCtx* c = sctx(q);
+  sss_engine_free(c->e);
+  c->e = sss_engine_new(fft_size);
+  if (!c->e) {
+    return SRSRAN_ERROR;
+  }
+  q->fft_size        = fft_size;
+  q->dftp_input.size = (int)fft_size;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_sss_set_N_id_2(srsran_sss_t* q, uint32_t N_id_2)
+{
+  if (N_id_2 > 2) {
+    fprintf(stderr, "Invalid N_id_2 %d\n", N_id_2);
+    return SRSRAN_ERROR;
+  }
+  q->N_id_2 = N_id_2;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_sss_set_threshold(srsran_sss_t* q, float threshold)
+{
+  q->corr_peak_threshold = threshold;
+}
+
+extern "C" uint32_t srsran_sss_subframe(uint32_t m0, uint32_t m1)
+{
+  return m1 > m0 ? 0 : 5;
+}
+
+extern "C" int srsran_sss_N_id_1(srsran_sss_t* q, uint32_t m0, uint32_t m1, float corr)
+{
+  int N_id_1 = SRSRAN_ERROR;
+  if (corr > q->corr_peak_threshold) { // sss.c:139-156
+    if (m1 > m0) {
+      if (m0 < 30 && m1 - 1 < 30) {
+        N_id_1 = (int)q->N_id_1_table[m0][m1 - 1];
+      }
+    } else {
+      if (m1 < 30 && m0 - 1 < 30) {
+        N_id_1 = (int)q->N_id_1_table[m1][m0 - 1];
+      }
+    }
+  }
+  return N_id_1;
+}
+
+static int sss_run(srsran_sss_t* q, const cf_t* input, int M, cf_t* ce, uint32_t* m0, float* m0_value, uint32_t* m1, float* m1_value)
+{
+  if (q == NULL || input == NULL || m0 == NULL || m1 == NULL || M > 3) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  SssCtx* c = sctx(q);
+  if (!c || !c->e) {
+    return SRSRAN_ERROR;
+  }
+  const uint32_t N = q->fft_size;
+  memcpy(c->h_in, input, N * sizeof(cf_t));
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, N * sizeof(cf_t), hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
+  if (ce) {
+    memcpy(c->h_in + N, ce, 62 * sizeof(cf_t));
+    PHY_HIP_CHECK(hipMemcpyAsync(c->d_ce + (size_t)q->N_id_2 * 62, c->h_in + N, 62 * sizeof(cf_t), hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
+  }
+  sync::SssParams p;
+  sss_params(&p, c->e, c->d_in, N, 1, N, SRSRAN_CP_NORM, M, 1 << q->N_id_2, -1.0f, c->d_pos, ce ? c->d_ce : nullptr);
+  PHY_HIP_CHECK(sync::launch_sss(p, nullptr, c->d_res, c->stream), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_res, c->d_res, 3 * sizeof(sync::SssResult), hipMemcpyDeviceToHost, c->stream), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(c->stream), SRSRAN_ERROR);
+  const sync::SssResult& r = c->h_res[q->N_id_2];
+  *m0 = r.m0;
+  *m1 = r.m1;
+  if (m0_value) {
+    *m0_value = r.m0_value;
+  }
+  if (m1_value) {
+    *m1_value = r.m1_value;
+  }
+  q->corr_output_m0[r.m0] = r.m0_value;
+  q->corr_output_m1[r.m1] = r.m1_value;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_sss_m0m1_partial(srsran_sss_t* q, const cf_t* input, uint32_t M, cf_t ce[2 * SRSRAN_SSS_N], uint32_t* m0,
+                                       float* m0_value, uint32_t* m1, float* m1_value)
+{
+  if (M == 0) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  return sss_run(q, input, (int)M, ce, m0, m0_value, m1, m1_value);
+}
+
+extern "C" int srsran_sss_m0m1_diff_coh(srsran_sss_t* q, const cf_t* input, cf_t ce[2 * SRSRAN_SSS_N], uint32_t* m0, float* m0_value,
+                                        uint32_t* m1, float* m1_value)
+{
+  return sss_run(q, input, 0, ce, m0, m0_value, m1, m1_value);
+}
+
+extern "C" int srsran_sss_m0m1_diff(srsran_sss_t* q, const cf_t* input, uint32_t* m0, float* m0_value, uint32_t* m1, float* m1_value)
+{
+  return srsran_sss_m0m1_diff_coh(q, input, NULL, m0, m0_value, m1, m1_value);
+}
+
+// ------------------------------------------------------------------------------------------------ batched cell search
+
+struct srsran_hip_cellsearch {
+  PssEngine*  pss = nullptr;
+  SssEngine*  sss = nullptr;
+  sync::SssResult* d_sss = nullptr;
+  srsran_cp_t cp = SRSRAN_CP_NORM;
+  int         M = 1;
+  uint32_t    max_caps = 0;
+};
+
+extern "C" int srsran_hip_cellsearch_create(srsran_hip_cellsearch_t** hh, uint32_t frame_size, uint32_t fft_size, srsran_cp_t cp,
+                                            int sss_alg, uint32_t max_captures)
+{
+  if (!hh || max_captures == 0 || !(sss_alg == 0 || sss_alg == 1 || sss_alg == 3)) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *hh     = nullptr;
+  auto* h = new srsran_hip_cellsearch;
+  h->pss  = pss_engine_new(frame_size, fft_size, 0, max_captures);
+  h->sss  = h->pss ? sss_engine_new(fft_size) : nullptr;
+  if (!h->pss || !h->sss || hipMalloc(&h->d_sss, (size_t)max_captures * 3 * sizeof(sync::SssResult)) != hipSuccess) {
+    srsran_hip_cellsearch_free(h);
+    return SRSRAN_ERROR;
+  }
+  h->cp       = cp;
+  h->M        = sss_alg;
+  h->max_caps = max_captures;
+  *hh         = h;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_hip_cellsearch_free(srsran_hip_cellsearch_t* h)
+{
+  if (!h) {
+    return;
+  }
+  pss_engine_free(h->pss);
+  sss_engine_free(h->sss);
+  (void)hipFree(h->d_sss);
+  delete h;
+}
+
+extern "C" int srsran_hip_cellsearch_run(srsran_hip_cellsearch_t* h, const cf_t* d_captures, uint32_t n_captures, int n_id_2_mask,
+                                         srsran_hip_cell_t* d_cells, void* stream)
+{
+  if (!h || !d_captures || !d_cells || n_captures == 0 || n_captures > h->max_caps || !(n_id_2_mask & 7)) {
+    set_error("cellsearch: invalid arguments");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  // ema_alpha = 1: stateless search (each capture on its own), as the batched use needs
+  if (pss_engine_run(h->pss, d_captures, n_captures, n_id_2_mask & 7, 0, 1.0f, st)) {
+    return SRSRAN_ERROR;
+  }
+  sync::SssParams p;
+  sss_params(&p, h->sss, d_captures, h->pss->frame_size, n_captures, h->pss->frame_size, h->cp, h->M, n_id_2_mask & 7, 0.0f, nullptr,
+             nullptr);
+  PHY_HIP_CHECK(sync::launch_sss(p, h->pss->d_res, h->d_sss, st), SRSRAN_ERROR);
+  static_assert(sizeof(sync::CellResult) == sizeof(srsran_hip_cell_t), "cell result layout");
+  PHY_HIP_CHECK(sync::launch_pack(h->pss->d_res, h->d_sss, reinterpret_cast<sync::CellResult*>(d_cells), (int)n_captures * 3, st), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" const float* srsran_hip_cellsearch_corr(srsran_hip_cellsearch_t* h, uint32_t capture, uint32_t N_id_2)
+{
+  if (!h || capture >= h->max_caps || N_id_2 > 2) {
+    return nullptr;
+  }
+  return h->pss->d_corr + ((size_t)capture * 3 + N_id_2) * h->pss->corr_stride;
+}

@@ -180,3 +180,45 @@ def ofdm_tx(cfg, x):
     for i in range(x.shape[0]):
         assert orc().orc_ofdm_tx_sf(C.byref(cfg), P(x[i]), P(out[i])) == 0
     return out
+
+
+# ------------------------------------------------------------------ sync helpers
+def pss_zc(N_id_2):
+    zc = np.zeros(62, np.complex64)
+    assert orc().orc_pss_generate(P(zc), N_id_2) == 0
+    return zc
+
+
+def sss_seq(cell_id):
+    s0, s5 = np.zeros(62, np.float32), np.zeros(62, np.float32)
+    assert orc().orc_sss_generate(P(s0), P(s5), cell_id) == 0
+    return s0, s5
+
+
+def sync_subframe(cell_id, nof_prb, symbol_sz, sf5=False):
+    """one subframe carrying PSS (last symbol of slot 0) and SSS (the one before), as sync_test.c:130-150 builds it"""
+    cfg = ofdm_cfg(nof_prb, symbol_sz, 0, 1)
+    grid = np.zeros((14, 12 * nof_prb), np.complex64)
+    k = 12 * nof_prb // 2 - 31
+    grid[6, k:k + 62] = pss_zc(cell_id % 3)
+    grid[5, k:k + 62] = sss_seq(cell_id)[1 if sf5 else 0]
+    return ofdm_tx(cfg, grid.reshape(1, -1))[0]
+
+
+def pss_find(frame, fft_size, N_id_2, want_corr=False):
+    orc().orc_pss_find.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    frame = np.ascontiguousarray(frame, np.complex64)
+    pv, psr = C.c_float(), C.c_float()
+    corr = np.zeros(frame.size + fft_size - 2, np.float32) if want_corr else None
+    pk = orc().orc_pss_find(P(frame), frame.size, fft_size, N_id_2, P(corr) if want_corr else None, C.byref(pv), C.byref(psr))
+    return (pk, pv.value, psr.value, corr) if want_corr else (pk, pv.value, psr.value)
+
+
+def sss_detect(symbol, fft_size, N_id_2, M):
+    orc().orc_sss_m0m1.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    symbol = np.ascontiguousarray(symbol, np.complex64)
+    m0, m1, v0, v1, nid, sf = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_float(), C.c_int(), C.c_int()
+    assert orc().orc_sss_m0m1(P(symbol), fft_size, N_id_2, M, C.byref(m0), C.byref(v0), C.byref(m1), C.byref(v1), C.byref(nid),
+                              C.byref(sf)) == 0
+    return m0.value, m1.value, v0.value, v1.value, nid.value, sf.value

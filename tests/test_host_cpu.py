@@ -46,8 +46,12 @@ def test_struct_layout_matches_ctypes_mirror(L):
     container, the reference headers: see test_struct_layout_matches_reference)"""
     from srslte_amd import capi
 
-    sizes = _c_sizes(["-I", os.path.join(ROOT, "include")], '#include "srsran_amd/phy_abi.h"')
+    sizes = _c_sizes(["-I", os.path.join(ROOT, "include")], OUR_INC)
     assert sizes["srsran_dft_plan_t"] == C.sizeof(capi.DftPlan)
+    assert sizes["srsran_pss_t"] == C.sizeof(capi.Pss)
+    assert sizes["srsran_sss_t"] == C.sizeof(capi.Sss)
+    assert sizes["srsran_dft_precoding_t"] == C.sizeof(capi.DftPrecoding)
+    assert sizes["off_pss_conv_output_avg"] == capi.Pss.conv_output_avg.offset
     assert sizes["srsran_ofdm_cfg_t"] == C.sizeof(capi.OfdmCfg)
     assert sizes["srsran_ofdm_t"] == C.sizeof(capi.Ofdm)
     assert sizes["srsran_tdec_t"] == C.sizeof(capi.Tdec)
@@ -58,7 +62,12 @@ def test_struct_layout_matches_ctypes_mirror(L):
 # sizeof/offsetof recorded from the reference headers (lib/include/srsran/phy/...) with gcc 11, x86-64
 REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_ofdm_t": 272, "srsran_tdec_t": 18264,
                     "srsran_ldpc_decoder_t": 88, "srsran_crc_t": 2088, "srsran_tc_interl_t": 24,
-                    "off_ofdm_tmp": 224, "off_tdec_interleaver": 208, "off_tdec_n_iter": 18256, "off_ldpc_decode_c": 80}
+                    "off_ofdm_tmp": 224, "off_tdec_interleaver": 208, "off_tdec_n_iter": 18256, "off_ldpc_decode_c": 80,
+                    "srsran_pss_t": 35248, "srsran_sss_t": 38888, "srsran_dft_precoding_t": 5336,
+                    "off_pss_conv_output_avg": 1864, "off_pss_tmp_ce": 34744, "off_sss_fc_tables": 3672}
+
+
+OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n'
 
 
 def _c_sizes(flags, include, extra=""):
@@ -73,6 +82,12 @@ int main(void) {
   printf("srsran_ldpc_decoder_t %zu\\n", sizeof(srsran_ldpc_decoder_t));
   printf("srsran_crc_t %zu\\n", sizeof(srsran_crc_t));
   printf("srsran_tc_interl_t %zu\\n", sizeof(srsran_tc_interl_t));
+  printf("srsran_pss_t %zu\\n", sizeof(srsran_pss_t));
+  printf("srsran_sss_t %zu\\n", sizeof(srsran_sss_t));
+  printf("srsran_dft_precoding_t %zu\\n", sizeof(srsran_dft_precoding_t));
+  printf("off_pss_conv_output_avg %zu\\n", offsetof(srsran_pss_t, conv_output_avg));
+  printf("off_pss_tmp_ce %zu\\n", offsetof(srsran_pss_t, tmp_ce));
+  printf("off_sss_fc_tables %zu\\n", offsetof(srsran_sss_t, fc_tables));
   printf("off_ofdm_tmp %zu\\n", offsetof(srsran_ofdm_t, tmp));
   printf("off_tdec_interleaver %zu\\n", offsetof(srsran_tdec_t, interleaver));
   printf("off_tdec_n_iter %zu\\n", offsetof(srsran_tdec_t, n_iter));
@@ -88,14 +103,15 @@ int main(void) {
 
 
 def test_struct_layout_matches_recorded_reference(L):
-    ours = _c_sizes(["-I", os.path.join(ROOT, "include")], '#include "srsran_amd/phy_abi.h"')
+    ours = _c_sizes(["-I", os.path.join(ROOT, "include")], OUR_INC)
     assert ours == REFERENCE_LAYOUT
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/lib/include"), reason="reference headers only exist in the dev container")
 def test_struct_layout_matches_reference():
     inc = ('#include <complex.h>\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
-           '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n')
+           '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n#include "srsran/phy/sync/pss.h"\n'
+           '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n')
     theirs = _c_sizes(["-I", "/root/reference/lib/include"], inc)
     assert theirs == REFERENCE_LAYOUT
 

@@ -37,7 +37,7 @@ def _run_batch(S, caps, frame, N, alg):
 
 
 @pytest.mark.parametrize("prb,N,frame,alg", [(6, 128, 9600, 1), (6, 128, 9600, 0), (6, 128, 9600, 3), (25, 384, 28800, 1),
-                                               (100, 2048, 30720, 1)])
+                                               (100, 2048, 61440, 1)])
 def test_cellsearch_vs_oracle(hiplib, prb, N, frame, alg):
     import srslte_amd as S
 
@@ -83,7 +83,7 @@ def test_full_capture_config5(hiplib):
     frame, N, prb = 307200, 2048, 100
     ids = [123, 124, 125, 360]
     delays = [123457, 1000, 250000, 77777]
-    caps = np.stack([_capture(c, prb, N, frame, d, 0.3, rng) for c, d in zip(ids, delays)])
+    caps = np.stack([_capture(c, prb, N, frame, d, 0.05, rng) for c, d in zip(ids, delays)])
     caps = np.concatenate([caps, caps[:1]])
     h, got = _run_batch(S, caps, frame, N, 1)
     for i, (cid, d) in enumerate(zip(ids, delays)):

@@ -97,11 +97,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the PHY engine has no CPU fallback")
+    # rehearsal switch for a 1-GPU box: all ranks share GPU 0 and the (tiny) collectives run over gloo
+    share_gpu = os.environ.get("SRSLTE_AMD_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if share_gpu else dev  # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import srslte_amd as S
     from srslte_amd import capi
@@ -110,7 +118,7 @@ def main():
     S.capi.check(S.lib().srsran_hip_set_device(local), "set_device")
 
     # ---- the only collective of the job: rank 0 broadcasts the cell / decoder configuration
-    cfg = torch.tensor([N_PRB, N_FFT, K_CB, NIT, CB_PER_SF, a.sf], dtype=torch.int32, device=dev)
+    cfg = torch.tensor([N_PRB, N_FFT, K_CB, NIT, CB_PER_SF, a.sf], dtype=torch.int32, device=cdev)
     if world > 1:
         dist.broadcast(cfg, src=0)
     n_prb, n_fft, k_cb, nit, cb_per_sf, n_sf = [int(v) for v in cfg.tolist()]
@@ -164,7 +172,7 @@ def main():
     dt = time.perf_counter() - t0
     t_ofdm = sum(e[0].elapsed_time(e[1]) for e in evs) / a.steps * 1e-3
     t_tdec = sum(e[1].elapsed_time(e[2]) for e in evs) / a.steps * 1e-3
-    tt = torch.tensor([dt, t_ofdm, t_tdec], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, t_ofdm, t_tdec], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, t_ofdm, t_tdec = [float(v) for v in tt.tolist()]

@@ -269,36 +269,40 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102)
   if (p.n_begin == 0) {
     const short* in = p.input + (size_t)cb * p.in_stride;
+    // All 48 element loads of an 8-step block are issued before the first use (addresses clamped instead of
+    // branching on the ragged last block), so the block costs one memory round trip, not eight.
     for (uint32_t b = 0; b < nblk; b++) {
+      const int nv = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8; // valid steps in this block
+      short     r[2][24];
+      if (p.sb_layout) {
+        // rm_turbo layout: element (step k, sub-block d) of array a at in[a*(K+32) + k*NB + d]
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t k = b * 8 + (j < nv ? j : nv - 1);
+#pragma unroll
+          for (int a3 = 0; a3 < 3; a3++) {
+            r[0][3 * j + a3] = in[a3 * (K + 32) + k * NB + 2 * pl];
+            r[1][3 * j + a3] = in[a3 * (K + 32) + k * NB + 2 * pl + 1];
+          }
+        }
+      } else {
+        // natural order: the 8 steps of one sub-block are 24 consecutive int16 [s p0 p1]...
+        const short* c0 = in + 3 * ((size_t)(2 * pl) * long_sb + b * 8);
+        const short* c1 = in + 3 * ((size_t)(2 * pl + 1) * long_sb + b * 8);
+        const int    lim = 3 * nv - 1;
+#pragma unroll
+        for (int t = 0; t < 24; t++) {
+          const int tt = t < lim ? t : lim;
+          r[0][t]      = c0[tt];
+          r[1][t]      = c1[tt];
+        }
+      }
       uint32_t s[8], y0[8], y1[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        uint32_t k = b * 8 + j;
-        uint32_t vs = 0, v0 = 0, v1 = 0;
-        if (k < long_sb) {
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            uint32_t d = 2 * pl + h;
-            short    a, bq, c;
-            if (p.sb_layout) {
-              uint32_t i = k * NB + d;
-              a  = in[i];
-              bq = in[K + 32 + i];
-              c  = in[2 * (K + 32) + i];
-            } else {
-              uint32_t n = d * long_sb + k;
-              a  = in[3 * n];
-              bq = in[3 * n + 1];
-              c  = in[3 * n + 2];
-            }
-            vs |= (uint32_t)(uint16_t)a << (16 * h);
-            v0 |= (uint32_t)(uint16_t)bq << (16 * h);
-            v1 |= (uint32_t)(uint16_t)c << (16 * h);
-          }
-        }
-        s[j]  = vs;
-        y0[j] = v0;
-        y1[j] = v1;
+        s[j]  = (uint32_t)(uint16_t)r[0][3 * j] | ((uint32_t)(uint16_t)r[1][3 * j] << 16);
+        y0[j] = (uint32_t)(uint16_t)r[0][3 * j + 1] | ((uint32_t)(uint16_t)r[1][3 * j + 1] << 16);
+        y1[j] = (uint32_t)(uint16_t)r[0][3 * j + 2] | ((uint32_t)(uint16_t)r[1][3 * j + 2] << 16);
       }
       store_block(S, b * 64 + lane, s);
       store_block(P0, b * 64 + lane, y0);
@@ -563,7 +567,9 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
     short*     o16  = p.dec_llr ? p.dec_llr + (size_t)cb * K : nullptr;
     if ((long_sb & 7) == 0) {
-      const uint32_t bps = long_sb >> 3; // bytes per sub-block
+      const uint32_t bps   = long_sb >> 3; // bytes per sub-block
+      const bool     wide  = ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0); // dword stores possible
+      uint32_t       w0 = 0, w1 = 0;
       for (uint32_t b = 0; b < nblk; b++) {
         uint32_t r[8], r2[8];
         load_rows(E1, b, lane, r);
@@ -584,8 +590,18 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
             o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
           }
         }
-        out[(2 * pl) * bps + b]     = (uint8_t)b0;
-        out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
+        if (wide) {
+          w0 |= b0 << (8 * (b & 3));
+          w1 |= b1 << (8 * (b & 3));
+          if ((b & 3) == 3) {
+            *reinterpret_cast<uint32_t*>(out + (2 * pl) * bps + (b & ~3u))     = w0;
+            *reinterpret_cast<uint32_t*>(out + (2 * pl + 1) * bps + (b & ~3u)) = w1;
+            w0 = w1 = 0;
+          }
+        } else {
+          out[(2 * pl) * bps + b]     = (uint8_t)b0;
+          out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
+        }
       }
     } else {
       const short* se = reinterpret_cast<const short*>(E1);

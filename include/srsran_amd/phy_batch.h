@@ -32,9 +32,12 @@ SRSRAN_API const char* srsran_hip_build_info(void);
 /* ---- turbo decoder: srsran_tdec_run_all (turbodecoder.c:536-549) over n_cb code blocks ---- */
 typedef struct srsran_hip_tdec_batch srsran_hip_tdec_batch_t;
 
-/* impl: SRSRAN_TDEC_AUTO / _GENERIC / _SSE_WINDOW / _AVX_WINDOW select which reference decoder is
- * reproduced bit-exactly (AUTO = the reference's choice on an AVX2 host, turbodecoder.c:381-408). */
+/* impl: SRSRAN_TDEC_AUTO / _GENERIC / _SSE_WINDOW / _AVX_WINDOW / _SSE8_WINDOW / _AVX8_WINDOW select which
+ * reference decoder is reproduced bit-exactly (AUTO = the reference's choice on an AVX2 host for the 16-bit
+ * API, turbodecoder.c:381-408).  create_8bit: AUTO resolves as srsran_tdec_run_all_8bit does (32 sub-blocks
+ * K%32==0 && K>2048, 16 sub-blocks K%16==0 && K>800, else the 16-bit decoders on widened LLRs, :410-478). */
 SRSRAN_API int  srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** h, uint32_t long_cb, uint32_t max_nof_cb, int impl);
+SRSRAN_API int  srsran_hip_tdec_batch_create_8bit(srsran_hip_tdec_batch_t** h, uint32_t long_cb, uint32_t max_nof_cb, int impl);
 SRSRAN_API void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h);
 /* d_input : n_cb blocks of int16 LLRs, `in_stride` int16 apart.  sb_layout = 0: natural order
  *           [s p0 p1]xK + 12 tail (3K+12);  sb_layout = 1: srsran_rm_turbo_rx_lut sub-block layout
@@ -43,6 +46,12 @@ SRSRAN_API void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h);
 SRSRAN_API int  srsran_hip_tdec_batch_run(srsran_hip_tdec_batch_t* h, const int16_t* d_input, uint32_t in_stride,
                                           uint8_t* d_output, uint32_t out_stride, uint32_t n_cb,
                                           uint32_t nof_iterations, int sb_layout, void* stream);
+/* same with int8 LLRs (srsran_tdec_run_all_8bit, turbodecoder.c:560-577); in_stride in int8 elements.  Either
+ * entry point works on either kind of batch object: the LLRs are converted as the reference does
+ * (convert_8_to_16 / convert_16_to_8, turbodecoder.c:443-453). */
+SRSRAN_API int  srsran_hip_tdec_batch_run_8bit(srsran_hip_tdec_batch_t* h, const int8_t* d_input, uint32_t in_stride,
+                                               uint8_t* d_output, uint32_t out_stride, uint32_t n_cb,
+                                               uint32_t nof_iterations, int sb_layout, void* stream);
 /* debug/parity aid: copy the SISO output of the last half iteration (K int16 per CB, natural order) */
 SRSRAN_API int  srsran_hip_tdec_batch_last_llr(srsran_hip_tdec_batch_t* h, int16_t* d_llr, uint32_t n_cb, void* stream);
 

@@ -37,7 +37,14 @@ uint32_t orc_tdec_autoimp_subblocks(uint32_t long_cb);
 uint32_t orc_tdec_autoimp_subblocks_8bit(uint32_t long_cb);
 
 /* implementation selector, values follow srsran_tdec_impl_type_t (turbodecoder_impl.h:28-38) */
-enum { ORC_TDEC_AUTO = 0, ORC_TDEC_GENERIC = 1, ORC_TDEC_SSE_WINDOW = 3, ORC_TDEC_AVX_WINDOW = 5 };
+enum {
+  ORC_TDEC_AUTO = 0,
+  ORC_TDEC_GENERIC = 1,
+  ORC_TDEC_SSE_WINDOW = 3,
+  ORC_TDEC_AVX_WINDOW = 5,
+  ORC_TDEC_SSE8_WINDOW = 6,
+  ORC_TDEC_AVX8_WINDOW = 7
+};
 
 /* srsran_tdec_run_all (turbodecoder.c:536-549) for 16-bit LLRs.
  *   input    : natural order [s0 p0 p0' s1 ...][12 tail]  (3K+12)  when sb_layout == 0
@@ -49,6 +56,12 @@ enum { ORC_TDEC_AUTO = 0, ORC_TDEC_GENERIC = 1, ORC_TDEC_SSE_WINDOW = 3, ORC_TDE
  * returns 0, or -1 on invalid arguments */
 int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb,
                      int impl, int sb_layout, int16_t* snap, int16_t* dec_llr);
+
+/* srsran_tdec_run_all_8bit (turbodecoder.c:560-577) for int8 LLRs: AUTO (32 sub-blocks K%32==0 && K>2048,
+ * 16 sub-blocks K%16==0 && K>800, else widened to the 16-bit decoders, turbodecoder.c:410-478),
+ * ORC_TDEC_SSE8_WINDOW (16) or ORC_TDEC_AVX8_WINDOW (32).  dec_llr: optional K decision LLRs (int16 holder). */
+int orc_tdec_run_all_8bit(const int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb,
+                          int impl, int sb_layout, int16_t* dec_llr);
 
 /* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
 int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);

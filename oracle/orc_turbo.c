@@ -426,7 +426,7 @@ int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterati
     default:
       return -1;
   }
-  if (nb && (K % nb || K / nb < WIN_OVERLAP)) {
+  if (nb && (K % nb || K / nb <= WIN_OVERLAP)) {
     return -1; /* the reference reads out of bounds here; refuse */
   }
   if (sb_layout && !nb) {

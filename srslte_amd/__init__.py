@@ -62,24 +62,31 @@ class DeviceBuffer:
 class TdecBatch:
     """srsran_tdec_run_all over a batch of code blocks (srsran_hip_tdec_batch_*, phy_batch.h)."""
 
-    def __init__(self, long_cb, max_nof_cb, impl=capi.TDEC_AUTO):
-        self.K, self.max_cb = int(long_cb), int(max_nof_cb)
+    def __init__(self, long_cb, max_nof_cb, impl=capi.TDEC_AUTO, llr8=False):
+        """llr8: resolve AUTO as the 8-bit API does (srsran_tdec_run_all_8bit); decode() then takes int8 LLRs"""
+        self.K, self.max_cb, self.llr8 = int(long_cb), int(max_nof_cb), bool(llr8)
         self._h = C.c_void_p()
-        capi.check(lib().srsran_hip_tdec_batch_create(C.byref(self._h), self.K, self.max_cb, impl), "tdec_batch_create")
+        create = lib().srsran_hip_tdec_batch_create_8bit if llr8 else lib().srsran_hip_tdec_batch_create
+        capi.check(create(C.byref(self._h), self.K, self.max_cb, impl), "tdec_batch_create")
 
     def run(self, d_input, in_stride, d_output, out_stride, n_cb, nof_iterations, sb_layout=0, stream=None):
         capi.check(lib().srsran_hip_tdec_batch_run(self._h, _ptr(d_input), in_stride, _ptr(d_output), out_stride, n_cb,
                                                    nof_iterations, sb_layout, stream), "tdec_batch_run")
 
     def decode(self, llr, nof_iterations, sb_layout=0, want_llr=False, n_begin=0):
-        """host convenience: llr int16 [n_cb, L] -> packed bytes [n_cb, K/8] (and decision LLRs)"""
-        llr = np.ascontiguousarray(llr, dtype=np.int16)
+        """host convenience: llr int16 (or int8) [n_cb, L] -> packed bytes [n_cb, K/8] (and decision LLRs)"""
+        in8 = np.asarray(llr).dtype == np.int8
+        llr = np.ascontiguousarray(llr, dtype=np.int8 if in8 else np.int16)
         n_cb, L = llr.shape
         d_in = DeviceBuffer.from_numpy(llr)
         d_out = DeviceBuffer(n_cb * (self.K // 8))
         if want_llr:
-            capi.check(lib().srsran_hip_tdec_batch_run_dbg(self._h, d_in.ptr, L, d_out.ptr, self.K // 8, n_cb, n_begin,
-                                                           max(1, nof_iterations), sb_layout, None), "tdec_batch_run_dbg")
+            dbg = lib().srsran_hip_tdec_batch_run_dbg_8bit if in8 else lib().srsran_hip_tdec_batch_run_dbg
+            capi.check(dbg(self._h, d_in.ptr, L, d_out.ptr, self.K // 8, n_cb, n_begin, max(1, nof_iterations), sb_layout, None),
+                       "tdec_batch_run_dbg")
+        elif in8:
+            capi.check(lib().srsran_hip_tdec_batch_run_8bit(self._h, d_in.ptr, L, d_out.ptr, self.K // 8, n_cb, nof_iterations,
+                                                            sb_layout, None), "tdec_batch_run_8bit")
         else:
             self.run(d_in, L, d_out, self.K // 8, n_cb, nof_iterations, sb_layout)
         capi.check(lib().srsran_hip_stream_sync(None), "sync")

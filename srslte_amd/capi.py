@@ -143,7 +143,10 @@ def lib():
             "srsran_hip_last_error": (C.c_char_p, []),
             "srsran_hip_build_info": (C.c_char_p, []),
             "srsran_hip_tdec_batch_create": (i32, [C.POINTER(vp), u32, u32, i32]),
+            "srsran_hip_tdec_batch_create_8bit": (i32, [C.POINTER(vp), u32, u32, i32]),
             "srsran_hip_tdec_batch_free": (None, [vp]),
+            "srsran_hip_tdec_batch_run_8bit": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, vp]),
+            "srsran_hip_tdec_batch_run_dbg_8bit": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, i32, vp]),
             "srsran_hip_tdec_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, i32, vp]),
             "srsran_hip_tdec_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, i32, vp]),
             "srsran_hip_tdec_batch_last_llr": (i32, [vp, vp, u32, vp]),
@@ -166,6 +169,8 @@ def lib():
             "srsran_tdec_autoimp_get_subblocks_8bit": (u32, [u32]),
             "srsran_tdec_iteration": (None, [C.POINTER(Tdec), vp, vp]),
             "srsran_tdec_run_all": (i32, [C.POINTER(Tdec), vp, vp, u32, u32]),
+            "srsran_tdec_iteration_8bit": (None, [C.POINTER(Tdec), vp, vp]),
+            "srsran_tdec_run_all_8bit": (i32, [C.POINTER(Tdec), vp, vp, u32, u32]),
             "srsran_tc_interl_init": (i32, [C.POINTER(TcInterl), u32]),
             "srsran_tc_interl_free": (None, [C.POINTER(TcInterl)]),
             "srsran_tc_interl_LTE_gen": (i32, [C.POINTER(TcInterl), u32]),

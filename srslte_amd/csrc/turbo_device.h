@@ -7,7 +7,7 @@ namespace phyhip {
 namespace turbo {
 
 struct WinParams {
-  const short*    input;   // n_cb code blocks, in_stride int16 apart
+  const short*    input;   // n_cb code blocks, in_stride elements apart (int8 elements when in_is8)
   uint8_t*        output;  // n_cb x K/8 bytes, out_stride apart
   short*          dec_llr; // optional: n_cb x K decision LLRs, natural order
   uint32_t*       ws;      // per-code-block workspace, ws_stride dwords apart
@@ -21,6 +21,7 @@ struct WinParams {
   uint32_t        n_end;   // one past the last half iteration; the hard decision is taken for n_iter = n_end
   int             n_cb;
   int             sb_layout;
+  int             in_is8;
 };
 
 struct GenParams {
@@ -37,6 +38,7 @@ struct GenParams {
   uint32_t        n_begin;
   uint32_t        n_end;
   int             n_cb;
+  int             in_is8;
 };
 
 // dwords of workspace per code block for the window decoder with nb sub-blocks
@@ -51,7 +53,7 @@ static inline size_t gen_ws_shorts(uint32_t K)
   return (size_t)15 * (K + 4) * 64;
 }
 
-hipError_t launch_win(int nb, const WinParams& p, hipStream_t stream);
+hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream);
 hipError_t launch_gen(const GenParams& p, hipStream_t stream);
 uint32_t   win_elem_index(int nb, uint32_t k, uint32_t d);
 

@@ -133,7 +133,8 @@ extern "C" uint32_t srsran_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb)
 struct srsran_hip_tdec_batch {
   uint32_t K       = 0;
   uint32_t max_cb  = 0;
-  int      nb      = 0; // 16, 8 (window decoders) or 0 (scalar decoder)
+  int      nb      = 0; // 32, 16, 8 (window decoders) or 0 (scalar decoder)
+  bool     arith8  = false; // 8-bit window decoder arithmetic (sse8: 16 sub-blocks, avx8: 32)
   // window decoder
   uint32_t* d_ws     = nullptr;
   uint32_t  ws_stride = 0;
@@ -147,11 +148,20 @@ struct srsran_hip_tdec_batch {
   short* d_dec_llr = nullptr;
 };
 
-static int impl_to_nb(int impl, uint32_t K, int* nb)
+// which decoder the reference runs: sub-block count and arithmetic (turbodecoder.c:381-441,455-512)
+static int impl_to_cfg(int impl, bool llr8_api, uint32_t K, int* nb, bool* arith8)
 {
+  *arith8 = false;
   switch (impl) {
     case SRSRAN_TDEC_AUTO:
-      *nb = (int)srsran_tdec_autoimp_get_subblocks(K);
+      if (llr8_api) {
+        *nb = (int)srsran_tdec_autoimp_get_subblocks_8bit(K);
+        if (*nb >= 16) {
+          *arith8 = true; // else: no 8-bit decoder takes this K, the LLRs are widened for sse16 / gen
+        }
+      } else {
+        *nb = (int)srsran_tdec_autoimp_get_subblocks(K);
+      }
       return 0;
     case SRSRAN_TDEC_GENERIC:
       *nb = 0;
@@ -162,12 +172,32 @@ static int impl_to_nb(int impl, uint32_t K, int* nb)
     case SRSRAN_TDEC_AVX_WINDOW:
       *nb = 16;
       return 0;
+    case SRSRAN_TDEC_SSE8_WINDOW:
+      *nb     = 16;
+      *arith8 = true;
+      return 0;
+    case SRSRAN_TDEC_AVX8_WINDOW:
+      *nb     = 32;
+      *arith8 = true;
+      return 0;
     default:
       return -1;
   }
 }
 
+static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api);
+
 extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl)
+{
+  return tdec_batch_create(hh, long_cb, max_nof_cb, impl, false);
+}
+
+extern "C" int srsran_hip_tdec_batch_create_8bit(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl)
+{
+  return tdec_batch_create(hh, long_cb, max_nof_cb, impl, true);
+}
+
+static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api)
 {
   if (!hh || max_nof_cb == 0) {
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -181,13 +211,16 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
     set_error("invalid turbo code block size %u", long_cb);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  int nb = 0;
-  if (impl_to_nb(impl, long_cb, &nb)) {
+  int  nb     = 0;
+  bool arith8 = false;
+  if (impl_to_cfg(impl, llr8_api, long_cb, &nb, &arith8)) {
     set_error("turbo decoder implementation %d not supported by the HIP engine", impl);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  if (nb && (long_cb % nb || long_cb / nb < 40)) {
-    // the reference's window decoders read out of bounds in this case (40-step warm-up > sub-block)
+  if (nb && (long_cb % nb || long_cb / nb <= 40)) {
+    // the reference's window decoders read out of bounds in this case (40-step warm-up > sub-block); with
+    // exactly 40 steps per sub-block its warm-up pass degenerates (turbodecoder_win.h:573,712).  AUTO never
+    // selects either.
     set_error("window decoder with %d sub-blocks is invalid for K=%u", nb, long_cb);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -195,6 +228,7 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
   h->K      = long_cb;
   h->max_cb = max_nof_cb;
   h->nb     = nb;
+  h->arith8 = arith8;
   std::vector<uint16_t> f, r;
   qpp_natural(long_cb, f, r);
   const uint32_t K = long_cb;
@@ -203,15 +237,15 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
     h->ws_stride = turbo::win_ws_dwords(K, nb);
     // Exchange tables, one dword per (step k, destination lane p'), stored blocked [k/8][p'][k%8]:
     //   bits 0..15  destination row o = PI'(k) mod W  (common to all sub-blocks: QPP is contention free)
-    //   bits 16..19 source sub-block whose output lands in destination sub-block 2p'
-    //   bits 20..23 source sub-block whose output lands in destination sub-block 2p'+1
+    //   bits 16..20 source sub-block whose output lands in destination sub-block 2p'
+    //   bits 21..25 source sub-block whose output lands in destination sub-block 2p'+1
     // deint: app2[reverse[n]] = ext1[n]   inter: app1[forward[n]] = ext2[n]   (turbodecoder_iter.h:118,124)
     std::vector<uint32_t> deint(nblk * lpc * 8, 0), inter(nblk * lpc * 8, 0);
     for (int dir = 0; dir < 2; dir++) {
       const std::vector<uint16_t>& tab = dir == 0 ? r : f;
       std::vector<uint32_t>&       out = dir == 0 ? deint : inter;
       for (uint32_t k = 0; k < long_sb; k++) {
-        uint32_t src_of[16];
+        uint32_t src_of[32];
         uint32_t row = tab[k] % long_sb;
         for (uint32_t j = 0; j < (uint32_t)nb; j++) {
           uint32_t t = tab[j * long_sb + k];
@@ -223,7 +257,7 @@ extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32
           src_of[t / long_sb] = j;
         }
         for (uint32_t pp = 0; pp < lpc; pp++) {
-          out[((k >> 3) * lpc + pp) * 8 + (k & 7)] = row | (src_of[2 * pp] << 16) | (src_of[2 * pp + 1] << 20);
+          out[((k >> 3) * lpc + pp) * 8 + (k & 7)] = row | (src_of[2 * pp] << 16) | (src_of[2 * pp + 1] << 21);
         }
       }
     }
@@ -263,10 +297,11 @@ extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
 }
 
 // run half iterations [n_begin, n_end) and take the hard decision for n_iter = n_end
-static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const int16_t* d_input, uint32_t in_stride, uint8_t* d_output,
-                                uint32_t out_stride, uint32_t n_cb, uint32_t n_begin, uint32_t n_end, int sb_layout,
-                                bool want_llr, hipStream_t stream)
+static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_v, bool in_is8, uint32_t in_stride,
+                                uint8_t* d_output, uint32_t out_stride, uint32_t n_cb, uint32_t n_begin, uint32_t n_end,
+                                int sb_layout, bool want_llr, hipStream_t stream)
 {
+  const int16_t* d_input = static_cast<const int16_t*>(d_input_v);
   if (!h || !d_output || (!d_input && n_begin == 0) || n_cb == 0 || n_cb > h->max_cb || n_end <= n_begin) {
     set_error("tdec batch: invalid arguments (n_cb=%u max=%u)", n_cb, h ? h->max_cb : 0);
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -299,7 +334,8 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const int16_t* d_inp
     p.n_end      = n_end;
     p.n_cb       = (int)n_cb;
     p.sb_layout  = sb_layout;
-    PHY_HIP_CHECK(turbo::launch_win(h->nb, p, stream), SRSRAN_ERROR);
+    p.in_is8     = in_is8 ? 1 : 0;
+    PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   } else {
     turbo::GenParams p;
     p.input      = d_input;
@@ -315,6 +351,7 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const int16_t* d_inp
     p.n_begin    = n_begin;
     p.n_end      = n_end;
     p.n_cb       = (int)n_cb;
+    p.in_is8     = in_is8 ? 1 : 0;
     PHY_HIP_CHECK(turbo::launch_gen(p, stream), SRSRAN_ERROR);
   }
   return SRSRAN_SUCCESS;
@@ -326,7 +363,15 @@ extern "C" int srsran_hip_tdec_batch_run(srsran_hip_tdec_batch_t* h, const int16
 {
   // turbodecoder.c:542-544 is a do/while: at least one half iteration runs
   uint32_t nit = nof_iterations ? nof_iterations : 1;
-  return tdec_batch_run_range(h, d_input, in_stride, d_output, out_stride, n_cb, 0, nit, sb_layout, false, (hipStream_t)stream);
+  return tdec_batch_run_range(h, d_input, false, in_stride, d_output, out_stride, n_cb, 0, nit, sb_layout, false, (hipStream_t)stream);
+}
+
+extern "C" int srsran_hip_tdec_batch_run_8bit(srsran_hip_tdec_batch_t* h, const int8_t* d_input, uint32_t in_stride,
+                                              uint8_t* d_output, uint32_t out_stride, uint32_t n_cb,
+                                              uint32_t nof_iterations, int sb_layout, void* stream)
+{
+  uint32_t nit = nof_iterations ? nof_iterations : 1;
+  return tdec_batch_run_range(h, d_input, true, in_stride, d_output, out_stride, n_cb, 0, nit, sb_layout, false, (hipStream_t)stream);
 }
 
 extern "C" int srsran_hip_tdec_batch_last_llr(srsran_hip_tdec_batch_t* h, int16_t* d_llr, uint32_t n_cb, void* stream)
@@ -347,7 +392,17 @@ extern "C" SRSRAN_API int srsran_hip_tdec_batch_run_dbg(srsran_hip_tdec_batch_t*
                                                         uint32_t n_cb, uint32_t n_begin, uint32_t n_end, int sb_layout,
                                                         void* stream)
 {
-  return tdec_batch_run_range(h, d_input, in_stride, d_output, out_stride, n_cb, n_begin, n_end, sb_layout, true, (hipStream_t)stream);
+  return tdec_batch_run_range(h, d_input, false, in_stride, d_output, out_stride, n_cb, n_begin, n_end, sb_layout, true,
+                              (hipStream_t)stream);
+}
+
+extern "C" SRSRAN_API int srsran_hip_tdec_batch_run_dbg_8bit(srsran_hip_tdec_batch_t* h, const int8_t* d_input,
+                                                             uint32_t in_stride, uint8_t* d_output, uint32_t out_stride,
+                                                             uint32_t n_cb, uint32_t n_begin, uint32_t n_end, int sb_layout,
+                                                             void* stream)
+{
+  return tdec_batch_run_range(h, d_input, true, in_stride, d_output, out_stride, n_cb, n_begin, n_end, sb_layout, true,
+                              (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ handle ABI
@@ -378,31 +433,37 @@ extern "C" int srsran_tdec_init(srsran_tdec_t* h, uint32_t max_long_cb)
 extern "C" int srsran_tdec_init_manual(srsran_tdec_t* h, uint32_t max_long_cb, srsran_tdec_impl_type_t dec_type)
 {
   memset(h, 0, sizeof(srsran_tdec_t)); // turbodecoder.c:150
+  h->current_llr_type = SRSRAN_TDEC_16;
   switch (dec_type) {
     case SRSRAN_TDEC_AUTO:
     case SRSRAN_TDEC_GENERIC:
     case SRSRAN_TDEC_SSE_WINDOW:
     case SRSRAN_TDEC_AVX_WINDOW:
       break;
+    case SRSRAN_TDEC_SSE8_WINDOW:
+    case SRSRAN_TDEC_AVX8_WINDOW:
+      h->current_llr_type = SRSRAN_TDEC_8; // turbodecoder.c:170-172,190-192
+      break;
     default:
-      // SSE (non-window), NEON and the 8-bit decoders are not reproduced by the HIP engine (yet)
+      // the non-window SSE decoder and the NEON one are not reproduced by the HIP engine
       fprintf(stderr, "Error decoder %d not supported\n", dec_type);
       return SRSRAN_ERROR;
   }
   if (!device_available()) {
     return SRSRAN_ERROR;
   }
-  h->dec_type         = dec_type;
-  h->max_long_cb      = max_long_cb;
-  h->current_llr_type = SRSRAN_TDEC_16;
-  h->current_cbidx    = -1;
+  h->dec_type      = dec_type;
+  h->max_long_cb   = max_long_cb;
+  h->current_cbidx = -1;
   if (dec_type == SRSRAN_TDEC_AUTO) {
-    // what the reference's tdec_init() of gen / sse16win / avx16win return (turbodecoder.c:252-258)
+    // what the reference's tdec_init() of gen / sse16win / avx16win / sse8win / avx8win return (turbodecoder.c:252-270)
     h->nof_blocks16[0] = 1;
     h->nof_blocks16[1] = 8;
     h->nof_blocks16[2] = 16;
     h->nof_blocks8[0]  = 16;
     h->nof_blocks8[1]  = 32;
+  } else if (dec_type == SRSRAN_TDEC_SSE8_WINDOW || dec_type == SRSRAN_TDEC_AVX8_WINDOW) {
+    h->nof_blocks8[0] = dec_type == SRSRAN_TDEC_SSE8_WINDOW ? 16 : 32;
   } else {
     h->nof_blocks16[0] = dec_type == SRSRAN_TDEC_GENERIC ? 1 : (dec_type == SRSRAN_TDEC_SSE_WINDOW ? 8 : 16);
   }
@@ -462,10 +523,13 @@ extern "C" int srsran_tdec_get_nof_iterations(srsran_tdec_t* h)
   return h->n_iter;
 }
 
-// one half iteration on the device + hard decision into `output` (turbodecoder.c:495-533)
-static void tdec_handle_iterate(srsran_tdec_t* h, int16_t* input, uint8_t* output, uint32_t n_end)
+// half iterations [n_iter, n_end) on the device + hard decision into `output` (turbodecoder.c:455-533).
+// ELEM is the caller's LLR type: int16_t (srsran_tdec_iteration / run_all) or int8_t (the *_8bit entry points).
+template <typename ELEM>
+static void tdec_handle_iterate(srsran_tdec_t* h, ELEM* input, uint8_t* output, uint32_t n_end)
 {
-  TdecCtx* c = ctx_of(h);
+  constexpr bool in8 = sizeof(ELEM) == 1;
+  TdecCtx*       c   = ctx_of(h);
   if (!c) {
     fprintf(stderr, "[srsran_phy_hip] srsran_tdec: handle not initialised\n");
     return;
@@ -475,18 +539,27 @@ static void tdec_handle_iterate(srsran_tdec_t* h, int16_t* input, uint8_t* outpu
     fprintf(stderr, "[srsran_phy_hip] srsran_tdec: K=%u is not a valid turbo block size\n", K);
     return;
   }
-  int nb = 0;
-  impl_to_nb(h->dec_type, K, &nb);
-  // input layout, turbodecoder_iter.h:88 : AUTO + window decoder + !force_not_sb -> rm_turbo sub-block layout
-  const int sb_layout = (h->dec_type == SRSRAN_TDEC_AUTO && nb > 0 && !h->force_not_sb) ? 1 : 0;
-  h->current_dec       = h->dec_type == SRSRAN_TDEC_AUTO ? (nb == 16 ? 2 : (nb == 8 ? 1 : 0)) : 0;
-  h->current_inter_idx = nb == 16 ? 2 : (nb == 8 ? 1 : 0);
+  int  nb     = 0;
+  bool arith8 = false;
+  impl_to_cfg(h->dec_type, in8, K, &nb, &arith8);
+  // Input layout (turbodecoder_iter.h:88): the 8-bit decoders always expect the rm_turbo sub-block layout, the
+  // 16-bit ones only in AUTO mode with a window decoder; srsran_tdec_force_not_sb() turns it off.
+  const bool auto_mode = h->dec_type == SRSRAN_TDEC_AUTO;
+  const int  sb_layout = (!h->force_not_sb && (arith8 || (auto_mode && nb > 0))) ? 1 : 0;
+  if (auto_mode) {
+    h->current_llr_type = arith8 ? SRSRAN_TDEC_8 : SRSRAN_TDEC_16;
+    h->current_dec      = arith8 ? (nb == 32 ? 1 : 0) : (nb == 16 ? 2 : (nb == 8 ? 1 : 0));
+  } else {
+    h->current_dec = 0;
+  }
+  h->current_inter_idx = nb == 32 ? 3 : (nb == 16 ? 2 : (nb == 8 ? 1 : 0)); // interleaver_idx(), turbodecoder.c:134-148
 
-  uint64_t key = ((uint64_t)K << 8) | (uint64_t)nb;
+  uint64_t key = ((uint64_t)K << 8) | ((uint64_t)nb << 1) | (arith8 ? 1u : 0u);
   auto     it  = c->dec.find(key);
   if (it == c->dec.end()) {
     srsran_hip_tdec_batch_t* b = nullptr;
-    int impl = nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC);
+    int impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)
+                      : (nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC));
     if (srsran_hip_tdec_batch_create(&b, K, 1, impl)) {
       fprintf(stderr, "[srsran_phy_hip] srsran_tdec: %s\n", get_error());
       return;
@@ -496,17 +569,21 @@ static void tdec_handle_iterate(srsran_tdec_t* h, int16_t* input, uint8_t* outpu
   const uint32_t n_begin = (uint32_t)h->n_iter;
   const size_t   in_len  = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
   if (n_begin == 0) {
-    memcpy(c->h_in, input, in_len * sizeof(int16_t));
-    if (sb_layout) {
+    // The reference converts between LLR widths on the host when API and decoder differ (convert_8_to_16 /
+    // convert_16_to_8, turbodecoder.c:443-453); here the kernel's extraction does it.  (The reference
+    // converts only 3K+12 elements even for the longer sub-block layout; all of it is converted here.)
+    memcpy(c->h_in, input, in_len * sizeof(ELEM));
+    if (sb_layout && in8 == arith8) {
       // the reference writes the tail into the caller's buffer here (turbodecoder_iter.h:58-70,92-96)
       for (uint32_t i = K; i < K + 3; i++) {
-        input[i]          = input[3 * (K + 32) + 2 * (i - K)];
-        input[K + 32 + i] = input[3 * (K + 32) + 2 * (i - K) + 1];
+        input[i]                = input[3 * (K + 32) + 2 * (i - K)];
+        input[K + 32 + i]       = input[3 * (K + 32) + 2 * (i - K) + 1];
+        input[2 * (K + 32) + i] = input[3 * (K + 32) + 6 + 2 * (i - K) + 1];
       }
     }
-    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, in_len * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, in_len * sizeof(ELEM), hipMemcpyHostToDevice, c->stream));
   }
-  if (tdec_batch_run_range(it->second, c->d_in, (uint32_t)in_len, c->d_out, K / 8, 1, n_begin, n_end, sb_layout, false,
+  if (tdec_batch_run_range(it->second, c->d_in, in8, (uint32_t)in_len, c->d_out, K / 8, 1, n_begin, n_end, sb_layout, false,
                            c->stream)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_tdec: %s\n", get_error());
     return;
@@ -535,19 +612,16 @@ extern "C" int srsran_tdec_run_all(srsran_tdec_t* h, int16_t* input, uint8_t* ou
 
 extern "C" void srsran_tdec_iteration_8bit(srsran_tdec_t* h, int8_t* input, uint8_t* output)
 {
-  (void)h;
-  (void)input;
-  (void)output;
-  fprintf(stderr, "[srsran_phy_hip] srsran_tdec_iteration_8bit: 8-bit LLR decoders are not implemented in the HIP engine\n");
+  if (h->current_cbidx >= 0) {
+    tdec_handle_iterate(h, input, output, (uint32_t)h->n_iter + 1);
+  }
 }
 
 extern "C" int srsran_tdec_run_all_8bit(srsran_tdec_t* h, int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
 {
-  (void)h;
-  (void)input;
-  (void)output;
-  (void)nof_iterations;
-  (void)long_cb;
-  fprintf(stderr, "[srsran_phy_hip] srsran_tdec_run_all_8bit: 8-bit LLR decoders are not implemented in the HIP engine\n");
-  return SRSRAN_ERROR;
+  if (srsran_tdec_new_cb(h, long_cb)) {
+    return SRSRAN_ERROR;
+  }
+  tdec_handle_iterate(h, input, output, nof_iterations ? nof_iterations : 1);
+  return h->n_iter ? SRSRAN_SUCCESS : SRSRAN_ERROR;
 }

@@ -31,18 +31,6 @@ typedef short s2 __attribute__((ext_vector_type(2)));
 #define TD_INF 10000 // turbodecoder_win.h:56 / turbodecoder_gen.c:37
 #define TD_WIN_OVERLAP 40
 
-__device__ __forceinline__ s2 adds(s2 a, s2 b)
-{
-  return __builtin_elementwise_add_sat(a, b);
-}
-__device__ __forceinline__ s2 subs(s2 a, s2 b)
-{
-  return __builtin_elementwise_sub_sat(a, b);
-}
-__device__ __forceinline__ s2 vmax(s2 a, s2 b)
-{
-  return __builtin_elementwise_max(a, b);
-}
 __device__ __forceinline__ s2 from_u(uint32_t u)
 {
   return __builtin_bit_cast(s2, u);
@@ -56,21 +44,87 @@ __device__ __forceinline__ s2 splat(short v)
   s2 r = {v, v};
   return r;
 }
-
-// turbodecoder_win.h:480-498 (normalize_period 2; caller checks the step index)
-__device__ __forceinline__ void normalize(s2 (&o)[8])
+__device__ __forceinline__ s2 vmax(s2 a, s2 b)
 {
-#pragma unroll
-  for (int i = 1; i < 8; i++) {
-    o[i] = subs(o[i], o[0]);
-  }
-  o[0] = splat(0);
+  return __builtin_elementwise_max(a, b);
+}
+__device__ __forceinline__ s2 vmin(s2 a, s2 b)
+{
+  return __builtin_elementwise_min(a, b);
 }
 
+// Arithmetic of the 16-bit window decoders (WINIMP_IS_SSE16 / AVX16, turbodecoder_win.h:60-150): saturating
+// int16, INF = 10000, state metrics re-based on state 0 every second step.
+struct Ar16 {
+  static constexpr bool kIs8 = false;
+  static constexpr int  kInf = TD_INF;
+  static __device__ __forceinline__ s2 add(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+  static __device__ __forceinline__ s2 sub(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }
+  static __device__ __forceinline__ bool norm_at(uint32_t k) { return (k & 1) == 0 && k != 0; }
+  // turbodecoder_win.h:480-498 (normalize_period 2; caller checks the step index)
+  static __device__ __forceinline__ void normalize(s2 (&o)[8])
+  {
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+      o[i] = sub(o[i], o[0]);
+    }
+    o[0] = splat(0);
+  }
+  static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return sub(m1, m0); }
+  static __device__ __forceinline__ short tadd(short a, short b) { return (short)(a + b); } // tail trellis, plain adds
+  static __device__ __forceinline__ short conv_in(int v) { return (short)v; }
+  // extrinsic exchange (turbodecoder_iter.h:108,115 = srsran_vec_sub_sss, wrapping): the stored word is the
+  // processed value; the raw decoder output the decision needs is recovered as E1 + A1 (exact, wrapping)
+  static __device__ __forceinline__ s2 ex_lo(s2 v) { return v; }
+  static __device__ __forceinline__ s2 ex_pack(s2 raw, s2 proc) { return proc; }
+  static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return a - b; }
+  static __device__ __forceinline__ s2 decide(s2 e1, s2 a1, uint32_t n_end) { return n_end >= 2 ? e1 + a1 : e1; }
+};
+
+// Arithmetic of the 8-bit window decoders (WINIMP_IS_SSE8 / AVX8, turbodecoder_win.h:154-300): saturating int8
+// (kept in int16 lanes and clamped), INF = 0, metrics re-based on their maximum at every step, LLR halved.
+struct Ar8 {
+  static constexpr bool kIs8 = true;
+  static constexpr int  kInf = 0;
+  static __device__ __forceinline__ s2 clamp8(s2 v) { return vmin(vmax(v, splat(-128)), splat(127)); }
+  static __device__ __forceinline__ s2 sext8(s2 v) { return (s2)(v << 8) >> 8; }
+  static __device__ __forceinline__ s2 add(s2 a, s2 b) { return clamp8(a + b); }
+  static __device__ __forceinline__ s2 sub(s2 a, s2 b) { return clamp8(a - b); }
+  static __device__ __forceinline__ bool norm_at(uint32_t k) { return k != 0; }
+  static __device__ __forceinline__ void normalize(s2 (&o)[8])
+  {
+    s2 m = vmax(o[0], o[1]);
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+      m = vmax(m, o[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      o[i] = sub(o[i], m);
+    }
+  }
+  static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return sub(m1, m0) >> 1; } // divide_output 1
+  static __device__ __forceinline__ short tadd(short a, short b) // sadd(), :470-478: clamps the positive side only
+  {
+    int z = a + b;
+    return z > 127 ? (short)127 : (short)(signed char)z;
+  }
+  static __device__ __forceinline__ short conv_in(int v) { return (short)(signed char)v; } // convert_16_to_8
+  // srsran_vec_sub_bbb saturates (and wraps in the ragged tail of the vector loop), so the raw value cannot
+  // be recovered by adding back: a stored word carries the raw output in its high byte and the processed
+  // one in its low byte
+  static __device__ __forceinline__ s2 ex_lo(s2 v) { return sext8(v); }
+  static __device__ __forceinline__ s2 ex_pack(s2 raw, s2 proc) { return (raw << 8) | (proc & splat(0xff)); }
+  static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return wrap ? sext8(a - b) : clamp8(a - b); }
+  static __device__ __forceinline__ s2 decide(s2 e1, s2 a1, uint32_t n_end) { return ((n_end & 1) ? e1 : a1) >> 8; }
+};
+
 // one backward step, turbodecoder_win.h:626-652
+template <class AR>
 __device__ __forceinline__ void beta_step(s2 (&o)[8], s2 x, s2 y)
 {
-  s2 xy = adds(x, y);
+  auto adds = [](s2 a, s2 b) { return AR::add(a, b); };
+  s2   xy   = adds(x, y);
   s2 n0 = vmax(adds(o[4], xy), o[0]);
   s2 n1 = vmax(o[4], adds(o[0], xy));
   s2 n2 = vmax(adds(o[5], y), adds(o[1], x));
@@ -90,10 +144,11 @@ __device__ __forceinline__ void beta_step(s2 (&o)[8], s2 x, s2 y)
 }
 
 // one forward step, turbodecoder_win.h:753-826.  WITH_LLR: also max1-max0 using the beta of the next step.
-template <bool WITH_LLR>
+template <class AR, bool WITH_LLR>
 __device__ __forceinline__ s2 alpha_step(s2 (&o)[8], const s2 (&b)[8], s2 x, s2 y)
 {
-  s2 xy = adds(x, y);
+  auto adds = [](s2 a, s2 b) { return AR::add(a, b); };
+  s2   xy   = adds(x, y);
   s2 m_b[8], nw[8];
   m_b[0] = o[0];
   m_b[1] = adds(o[3], y);
@@ -120,7 +175,7 @@ __device__ __forceinline__ s2 alpha_step(s2 (&o)[8], const s2 (&b)[8], s2 x, s2 
       m0 = vmax(m0, adds(b[i], m_b[i]));
       m1 = vmax(m1, adds(b[i], nw[i]));
     }
-    out = subs(m1, m0);
+    out = AR::llr(m1, m0);
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -135,33 +190,34 @@ __device__ __forceinline__ short wrap16(int v)
 }
 
 // turbodecoder_win.h:500-548: start state of the last sub-block from the 3 tail steps (plain adds)
+template <class AR>
 __device__ __forceinline__ void tail_trellis(const short* xt, const short* yt, short (&old)[8])
 {
   old[0] = 0;
 #pragma unroll
   for (int i = 1; i < 8; i++) {
-    old[i] = -TD_INF;
+    old[i] = -AR::kInf;
   }
 #pragma unroll
   for (int k = 2; k >= 0; k--) {
     short x = xt[k], y = yt[k];
-    short xy = wrap16(x + y);
+    short xy = AR::tadd(x, y);
     short m_b[8], nw[8];
-    m_b[0] = wrap16(old[4] + xy);
+    m_b[0] = AR::tadd(old[4], xy);
     m_b[1] = old[4];
-    m_b[2] = wrap16(old[5] + y);
-    m_b[3] = wrap16(old[5] + x);
-    m_b[4] = wrap16(old[6] + x);
-    m_b[5] = wrap16(old[6] + y);
+    m_b[2] = AR::tadd(old[5], y);
+    m_b[3] = AR::tadd(old[5], x);
+    m_b[4] = AR::tadd(old[6], x);
+    m_b[5] = AR::tadd(old[6], y);
     m_b[6] = old[7];
-    m_b[7] = wrap16(old[7] + xy);
+    m_b[7] = AR::tadd(old[7], xy);
     nw[0] = old[0];
-    nw[1] = wrap16(old[0] + xy);
-    nw[2] = wrap16(old[1] + x);
-    nw[3] = wrap16(old[1] + y);
-    nw[4] = wrap16(old[2] + y);
-    nw[5] = wrap16(old[2] + x);
-    nw[6] = wrap16(old[3] + xy);
+    nw[1] = AR::tadd(old[0], xy);
+    nw[2] = AR::tadd(old[1], x);
+    nw[3] = AR::tadd(old[1], y);
+    nw[4] = AR::tadd(old[2], y);
+    nw[5] = AR::tadd(old[2], x);
+    nw[6] = AR::tadd(old[3], xy);
     nw[7] = old[3];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -226,7 +282,7 @@ __device__ __forceinline__ void load_rows(const uint32_t* arr, uint32_t b, int l
 template <int LPC>
 __device__ __forceinline__ uint32_t permute_pair(uint32_t v, uint32_t sel)
 {
-  const uint32_t jlo = sel & 15u, jhi = (sel >> 4) & 15u;
+  const uint32_t jlo = sel & 31u, jhi = (sel >> 5) & 31u;
   const uint32_t a   = __shfl(v, (int)(jlo >> 1), LPC);
   const uint32_t c   = __shfl(v, (int)(jhi >> 1), LPC);
   const uint32_t lo  = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
@@ -234,7 +290,64 @@ __device__ __forceinline__ uint32_t permute_pair(uint32_t v, uint32_t sel)
   return lo | (hi << 16);
 }
 
-template <int LPC>
+// phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102) from int16 or int8
+// LLRs.  All 48 element loads of an 8-step block are issued before the first use (addresses clamped instead
+// of branching on the ragged last block), so the block costs one memory round trip, not eight.
+template <int LPC, class AR, typename T>
+__device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32_t K, uint32_t long_sb, uint32_t nblk,
+                                              int lane, int pl, uint32_t* S, uint32_t* P0, uint32_t* P1, short* TL)
+{
+  constexpr int NB = 2 * LPC;
+  for (uint32_t b = 0; b < nblk; b++) {
+    const int nv = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8; // valid steps in this block
+    short     r[2][24];
+    if (sb_layout) {
+      // rm_turbo layout: element (step k, sub-block d) of array a at in[a*(K+32) + k*NB + d]
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t k = b * 8 + (j < nv ? j : nv - 1);
+#pragma unroll
+        for (int a3 = 0; a3 < 3; a3++) {
+          r[0][3 * j + a3] = AR::conv_in(in[a3 * (K + 32) + k * NB + 2 * pl]);
+          r[1][3 * j + a3] = AR::conv_in(in[a3 * (K + 32) + k * NB + 2 * pl + 1]);
+        }
+      }
+    } else {
+      // natural order: the 8 steps of one sub-block are 24 consecutive LLRs [s p0 p1]...
+      const T*  c0  = in + 3 * ((size_t)(2 * pl) * long_sb + b * 8);
+      const T*  c1  = in + 3 * ((size_t)(2 * pl + 1) * long_sb + b * 8);
+      const int lim = 3 * nv - 1;
+#pragma unroll
+      for (int t = 0; t < 24; t++) {
+        const int tt = t < lim ? t : lim;
+        r[0][t]      = AR::conv_in(c0[tt]);
+        r[1][t]      = AR::conv_in(c1[tt]);
+      }
+    }
+    uint32_t s[8], y0[8], y1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      s[j]  = (uint32_t)(uint16_t)r[0][3 * j] | ((uint32_t)(uint16_t)r[1][3 * j] << 16);
+      y0[j] = (uint32_t)(uint16_t)r[0][3 * j + 1] | ((uint32_t)(uint16_t)r[1][3 * j + 1] << 16);
+      y1[j] = (uint32_t)(uint16_t)r[0][3 * j + 2] | ((uint32_t)(uint16_t)r[1][3 * j + 2] << 16);
+    }
+    store_block(S, b * 64 + lane, s);
+    store_block(P0, b * 64 + lane, y0);
+    store_block(P1, b * 64 + lane, y1);
+  }
+  if (pl == 0) {
+    const uint32_t tb = sb_layout ? 3 * (K + 32) : 3 * K;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      TL[i]     = AR::conv_in(in[tb + 2 * i]);         // syst tail
+      TL[3 + i] = AR::conv_in(in[tb + 2 * i + 1]);     // parity0 tail
+      TL[6 + i] = AR::conv_in(in[tb + 6 + 2 * i]);     // app2 tail
+      TL[9 + i] = AR::conv_in(in[tb + 6 + 2 * i + 1]); // parity1 tail
+    }
+  }
+}
+
+template <int LPC, class AR>
 __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 {
   constexpr int NB  = 2 * LPC;
@@ -266,59 +379,19 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   uint32_t* CK  = ws + 6 * AWG;
   short*    TL  = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * 64 * 8) + 16 * (lane / LPC); // 12 tail LLRs per block
 
-  // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102)
+  // ---- phase 0: input extraction
   if (p.n_begin == 0) {
-    const short* in = p.input + (size_t)cb * p.in_stride;
-    // All 48 element loads of an 8-step block are issued before the first use (addresses clamped instead of
-    // branching on the ragged last block), so the block costs one memory round trip, not eight.
-    for (uint32_t b = 0; b < nblk; b++) {
-      const int nv = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8; // valid steps in this block
-      short     r[2][24];
-      if (p.sb_layout) {
-        // rm_turbo layout: element (step k, sub-block d) of array a at in[a*(K+32) + k*NB + d]
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const uint32_t k = b * 8 + (j < nv ? j : nv - 1);
-#pragma unroll
-          for (int a3 = 0; a3 < 3; a3++) {
-            r[0][3 * j + a3] = in[a3 * (K + 32) + k * NB + 2 * pl];
-            r[1][3 * j + a3] = in[a3 * (K + 32) + k * NB + 2 * pl + 1];
-          }
-        }
-      } else {
-        // natural order: the 8 steps of one sub-block are 24 consecutive int16 [s p0 p1]...
-        const short* c0 = in + 3 * ((size_t)(2 * pl) * long_sb + b * 8);
-        const short* c1 = in + 3 * ((size_t)(2 * pl + 1) * long_sb + b * 8);
-        const int    lim = 3 * nv - 1;
-#pragma unroll
-        for (int t = 0; t < 24; t++) {
-          const int tt = t < lim ? t : lim;
-          r[0][t]      = c0[tt];
-          r[1][t]      = c1[tt];
-        }
-      }
-      uint32_t s[8], y0[8], y1[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        s[j]  = (uint32_t)(uint16_t)r[0][3 * j] | ((uint32_t)(uint16_t)r[1][3 * j] << 16);
-        y0[j] = (uint32_t)(uint16_t)r[0][3 * j + 1] | ((uint32_t)(uint16_t)r[1][3 * j + 1] << 16);
-        y1[j] = (uint32_t)(uint16_t)r[0][3 * j + 2] | ((uint32_t)(uint16_t)r[1][3 * j + 2] << 16);
-      }
-      store_block(S, b * 64 + lane, s);
-      store_block(P0, b * 64 + lane, y0);
-      store_block(P1, b * 64 + lane, y1);
-    }
-    if (pl == 0) {
-      const uint32_t tb = p.sb_layout ? 3 * (K + 32) : 3 * K;
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        TL[i]     = in[tb + 2 * i];         // syst tail
-        TL[3 + i] = in[tb + 2 * i + 1];     // parity0 tail
-        TL[6 + i] = in[tb + 6 + 2 * i];     // app2 tail
-        TL[9 + i] = in[tb + 6 + 2 * i + 1]; // parity1 tail
-      }
+    if (p.in_is8) {
+      const signed char* in = reinterpret_cast<const signed char*>(p.input) + (size_t)cb * p.in_stride;
+      extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
+    } else {
+      const short* in = p.input + (size_t)cb * p.in_stride;
+      extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     }
   }
+  // rows of the exchanged vectors whose subtraction wraps instead of saturating (8-bit only: the ragged
+  // tail of srsran_vec_sub_bbb's 32-byte vector loop, vector_simd.c:162-190)
+  const uint32_t wrap_row = (AR::kIs8 && (K & 31u)) ? long_sb - 1 : 0xffffffffu;
   __syncthreads();
 
   // ---- half iterations (turbodecoder_iter.h:72-141)
@@ -353,8 +426,8 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         ys[j] = from_u(q.y[j]);
         ap[j] = splat(0);
         if (has_app) {
-          ap[j] = from_u(q.a[j]);
-          xs[j] = adds(ap[j], xs[j]);
+          ap[j] = AR::ex_lo(from_u(q.a[j]));
+          xs[j] = AR::add(ap[j], xs[j]);
         }
       }
     };
@@ -364,7 +437,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     // ================= backward recursion (turbodecoder_win.h:551-681)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      o[i] = splat(-TD_INF);
+      o[i] = splat(-AR::kInf);
     }
     // pass 0: 40 steps on the head of every sub-block, all states unknown
     issue(TD_WIN_OVERLAP / 8 - 1, cur);
@@ -374,10 +447,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       prep(cur, xs, ys, ap);
 #pragma unroll
       for (int j = 7; j >= 0; j--) {
-        beta_step(o, xs[j], ys[j]);
+        beta_step<AR>(o, xs[j], ys[j]);
         uint32_t k = b * 8 + j;
-        if ((k & 1) == 0 && k != 0) {
-          normalize(o);
+        if (AR::norm_at(k)) {
+          AR::normalize(o);
         }
       }
       cur = nxt;
@@ -385,7 +458,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     // hand every estimate to the previous sub-block; the last one starts from the tail trellis
     {
       short tr[8];
-      tail_trellis(xt, yt, tr);
+      tail_trellis<AR>(xt, yt, tr);
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         uint32_t u   = to_u(o[i]);
@@ -412,7 +485,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       for (int j = 7; j >= 0; j--) {
         uint32_t k = b * 8 + j;
         if (k < long_sb) {
-          beta_step(o, xs[j], ys[j]);
+          beta_step<AR>(o, xs[j], ys[j]);
           if (j == 0 && b > 0) {
             uint32_t ck[8];
 #pragma unroll
@@ -421,8 +494,8 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
             }
             store_block(CK, b * 64 + lane, ck);
           }
-          if ((k & 1) == 0 && k != 0) {
-            normalize(o);
+          if (AR::norm_at(k)) {
+            AR::normalize(o);
           }
         }
       }
@@ -433,7 +506,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     // ================= forward recursion + LLR (turbodecoder_win.h:684-832)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      o[i] = splat(-TD_INF);
+      o[i] = splat(-AR::kInf);
     }
     {
       const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
@@ -447,10 +520,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         for (int j = 0; j < 8; j++) {
           uint32_t k = b * 8 + j;
           if (k >= w0 && k < long_sb) {
-            alpha_step<false>(o, o, xs[j], ys[j]);
+            alpha_step<AR, false>(o, o, xs[j], ys[j]);
             uint32_t kk = k - w0;
-            if ((kk & 1) == 0 && kk != 0) {
-              normalize(o);
+            if (AR::norm_at(kk)) {
+              AR::normalize(o);
             }
           }
         }
@@ -462,7 +535,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     for (int i = 0; i < 8; i++) {
       uint32_t u   = to_u(o[i]);
       uint32_t prv = __shfl_up(u, 1, LPC);
-      uint32_t lo  = (pl == 0) ? (uint32_t)(uint16_t)(short)(i ? -TD_INF : 0) : (prv >> 16);
+      uint32_t lo  = (pl == 0) ? (uint32_t)(uint16_t)(short)(i ? -AR::kInf : 0) : (prv >> 16);
       uint32_t hi  = u & 0xffffu;
       o[i]         = from_u(lo | (hi << 16));
     }
@@ -508,10 +581,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         for (int j = 6; j >= 0; j--) {
           if (j <= len - 2) {
             uint32_t idx = b * 8 + j + 2; // index of the stored value we start from
-            if (idx != long_sb && (idx & 1) == 0) {
-              normalize(st);
+            if (idx != long_sb && AR::norm_at(idx)) {
+              AR::normalize(st);
             }
-            beta_step(st, xs[j + 1], ys[j + 1]);
+            beta_step<AR>(st, xs[j + 1], ys[j + 1]);
             Bl[j][0][lane] = make_uint4(to_u(st[0]), to_u(st[1]), to_u(st[2]), to_u(st[3]));
             Bl[j][1][lane] = make_uint4(to_u(st[4]), to_u(st[5]), to_u(st[6]), to_u(st[7]));
           }
@@ -525,28 +598,32 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           const uint4 b0 = Bl[j][0][lane], b1 = Bl[j][1][lane];
           const s2    B[8] = {from_u(b0.x), from_u(b0.y), from_u(b0.z), from_u(b0.w),
                               from_u(b1.x), from_u(b1.y), from_u(b1.z), from_u(b1.w)};
-          s2       llr = alpha_step<true>(o, B, xs[j], ys[j]);
+          s2       llr = alpha_step<AR, true>(o, B, xs[j], ys[j]);
           uint32_t k   = b * 8 + j;
-          if ((k & 1) == 0 && k != 0) {
-            normalize(o);
+          if (AR::norm_at(k)) {
+            AR::normalize(o);
           }
+          s2 proc = llr;
           if (fuse) {
-            llr = llr - ap[j];
+            proc = AR::ex_sub(llr, ap[j], k == wrap_row);
           }
-          outv[j] = to_u(llr);
+          outv[j] = to_u(proc);
+          if (dec1) {
+            E1[(size_t)k * 64 + lane] = to_u(AR::ex_pack(llr, proc));
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         if (j < len) {
-          if (dec1) {
-            E1[(size_t)(b * 8 + j) * 64 + lane] = outv[j];
-          }
-          uint32_t w = permute_pair<LPC>(outv[j], tr[j] >> 16);
+          uint32_t       w   = permute_pair<LPC>(outv[j], tr[j] >> 16);
+          const uint32_t row = tr[j] & 0xffffu;
           if (!dec1) {
-            w = to_u(from_u(w) - from_u(eg[j])); // app1 - ext1 (srsran_vec_sub_sss: wrapping)
+            // app1 - ext1 of the next half iteration (turbodecoder_iter.h:108)
+            const s2 raw = from_u(w);
+            w            = to_u(AR::ex_pack(raw, AR::ex_sub(raw, AR::ex_lo(from_u(eg[j])), row == wrap_row)));
           }
-          dst[(size_t)(tr[j] & 0xffffu) * 64 + lane] = w;
+          dst[(size_t)row * 64 + lane] = w;
         }
       }
       cur = nxt;
@@ -563,7 +640,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   // Source: app1 after an even number of half iterations, else ext1.  With the fused subtractions both
   // are E1 + A1 (wrapping) once two half iterations have run; after a single one it is E1.
   {
-    const bool both = p.n_end >= 2;
+    const bool both = p.n_end >= 2; // A1 has been written
     uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
     short*     o16  = p.dec_llr ? p.dec_llr + (size_t)cb * K : nullptr;
     if ((long_sb & 7) == 0) {
@@ -579,10 +656,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          s2 v = from_u(r[j]);
-          if (both) {
-            v = v + from_u(r2[j]);
-          }
+          s2 v = AR::decide(from_u(r[j]), both ? from_u(r2[j]) : splat(0), p.n_end);
           b0 |= (v.x > 0 ? 0x80u : 0u) >> j;
           b1 |= (v.y > 0 ? 0x80u : 0u) >> j;
           if (o16) { // parity aid: decision LLRs in natural order
@@ -612,10 +686,8 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           uint32_t nn = jb * 8 + t;
           uint32_t d = nn / long_sb, k = nn % long_sb;
           uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
-          short    v = se[e];
-          if (both) {
-            v = wrap16(v + sa[e]);
-          }
+          s2 ve = {se[e], 0}, va = {both ? sa[e] : (short)0, 0};
+          short v = AR::decide(ve, va, p.n_end).x;
           byte |= (v > 0 ? 0x80u : 0u) >> t;
           if (o16) {
             o16[nn] = v;
@@ -674,17 +746,20 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
   // beta: 8 * (K+4) from oB
 
   if (p.n_begin == 0) {
-    const short* in = p.input + (size_t)cb * p.in_stride;
+    // int8 input: the 8-bit API widens to int16 when no 8-bit decoder takes this K (turbodecoder.c:455-478)
+    const short*       in16 = p.input + (size_t)cb * p.in_stride;
+    const signed char* in8  = reinterpret_cast<const signed char*>(p.input) + (size_t)cb * p.in_stride;
+    auto               in   = [&](uint32_t i) -> short { return p.in_is8 ? (short)in8[i] : in16[i]; };
     for (uint32_t i = 0; i < K; i++) { // turbodecoder_gen.c:238-258
-      GV(oS, i)  = in[3 * i];
-      GV(oP0, i) = in[3 * i + 1];
-      GV(oP1, i) = in[3 * i + 2];
+      GV(oS, i)  = in(3 * i);
+      GV(oP0, i) = in(3 * i + 1);
+      GV(oP1, i) = in(3 * i + 2);
     }
     for (uint32_t i = K; i < K + 3; i++) {
-      GV(oS, i)  = in[3 * K + 2 * (i - K)];
-      GV(oP0, i) = in[3 * K + 2 * (i - K) + 1];
-      GV(oA2, i) = in[3 * K + 6 + 2 * (i - K)];
-      GV(oP1, i) = in[3 * K + 6 + 2 * (i - K) + 1];
+      GV(oS, i)  = in(3 * K + 2 * (i - K));
+      GV(oP0, i) = in(3 * K + 2 * (i - K) + 1);
+      GV(oA2, i) = in(3 * K + 6 + 2 * (i - K));
+      GV(oP1, i) = in(3 * K + 6 + 2 * (i - K) + 1);
     }
   }
   const uint16_t* inter   = p.inter;
@@ -821,14 +896,20 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
 
 // ------------------------------------------------------------------------------------------------ launchers
 
-hipError_t launch_win(int nb, const WinParams& p, hipStream_t stream)
+hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream)
 {
-  if (nb == 16) {
-    dim3 grid(ceil_div(p.n_cb, 8));
-    hipLaunchKernelGGL(tdec_win_kernel<8>, grid, dim3(64), 0, stream, p);
+  const int lpc = nb / 2;
+  dim3      grid(ceil_div(p.n_cb, 64 / lpc));
+  if (!arith8 && nb == 16) {
+    hipLaunchKernelGGL((tdec_win_kernel<8, Ar16>), grid, dim3(64), 0, stream, p);
+  } else if (!arith8 && nb == 8) {
+    hipLaunchKernelGGL((tdec_win_kernel<4, Ar16>), grid, dim3(64), 0, stream, p);
+  } else if (arith8 && nb == 16) {
+    hipLaunchKernelGGL((tdec_win_kernel<8, Ar8>), grid, dim3(64), 0, stream, p);
+  } else if (arith8 && nb == 32) {
+    hipLaunchKernelGGL((tdec_win_kernel<16, Ar8>), grid, dim3(64), 0, stream, p);
   } else {
-    dim3 grid(ceil_div(p.n_cb, 16));
-    hipLaunchKernelGGL(tdec_win_kernel<4>, grid, dim3(64), 0, stream, p);
+    return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
@@ -842,7 +923,7 @@ hipError_t launch_gen(const GenParams& p, hipStream_t stream)
 
 uint32_t win_elem_index(int nb, uint32_t k, uint32_t d)
 {
-  return nb == 16 ? elem_index<8>(k, d) : elem_index<4>(k, d);
+  return nb == 32 ? elem_index<16>(k, d) : (nb == 16 ? elem_index<8>(k, d) : elem_index<4>(k, d));
 }
 
 } // namespace turbo

@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libsrsran_ref.so")
 
-ORC_TDEC_AUTO, ORC_TDEC_GENERIC, ORC_TDEC_SSE_WINDOW, ORC_TDEC_AVX_WINDOW = 0, 1, 3, 5
+ORC_TDEC_AUTO, ORC_TDEC_GENERIC, ORC_TDEC_SSE_WINDOW, ORC_TDEC_AVX_WINDOW, ORC_TDEC_SSE8_WINDOW, ORC_TDEC_AVX8_WINDOW = 0, 1, 3, 5, 6, 7
 
 
 class LdpcGraph(C.Structure):
@@ -43,6 +43,7 @@ def orc():
         L = C.CDLL(build_oracle())
         vp = C.c_void_p
         L.orc_tdec_run_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]
+        L.orc_tdec_run_all_8bit.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp]
         L.orc_tcod_encode.argtypes = [vp, vp, C.c_uint32]
         L.orc_qpp_gen.argtypes = [C.c_uint32, C.c_uint32, vp, vp]
         L.orc_ldpc_graph.argtypes = [C.POINTER(LdpcGraph), C.c_int, C.c_uint16]
@@ -101,11 +102,29 @@ def turbo_decode(llr, nof_iterations, K, impl=ORC_TDEC_AUTO, sb_layout=0, want_l
     return (out, dl) if want_llr else out
 
 
+def turbo_decode_8bit(llr, nof_iterations, K, impl=ORC_TDEC_AUTO, sb_layout=0, want_llr=False):
+    """srsran_tdec_run_all_8bit on int8 LLRs"""
+    llr = np.ascontiguousarray(llr, np.int8)
+    n_cb = llr.shape[0]
+    out = np.zeros((n_cb, K // 8), np.uint8)
+    dl = np.zeros((n_cb, K), np.int16)
+    for i in range(n_cb):
+        rc = orc().orc_tdec_run_all_8bit(P(llr[i]), P(out[i]), nof_iterations, K, impl, sb_layout, P(dl[i]))
+        assert rc == 0, rc
+    return (out, dl) if want_llr else out
+
+
+def turbo_llrs_8bit(K, n_cb, esn0_db, seed, scale=12.0):
+    """int8 LLRs for the 8-bit API (scaled to about +-30, clipped to +-127)"""
+    msgs, llr = turbo_llrs(K, n_cb, esn0_db, seed, scale=scale)
+    return msgs, np.clip(llr, -127, 127).astype(np.int8)
+
+
 def natural_to_sb_layout(llr_nat, K, nb):
     """what srsran_rm_turbo_rx_lut hands to the window decoders (rm_turbo.c:260-273,
     turbodecoder_iter.h:88-102): syst @0, parity0 @K+32, parity1 @2(K+32) in [step][sub-block] order,
     12 tail LLRs @3(K+32)."""
-    out = np.zeros(3 * (K + 32) + 12, np.int16)
+    out = np.zeros(3 * (K + 32) + 12, llr_nat.dtype)
     sb = K // nb
     n = np.arange(K)
     idx = (n % sb) * nb + n // sb

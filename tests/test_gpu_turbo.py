@@ -48,7 +48,7 @@ def test_every_block_size_once(hiplib):
 
 
 @pytest.mark.parametrize("impl_g,impl_o,K", [("GENERIC", O.ORC_TDEC_GENERIC, 1024), ("SSE_WINDOW", O.ORC_TDEC_SSE_WINDOW, 6144),
-                                              ("AVX_WINDOW", O.ORC_TDEC_AVX_WINDOW, 640), ("SSE_WINDOW", O.ORC_TDEC_SSE_WINDOW, 328)])
+                                              ("AVX_WINDOW", O.ORC_TDEC_AVX_WINDOW, 1024), ("SSE_WINDOW", O.ORC_TDEC_SSE_WINDOW, 328)])
 def test_manual_implementations(hiplib, impl_g, impl_o, K):
     import srslte_amd as S
     from srslte_amd import capi
@@ -63,6 +63,91 @@ def test_rm_turbo_subblock_layout(hiplib, K):
     from srslte_amd import capi
 
     _check(S, K, capi.TDEC_AUTO, O.ORC_TDEC_AUTO, 9, -1.0, (1, 2, 8), seed=K + 1, sb_layout=1)
+
+
+def _check8(S, K, impl_g, impl_o, n_cb, snr, nits, seed, scale=12.0, sb_layout=0, via16=False):
+    """8-bit LLR API (srsran_tdec_run_all_8bit); via16: a manual 8-bit decoder driven through the int16 entry point,
+    which truncates the LLRs to int8 (convert_16_to_8, turbodecoder.c:449-453) -- the only way the reference can run
+    its manually selected 8-bit decoders (its 8-bit entry point leaves the interleaver index unset in manual mode)"""
+    msgs, llr = O.turbo_llrs_8bit(K, n_cb, snr, seed, scale)
+    src = llr
+    if sb_layout:
+        nb = S.lib().srsran_tdec_autoimp_get_subblocks_8bit(K)
+        src = np.stack([O.natural_to_sb_layout(llr[i], K, nb) for i in range(n_cb)])
+    dec = S.TdecBatch(K, n_cb, impl_g, llr8=True)
+    for nit in nits:
+        ref, ref_llr = O.turbo_decode_8bit(src, nit, K, impl_o, sb_layout, want_llr=True)
+        out, out_llr = dec.decode(src.astype(np.int16) if via16 else src, nit, sb_layout, want_llr=True)
+        assert np.array_equal(ref, out), "K=%d nit=%d snr=%g: %d code blocks differ" % (K, nit, snr, np.any(ref != out, axis=1).sum())
+        assert np.array_equal(ref_llr, out_llr), "K=%d nit=%d snr=%g: decision LLRs differ" % (K, nit, snr)
+    dec.free()
+
+
+@pytest.mark.parametrize("K", [40, 416, 504, 816, 832, 1008, 1024, 2048, 2112, 3136, 6144])
+def test_8bit_auto_all_regimes(hiplib, K):
+    """AUTO through the 8-bit API: avx8 (32 sub-blocks), sse8 (16), or widened to sse16 / gen (turbodecoder.c:410-478).
+    K=816 and 1008 have K%32 == 16: the last row of the exchanged vectors is subtracted wrapping, not saturating."""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    for snr, scale in ((3.0, 12.0), (-1.0, 12.0), (0.0, 60.0), (-4.0, 8.0)):
+        _check8(S, K, capi.TDEC_AUTO, O.ORC_TDEC_AUTO, 7, snr, (1, 2, 3, 4, 7, 8), seed=K * 5 + int(scale), scale=scale)
+
+
+@pytest.mark.parametrize("impl,K", [("SSE8_WINDOW", 816), ("SSE8_WINDOW", 6144), ("AVX8_WINDOW", 1344), ("AVX8_WINDOW", 6144)])
+def test_8bit_manual_implementations(hiplib, impl, K):
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    for via16 in (False, True):
+        _check8(S, K, getattr(capi, "TDEC_" + impl), getattr(O, "ORC_TDEC_" + impl), 5, -1.0, (1, 2, 5, 8), seed=K, scale=30.0,
+                via16=via16)
+    h = C.c_void_p()
+    assert S.lib().srsran_hip_tdec_batch_create(C.byref(h), 1280, 1, capi.TDEC_AVX8_WINDOW) == capi.SRSRAN_ERROR_INVALID_INPUTS
+
+
+@pytest.mark.parametrize("K", [6144, 1024])
+def test_8bit_rm_turbo_subblock_layout(hiplib, K):
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    _check8(S, K, capi.TDEC_AUTO, O.ORC_TDEC_AUTO, 5, -1.0, (1, 2, 8), seed=K + 1, sb_layout=1)
+
+
+def test_8bit_handle_api(hiplib):
+    """srsran_tdec_run_all_8bit / iteration_8bit through the drop-in handle"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    h = capi.Tdec()
+    assert lib.srsran_tdec_init(C.byref(h), 6144) == 0
+    lib.srsran_tdec_force_not_sb(C.byref(h))
+    for K in (6144, 1024, 504, 40):
+        msgs, llr = O.turbo_llrs_8bit(K, 2, -1.0, seed=K + 3)
+        for nit in (1, 4, 8):
+            ref = O.turbo_decode_8bit(llr, nit, K)
+            for i in range(2):
+                out = np.zeros(K // 8, np.uint8)
+                assert lib.srsran_tdec_run_all_8bit(C.byref(h), O.P(llr[i].copy()), O.P(out), nit, K) == 0
+                assert np.array_equal(out, ref[i])
+        assert lib.srsran_tdec_new_cb(C.byref(h), K) == 0
+        inp = llr[0].copy()
+        for nit in range(1, 5):
+            out = np.zeros(K // 8, np.uint8)
+            lib.srsran_tdec_iteration_8bit(C.byref(h), O.P(inp), O.P(out))
+            assert np.array_equal(out, O.turbo_decode_8bit(llr[:1], nit, K)[0]), (K, nit)
+    lib.srsran_tdec_free(C.byref(h))
+    # manual 8-bit decoder behind the 16-bit entry point, sub-block layout (what turbodecoder_test -d 7 does)
+    h2 = capi.Tdec()
+    assert lib.srsran_tdec_init_manual(C.byref(h2), 6144, capi.TDEC_AVX8_WINDOW) == 0
+    K = 6144
+    msgs, llr = O.turbo_llrs_8bit(K, 1, 0.0, seed=11)
+    sb = O.natural_to_sb_layout(llr[0], K, 32).astype(np.int16)
+    out = np.zeros(K // 8, np.uint8)
+    assert lib.srsran_tdec_run_all(C.byref(h2), O.P(sb), O.P(out), 8, K) == 0
+    assert np.array_equal(out, O.turbo_decode_8bit(llr, 8, K, O.ORC_TDEC_AVX8_WINDOW)[0])
+    lib.srsran_tdec_free(C.byref(h2))
 
 
 def test_saturating_llrs(hiplib):

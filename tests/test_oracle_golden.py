@@ -23,6 +23,17 @@ def test_turbo_reference_outputs():
             assert np.array_equal(got, outs[nit - 1]), (key, nit)
 
 
+def test_turbo_8bit_reference_outputs():
+    """outputs of the reference's 8-bit decoders (AUTO, and the manually selected sse8 / avx8) on seeded int8 LLRs"""
+    d = np.load(os.path.join(G, "turbo8_ref.npz"))
+    for key in d["cases"]:
+        impl, K = int(str(key).split("_")[0][1:]), int(str(key).split("_")[1][1:])
+        llr, outs = d[str(key) + "_llr"], d[str(key) + "_out"]
+        for nit in (1, 2, 3, 5, 8):
+            got = O.turbo_decode_8bit(llr, nit, K, impl)
+            assert np.array_equal(got, outs[nit - 1]), (key, nit)
+
+
 def test_turbo_known_answer_block():
     """turbodecoder_test.h:69-125: K=504 message and its 1524 coded bits"""
     d = np.load(os.path.join(G, "turbo_ref.npz"))
@@ -121,6 +132,14 @@ def test_live_against_compiled_reference():
             for i in range(3):
                 out = np.zeros(K // 8, np.uint8)
                 assert ref.srsran_tdec_run_all(h, O.P(llr[i]), O.P(out), nit, K) == 0
+                assert np.array_equal(out, got[i])
+    for K in (504, 816, 1024, 3136):  # 8-bit API
+        _, l8 = O.turbo_llrs_8bit(K, 2, -1.0, seed=K)
+        for nit in (1, 4, 8):
+            got = O.turbo_decode_8bit(l8, nit, K)
+            for i in range(2):
+                out = np.zeros(K // 8, np.uint8)
+                assert ref.srsran_tdec_run_all_8bit(h, O.P(l8[i].copy()), O.P(out), nit, K) == 0
                 assert np.array_equal(out, got[i])
     # CRC restatement against srsran_crc_checksum for byte-aligned and ragged lengths
     ref.srsran_crc_checksum.restype = C.c_uint32

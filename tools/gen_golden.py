@@ -8,6 +8,7 @@ No reference source text is stored.
 
   tests/golden/turbo_ref.npz   reference srsran_tdec_run_all outputs on seeded noisy LLRs; known-answer
                                K=504 message/code word; CRC32 of every QPP table the reference builds
+  tests/golden/turbo8_ref.npz  reference 8-bit turbo decoders (sse8 / avx8 window) on seeded int8 LLRs
   tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
@@ -85,6 +86,36 @@ def turbo():
     print("turbo_ref.npz", os.path.getsize(os.path.join(OUT, "turbo_ref.npz")))
 
 
+def turbo8():
+    """reference 8-bit decoders: AUTO through srsran_tdec_run_all_8bit; the manually selected sse8 / avx8 decoders
+    through srsran_tdec_run_all on int8-valued int16 LLRs (the reference's 8-bit entry point cannot run them)"""
+    d = {}
+    cases = []
+    for impl, sizes in ((0, ((40, 4), (504, 3), (816, 3), (1024, 3), (2112, 3), (6144, 3))), (6, ((816, 2), (6144, 2))),
+                        (7, ((1344, 2), (6144, 2)))):
+        h = C.create_string_buffer(64 * 1024)
+        assert ref.srsran_tdec_init_manual(h, 6144, impl) == 0
+        ref.srsran_tdec_force_not_sb(h)
+        for K, n_cb in sizes:
+            for snr, scale in ((2.0, 12.0), (-1.0, 12.0), (0.0, 60.0)):
+                _, llr = O.turbo_llrs_8bit(K, n_cb, snr, seed=K * 3 + impl + int(scale), scale=scale)
+                outs = np.zeros((8, n_cb, K // 8), np.uint8)
+                for nit in range(1, 9):
+                    for i in range(n_cb):
+                        if impl == 0:
+                            assert ref.srsran_tdec_run_all_8bit(h, P(llr[i].copy()), P(outs[nit - 1, i]), nit, K) == 0
+                        else:
+                            assert ref.srsran_tdec_run_all(h, P(llr[i].astype(np.int16)), P(outs[nit - 1, i]), nit, K) == 0
+                key = "i%d_K%d_snr%d_s%d" % (impl, K, int(snr * 10), int(scale))
+                d[key + "_llr"] = llr
+                d[key + "_out"] = outs
+                cases.append(key)
+        ref.srsran_tdec_free(h)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "turbo8_ref.npz"), **d)
+    print("turbo8_ref.npz", os.path.getsize(os.path.join(OUT, "turbo8_ref.npz")))
+
+
 class Args(C.Structure):
     _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_uint32)]
 
@@ -140,5 +171,6 @@ def ldpc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    turbo()
-    ldpc()
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc"]
+    for name in which:
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc}[name]()

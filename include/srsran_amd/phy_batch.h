@@ -79,6 +79,8 @@ SRSRAN_API uint32_t srsran_hip_ofdm_batch_sf_sz(srsran_hip_ofdm_batch_t* h);    
 SRSRAN_API uint32_t srsran_hip_ofdm_batch_sf_re(srsran_hip_ofdm_batch_t* h);    /* resource elements per subframe */
 /* rx: d_in n_sf x sf_sz time samples -> d_out n_sf x sf_re REs.  The input is NOT modified (the
  * reference multiplies in_buffer by the shift table in place, ofdm.c:455-457; here it is applied on load). */
+/* MBSFN objects (cfg.sf_type = SRSRAN_SF_MBSFN, extended CP): srsran_ofdm_set_non_mbsfn_region (ofdm.c:214), default 2 */
+SRSRAN_API int  srsran_hip_ofdm_batch_set_non_mbsfn_region(srsran_hip_ofdm_batch_t* h, uint8_t non_mbsfn_region);
 SRSRAN_API int  srsran_hip_ofdm_batch_rx(srsran_hip_ofdm_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t n_sf, void* stream);
 /* tx: d_in n_sf x sf_re REs -> d_out n_sf x sf_sz time samples */
 SRSRAN_API int  srsran_hip_ofdm_batch_tx(srsran_hip_ofdm_batch_t* h, const cf_t* d_in, cf_t* d_out, uint32_t n_sf, void* stream);

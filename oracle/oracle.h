@@ -112,6 +112,7 @@ typedef struct {
   float    freq_shift_f;
   float    rx_window_offset;
   int      keep_dc;
+  int      mbsfn_region;     /* 0: normal subframe; 1, 2: MBSFN subframe with this non-MBSFN region (needs cp_ext) */
 } orc_ofdm_cfg_t;
 
 int  orc_symbol_sz(uint32_t nof_prb);            /* phy_common.c:361-385, default (non standard) rates */

@@ -169,8 +169,41 @@ void orc_dft_c(const float* in, float* out, int n, int backward, int mirror, int
 
 typedef struct {
   int    N, nsym, cp0, cp1, nof_re, slot_sz, sf_sz, dc, win_n, shift_on;
+  int    mbsfn;      /* slot 0 is laid out by ofdm_rx_slot_mbsfn / ofdm_tx_slot_mbsfn */
+  int    mpos[6];    /* start of the useful part of each of its 6 symbols */
+  int    mcp[6];     /* and their cyclic prefix lengths */
   double norm;
 } geom_t;
+
+/* symbol positions of the MBSFN slot.  rx: ofdm.c:424-437, tx: ofdm.c:538-555 (same layout for region 1, 2) */
+static int mbsfn_layout(geom_t* g, int region, int tx)
+{
+  int N = g->N, ext = orc_cp_len(N, 512), n0 = orc_cp_len(N, 160), n1 = orc_cp_len(N, 144);
+  int guard = region == 1 ? ext - n0 : 2 * ext - n0 - n1; /* SRSRAN_NON_MBSFN_REGION_GUARD_LENGTH, phy_common.h:166 */
+  int at = 0;
+  for (int i = 0; i < 6; i++) {
+    if (!tx) {
+      if (i == region) {
+        at += guard;
+      }
+      g->mcp[i] = i >= region ? ext : (i == 0 ? n0 : n1);
+      at += g->mcp[i];
+      g->mpos[i] = at;
+      at += N;
+    } else {
+      g->mcp[i]  = i > region - 1 ? ext : (i == 0 ? n0 : n1);
+      g->mpos[i] = at + g->mcp[i];
+      at += N + g->mcp[i];
+      if (i == region - 1) {
+        at += guard;
+      }
+    }
+    if (g->mpos[i] + N > g->sf_sz) {
+      return -1;
+    }
+  }
+  return 0;
+}
 
 static int geometry(const orc_ofdm_cfg_t* cfg, geom_t* g)
 {
@@ -194,7 +227,8 @@ static int geometry(const orc_ofdm_cfg_t* cfg, geom_t* g)
     off       = off > 100 ? 100 : off;
     g->win_n  = (int)roundf((float)g->cp1 * off);
   }
-  g->norm = cfg->normalize ? (double)(1.0f / sqrtf((float)N)) : 0.0;
+  g->norm  = cfg->normalize ? (double)(1.0f / sqrtf((float)N)) : 0.0;
+  g->mbsfn = 0;
   return 0;
 }
 
@@ -219,6 +253,12 @@ int orc_ofdm_rx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out)
   if (geometry(cfg, &g) || g.nof_re > g.N - g.dc) {
     return -1;
   }
+  if (cfg->mbsfn_region) { /* ofdm.c:459-463: slot 0 = ofdm_rx_slot_mbsfn, slot 1 = the regular path */
+    if (!cfg->cp_ext || mbsfn_layout(&g, cfg->mbsfn_region, 0)) {
+      return -1;
+    }
+    g.mbsfn = 1;
+  }
   const int       N = g.N;
   float _Complex* sh = NULL;
   if (g.shift_on) {
@@ -229,7 +269,9 @@ int orc_ofdm_rx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out)
   cd* X = malloc(sizeof(cd) * N);
   for (int slot = 0; slot < 2; slot++) {
     for (int l = 0; l < g.nsym; l++) {
-      int pos = slot * g.slot_sz + g.cp0 + l * (N + g.cp1) - g.win_n; /* ofdm.c:157-166 */
+      const int special = g.mbsfn && slot == 0; /* no window offset there: plain srsran_dft_run_c, ofdm.c:432 */
+      const int win_n   = special ? 0 : g.win_n;
+      int pos = special ? g.mpos[l] : slot * g.slot_sz + g.cp0 + l * (N + g.cp1) - g.win_n; /* ofdm.c:157-166 */
       for (int n = 0; n < N; n++) {
         float _Complex s = in[2 * (pos + n)] + I * in[2 * (pos + n) + 1];
         if (sh) {
@@ -242,8 +284,8 @@ int orc_ofdm_rx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out)
       for (int k = 0; k < g.nof_re; k++) {
         int f = k < g.nof_re / 2 ? N - g.nof_re / 2 + k : g.dc + k - g.nof_re / 2; /* ofdm.c:410-411 */
         cd  v = X[f];
-        if (g.win_n) { /* ofdm.c:134-136,405-407 */
-          float _Complex r = cexpf(I * M_PI * 2.0f * (float)g.win_n * (float)f / (float)N);
+        if (win_n) { /* ofdm.c:134-136,405-407 */
+          float _Complex r = cexpf(I * M_PI * 2.0f * (float)win_n * (float)f / (float)N);
           v *= (cd)r;
         }
         if (g.norm != 0.0) {
@@ -266,6 +308,13 @@ int orc_ofdm_tx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out)
   if (geometry(cfg, &g) || g.nof_re > g.N - g.dc) {
     return -1;
   }
+  if (cfg->mbsfn_region) { /* ofdm.c:569-571.  Guard carriers of the MBSFN slot are zero here, as on the first
+                            * call of the reference (later calls leak stale scratch of slot 1 into them) */
+    if (!cfg->cp_ext || mbsfn_layout(&g, cfg->mbsfn_region, 1)) {
+      return -1;
+    }
+    g.mbsfn = 1;
+  }
   const int       N = g.N;
   float _Complex* sh = NULL;
   if (g.shift_on) {
@@ -284,8 +333,9 @@ int orc_ofdm_tx_sf(const orc_ofdm_cfg_t* cfg, const float* in, float* out)
         X[f]  = s[2 * k] + I * s[2 * k + 1];
       }
       dft_f64(X, x, N, 1);
-      int cp  = l == 0 ? g.cp0 : g.cp1;
-      int pos = slot * g.slot_sz + g.cp0 + l * (N + g.cp1);
+      const int special = g.mbsfn && slot == 0;
+      int cp  = special ? g.mcp[l] : (l == 0 ? g.cp0 : g.cp1);
+      int pos = special ? g.mpos[l] : slot * g.slot_sz + g.cp0 + l * (N + g.cp1);
       for (int n = 0; n < N; n++) {
         cd v = x[n];
         if (g.norm != 0.0) {

@@ -164,15 +164,18 @@ class OfdmBatch:
     """srsran_ofdm_rx_sf / srsran_ofdm_tx_sf over a batch of subframes (srsran_hip_ofdm_batch_*)."""
 
     def __init__(self, nof_prb, tx=False, symbol_sz=0, cp=capi.CP_NORM, normalize=False, freq_shift_f=0.0,
-                 rx_window_offset=0.0, keep_dc=False):
+                 rx_window_offset=0.0, keep_dc=False, mbsfn_region=0):
+        """mbsfn_region: 0 = normal subframes; 1, 2 = MBSFN subframes with that non-MBSFN region (needs CP_EXT)"""
         cfg = capi.OfdmCfg()
-        cfg.nof_prb, cfg.cp, cfg.sf_type = nof_prb, cp, capi.SF_NORM
+        cfg.nof_prb, cfg.cp, cfg.sf_type = nof_prb, cp, (capi.SF_MBSFN if mbsfn_region else capi.SF_NORM)
         cfg.normalize, cfg.freq_shift_f, cfg.rx_window_offset = normalize, freq_shift_f, rx_window_offset
         cfg.symbol_sz, cfg.keep_dc = symbol_sz, keep_dc
         self.tx = tx
         self._h = C.c_void_p()
         capi.check(lib().srsran_hip_ofdm_batch_create(C.byref(self._h), C.byref(cfg),
                                                       capi.DFT_BACKWARD if tx else capi.DFT_FORWARD), "ofdm_batch_create")
+        if mbsfn_region:
+            capi.check(lib().srsran_hip_ofdm_batch_set_non_mbsfn_region(self._h, mbsfn_region), "set_non_mbsfn_region")
         self.sf_sz = lib().srsran_hip_ofdm_batch_sf_sz(self._h)
         self.sf_re = lib().srsran_hip_ofdm_batch_sf_re(self._h)
 

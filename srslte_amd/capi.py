@@ -157,6 +157,7 @@ def lib():
             "srsran_hip_ofdm_batch_free": (None, [vp]),
             "srsran_hip_ofdm_batch_sf_sz": (u32, [vp]),
             "srsran_hip_ofdm_batch_sf_re": (u32, [vp]),
+            "srsran_hip_ofdm_batch_set_non_mbsfn_region": (i32, [vp, C.c_uint8]),
             "srsran_hip_ofdm_batch_rx": (i32, [vp, vp, vp, u32, vp]),
             "srsran_hip_ofdm_batch_tx": (i32, [vp, vp, vp, u32, vp]),
             "srsran_tdec_init": (i32, [C.POINTER(Tdec), u32]),

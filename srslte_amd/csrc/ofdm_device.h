@@ -24,6 +24,11 @@ struct Params {
   int         win_n; // rx: FFT window advanced by this many samples into the CP
   int         spw;   // symbols per workgroup (set by the launcher)
   float       norm;  // 1/sqrt(N), or 0 for no normalisation
+  // MBSFN subframe (ofdm.c:424-437,538-555): slot 0 holds 6 symbols at these positions / CP lengths, is
+  // processed without window offset; slot 1 is a regular extended-CP slot
+  int         mbsfn;
+  int         mpos[6];
+  int         mcp[6];
 };
 
 bool       size_supported(int n);

@@ -81,7 +81,43 @@ struct Geometry {
   bool  norm = false;
   bool  shift_on = false;
   float freq_shift = 0.f;
+  bool  mbsfn = false; // MBSFN subframe: slot 0 laid out by mbsfn_layout()
 };
+
+// symbol positions and CP lengths of the MBSFN slot; rx: ofdm.c:424-437, tx: ofdm.c:538-555.
+// Returns false when the layout does not fit the subframe (region 0 on rx, region > 6)
+bool mbsfn_layout(int N, int sf_sz, int region, bool tx, int (&pos)[6], int (&cp)[6], int* gap_start, int* gap_len)
+{
+  const int ext = cp_len(N, 512), n0 = cp_len(N, 160), n1 = cp_len(N, 144);
+  // SRSRAN_NON_MBSFN_REGION_GUARD_LENGTH, phy_common.h:166
+  const int guard = region == 1 ? ext - n0 : 2 * ext - n0 - n1;
+  int       at    = 0;
+  *gap_start = *gap_len = 0;
+  for (int i = 0; i < 6; i++) {
+    if (!tx) {
+      if (i == region) {
+        at += guard;
+      }
+      cp[i] = i >= region ? ext : (i == 0 ? n0 : n1);
+      at += cp[i];
+      pos[i] = at;
+      at += N;
+    } else {
+      cp[i]  = i > region - 1 ? ext : (i == 0 ? n0 : n1);
+      pos[i] = at + cp[i];
+      at += N + cp[i];
+      if (i == region - 1) {
+        *gap_start = at;
+        *gap_len   = guard;
+        at += guard;
+      }
+    }
+    if (pos[i] - cp[i] < 0 || pos[i] + N > sf_sz) {
+      return false;
+    }
+  }
+  return true;
+}
 
 void make_twiddles(int N, std::vector<std::complex<float>>& tw)
 {
@@ -126,6 +162,7 @@ void make_shift(const Geometry& g, cf_t* tab)
 
 struct srsran_hip_ofdm_batch {
   Geometry g;
+  int      region  = 2; // non-MBSFN region length of an MBSFN subframe (default of ofdm.c:198)
   bool     tx      = false;
   float2*  d_tw    = nullptr;
   float2*  d_shift = nullptr;
@@ -144,6 +181,10 @@ static int batch_build(srsran_hip_ofdm_batch_t** hh, const Geometry& g, bool tx,
   }
   if (g.nof_re > g.N - g.dc || g.nof_re <= 0 || (g.nof_re & 1)) {
     set_error("OFDM: nof_re=%d does not fit symbol size %d", g.nof_re, g.N);
+    return SRSRAN_ERROR;
+  }
+  if (g.mbsfn && g.nsym_slot != 6) {
+    set_error("OFDM: MBSFN subframes need the extended cyclic prefix");
     return SRSRAN_ERROR;
   }
   if (!tx && g.win_n > g.cp1) {
@@ -201,6 +242,7 @@ static int geometry_from_cfg(const srsran_ofdm_cfg_t* cfg, Geometry* g, uint32_t
     win_n     = (uint32_t)roundf((float)g->cp1 * off);
   }
   g->win_n = (int)win_n;
+  g->mbsfn = cfg->sf_type == SRSRAN_SF_MBSFN;
   if (win_n_out) {
     *win_n_out = win_n;
   }
@@ -211,10 +253,6 @@ extern "C" int srsran_hip_ofdm_batch_create(srsran_hip_ofdm_batch_t** hh, const 
 {
   if (!hh || !cfg) {
     return SRSRAN_ERROR_INVALID_INPUTS;
-  }
-  if (cfg->sf_type == SRSRAN_SF_MBSFN) {
-    set_error("OFDM: MBSFN subframes are not implemented in the HIP engine");
-    return SRSRAN_ERROR;
   }
   Geometry g;
   if (geometry_from_cfg(cfg, &g, nullptr)) {
@@ -281,7 +319,25 @@ static int batch_run(srsran_hip_ofdm_batch_t* h, const void* d_in, void* d_out, 
   p.win_n       = tx ? 0 : g.win_n;
   p.spw         = 1;
   p.norm        = g.norm ? 1.0f / sqrtf((float)g.N) : 0.0f;
+  p.mbsfn       = g.mbsfn ? 1 : 0;
+  if (g.mbsfn) {
+    int gs, gl;
+    if (!mbsfn_layout(g.N, g.sf_sz, h->region, tx, p.mpos, p.mcp, &gs, &gl)) {
+      set_error("ofdm batch: non-MBSFN region of %d symbols does not fit the subframe", h->region);
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+  }
   PHY_HIP_CHECK(ofdm::launch(p, tx, stream), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_ofdm_batch_set_non_mbsfn_region(srsran_hip_ofdm_batch_t* h, uint8_t non_mbsfn_region)
+{
+  if (!h || !h->g.mbsfn) {
+    set_error("ofdm batch: not an MBSFN object");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  h->region = non_mbsfn_region;
   return SRSRAN_SUCCESS;
 }
 
@@ -420,13 +476,12 @@ int ofdm_init_(srsran_ofdm_t* q, srsran_ofdm_cfg_t* cfg, srsran_dft_dir_t dir)
 
   q->fft_plan.mirror = true;
 
-  if (q->cfg.sf_type == SRSRAN_SF_MBSFN) {
+  if (q->cfg.sf_type == SRSRAN_SF_MBSFN) { // :196-201
     q->mbsfn_subframe   = true;
     q->non_mbsfn_region = 2;
-    fprintf(stderr, "[srsran_phy_hip] srsran_ofdm: MBSFN subframes are not implemented in the HIP engine\n");
-    return SRSRAN_ERROR;
+  } else {
+    q->mbsfn_subframe = false;
   }
-  q->mbsfn_subframe = false;
 
   // :205-209
   if (srsran_ofdm_set_freq_shift(q, q->cfg.freq_shift_f)) {
@@ -461,10 +516,12 @@ int ctx_sync(srsran_ofdm_t* q)
   g.norm       = q->fft_plan.norm;
   g.freq_shift = q->cfg.freq_shift_f;
   g.shift_on   = std::isnormal(q->cfg.freq_shift_f);
-  bool same = c->b && c->b->g.N == g.N && c->b->g.nsym_slot == g.nsym_slot && c->b->g.nof_re == g.nof_re &&
+  g.mbsfn      = q->mbsfn_subframe;
+  bool same = c->b && c->b->g.mbsfn == g.mbsfn && c->b->g.N == g.N && c->b->g.nsym_slot == g.nsym_slot && c->b->g.nof_re == g.nof_re &&
               c->b->g.dc == g.dc && c->b->g.win_n == g.win_n && c->b->g.norm == g.norm &&
               c->b->g.shift_on == g.shift_on && c->b->g.freq_shift == g.freq_shift;
   if (same) {
+    c->b->region = q->non_mbsfn_region;
     return SRSRAN_SUCCESS;
   }
   srsran_hip_ofdm_batch_free(c->b);
@@ -473,6 +530,7 @@ int ctx_sync(srsran_ofdm_t* q)
     fprintf(stderr, "[srsran_phy_hip] srsran_ofdm: %s\n", get_error());
     return SRSRAN_ERROR;
   }
+  c->b->region = q->non_mbsfn_region;
   const size_t nt = (size_t)g.sf_sz, nr = (size_t)g.nof_re * 2 * g.nsym_slot;
   if (nt > c->cap_time) {
     (void)hipFree(c->d_time);
@@ -661,6 +719,11 @@ extern "C" void srsran_ofdm_rx_sf_ng(srsran_ofdm_t* q, cf_t* input, cf_t* output
   // dc, norm) and copies &tmp[nof_guards]: same RE order and scaling as the guru path.  It moves the
   // FFT window by window_offset_n but does NOT apply the compensating phase ramp (:375-377 vs :405-407);
   // that quirk is kept.
+  if (q->mbsfn_subframe) {
+    // ofdm.c:477-480: the MBSFN branch works on the buffers given at init, whatever the arguments are
+    rx_run(q, q->cfg.in_buffer, q->cfg.out_buffer, true);
+    return;
+  }
   rx_run(q, input, output, false);
 }
 
@@ -679,5 +742,13 @@ extern "C" void srsran_ofdm_tx_sf(srsran_ofdm_t* q)
   }
   PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_time, c->d_time, nt * sizeof(cf_t), hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
-  memcpy(q->cfg.out_buffer, c->h_time, nt * sizeof(cf_t));
+  if (q->mbsfn_subframe) {
+    // the samples between the non-MBSFN and the MBSFN region are not written (ofdm.c:551-553)
+    int pos[6], cp[6], gs = 0, gl = 0;
+    mbsfn_layout((int)q->cfg.symbol_sz, (int)q->sf_sz, q->non_mbsfn_region, true, pos, cp, &gs, &gl);
+    memcpy(q->cfg.out_buffer, c->h_time, (size_t)gs * sizeof(cf_t));
+    memcpy(q->cfg.out_buffer + gs + gl, c->h_time + gs + gl, (nt - gs - gl) * sizeof(cf_t));
+  } else {
+    memcpy(q->cfg.out_buffer, c->h_time, nt * sizeof(cf_t));
+  }
 }

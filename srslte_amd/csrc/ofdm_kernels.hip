@@ -101,21 +101,29 @@ __global__ __launch_bounds__(256) void ofdm_kernel(const Params p)
   const int  l   = active ? (int)(sym - sf * p.nsym_sf) : 0;
   const int  half = p.nsym_sf >> 1;
   const int  slot = l / half, li = l - slot * half;
-  const int  pos  = slot * p.slot_sz + p.cp0 + li * (N + p.cp1); // sample index inside the subframe
-  const float2* in  = reinterpret_cast<const float2*>(p.in);
-  float2*       out = reinterpret_cast<float2*>(p.out);
-  const float2* tw  = reinterpret_cast<const float2*>(p.twiddle);
-  const float2* sh  = reinterpret_cast<const float2*>(p.shift);
+  int        pos  = slot * p.slot_sz + p.cp0 + li * (N + p.cp1); // sample index inside the subframe
+  int        cp   = li == 0 ? p.cp0 : p.cp1;
+  int        win  = p.win_n;
+  const float2* in   = reinterpret_cast<const float2*>(p.in);
+  float2*       out  = reinterpret_cast<float2*>(p.out);
+  const float2* tw   = reinterpret_cast<const float2*>(p.twiddle);
+  const float2* sh   = reinterpret_cast<const float2*>(p.shift);
+  const float2* ramp = reinterpret_cast<const float2*>(p.ramp);
+  if (p.mbsfn && slot == 0) {
+    pos  = p.mpos[li];
+    cp   = p.mcp[li];
+    win  = 0;
+    ramp = nullptr;
+  }
 
   if (!TX) {
-    const int wpos = pos - p.win_n;
+    const int wpos = pos - win;
     RxLoad    ld{in + sf * p.sf_sz + wpos, sh ? sh + wpos : nullptr};
-    RxStore   st{out + (sf * p.nsym_sf + l) * (long)p.nof_re, reinterpret_cast<const float2*>(p.ramp), p.norm, N,
-               p.nof_re >> 1, p.dc};
+    RxStore   st{out + (sf * p.nsym_sf + l) * (long)p.nof_re, win ? ramp : nullptr, p.norm, N, p.nof_re >> 1, p.dc};
     transform<P, false>(lds, tid, active, tw, ld, st);
   } else {
     TxLoad  ld{in + (sf * p.nsym_sf + l) * (long)p.nof_re, N, p.nof_re >> 1, p.dc};
-    TxStore st{out + sf * p.sf_sz + pos, sh ? sh + pos : nullptr, p.norm, N, li == 0 ? p.cp0 : p.cp1};
+    TxStore st{out + sf * p.sf_sz + pos, sh ? sh + pos : nullptr, p.norm, N, cp};
     transform<P, true>(lds, tid, active, tw, ld, st);
   }
 }

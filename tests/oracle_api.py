@@ -24,7 +24,7 @@ class LdpcGraph(C.Structure):
 
 class OfdmCfg(C.Structure):
     _fields_ = [("nof_prb", C.c_uint32), ("symbol_sz", C.c_uint32), ("cp_ext", C.c_int), ("normalize", C.c_int),
-                ("freq_shift_f", C.c_float), ("rx_window_offset", C.c_float), ("keep_dc", C.c_int)]
+                ("freq_shift_f", C.c_float), ("rx_window_offset", C.c_float), ("keep_dc", C.c_int), ("mbsfn_region", C.c_int)]
 
 
 _orc = None
@@ -173,8 +173,8 @@ def ldpc_decode(bg, ls, llrs, scaling_fctr, max_iter, cdwd_rm_length=None, crc=N
 
 
 # ------------------------------------------------------------------ OFDM helpers
-def ofdm_cfg(nof_prb, symbol_sz=0, cp_ext=0, normalize=0, freq_shift_f=0.0, rx_window_offset=0.0, keep_dc=0):
-    return OfdmCfg(nof_prb, symbol_sz, cp_ext, normalize, freq_shift_f, rx_window_offset, keep_dc)
+def ofdm_cfg(nof_prb, symbol_sz=0, cp_ext=0, normalize=0, freq_shift_f=0.0, rx_window_offset=0.0, keep_dc=0, mbsfn_region=0):
+    return OfdmCfg(nof_prb, symbol_sz, cp_ext, normalize, freq_shift_f, rx_window_offset, keep_dc, mbsfn_region)
 
 
 def ofdm_geometry(cfg):

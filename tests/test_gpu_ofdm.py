@@ -67,6 +67,74 @@ def test_loopback_all_bandwidths(hiplib, prb):
     assert np.abs(back - re).max() < 1e-4
 
 
+@pytest.mark.parametrize("prb,N,region,fs", [(6, 0, 2, 0.0), (25, 512, 1, 0.0), (100, 2048, 2, 0.0), (100, 0, 1, 0.0), (50, 1024, 2, 0.5)])
+def test_mbsfn_subframes(hiplib, prb, N, region, fs):
+    """MBSFN subframe (ofdm.c:424-437,538-555): slot 0 = `region` normal-CP symbols, a guard gap, then extended-CP
+    symbols; slot 1 a regular extended-CP slot.  Batch API against the oracle, plus the pmch_test.c loop-back."""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    cfg = O.ofdm_cfg(prb, N, 1, 1, fs, 0.0, 0, mbsfn_region=region)
+    n, nsym, sf_sz, sf_re = O.ofdm_geometry(cfg)
+    rng = np.random.default_rng(prb + region)
+    n_sf = 3
+    re = (rng.uniform(-1, 1, (n_sf, sf_re)) + 1j * rng.uniform(-1, 1, (n_sf, sf_re))).astype(np.complex64)
+    tx = S.OfdmBatch(prb, True, N, capi.CP_EXT, True, fs, mbsfn_region=region)
+    rx = S.OfdmBatch(prb, False, N, capi.CP_EXT, True, fs, mbsfn_region=region)
+    t_ref, t_gpu = O.ofdm_tx(cfg, re), tx.process(re)
+    assert _rel_err(t_gpu, t_ref) < TOL
+    # the layout differs from a plain extended-CP subframe (else this test would prove nothing)
+    assert _rel_err(t_gpu, O.ofdm_tx(O.ofdm_cfg(prb, N, 1, 1, fs, 0.0, 0), re)) > 0.1
+    x = ((rng.standard_normal((n_sf, sf_sz)) + 1j * rng.standard_normal((n_sf, sf_sz))) * 0.7).astype(np.complex64)
+    assert _rel_err(rx.process(x), O.ofdm_rx(cfg, x)) < TOL
+    if fs == 0.0:
+        assert np.abs(rx.process(t_gpu) - re).max() < 1e-4
+    # the other region on the same objects (srsran_ofdm_set_non_mbsfn_region at run time, enb_dl.c:346)
+    other = 3 - region
+    S.lib().srsran_hip_ofdm_batch_set_non_mbsfn_region(tx._h, other)
+    cfg2 = O.ofdm_cfg(prb, N, 1, 1, fs, 0.0, 0, mbsfn_region=other)
+    assert _rel_err(tx.process(re), O.ofdm_tx(cfg2, re)) < TOL
+    plain = S.OfdmBatch(prb, True, N, capi.CP_EXT, True, fs)
+    assert S.lib().srsran_hip_ofdm_batch_set_non_mbsfn_region(plain._h, 1) == capi.SRSRAN_ERROR_INVALID_INPUTS
+
+
+def test_mbsfn_handle_api(hiplib):
+    """srsran_ofdm_{tx,rx}_init_mbsfn + set_non_mbsfn_region + set_normalize, as pmch_test.c:207-225,316,347 uses them"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(8)
+    for prb, region in ((100, 2), (25, 1)):
+        ocfg = O.ofdm_cfg(prb, 0, 1, 1, 0.0, 0.0, 0, mbsfn_region=region)
+        n, nsym, sf_sz, sf_re = O.ofdm_geometry(ocfg)
+        re_in, t_out = np.zeros(sf_re, np.complex64), np.full(sf_sz, 7 + 7j, np.complex64)
+        t_in, re_out = np.zeros(sf_sz, np.complex64), np.zeros(sf_re, np.complex64)
+        ifft, fft = capi.Ofdm(), capi.Ofdm()
+        assert lib.srsran_ofdm_tx_init_mbsfn(C.byref(ifft), capi.CP_EXT, O.P(re_in), O.P(t_out), prb) == 0
+        lib.srsran_ofdm_set_non_mbsfn_region(C.byref(ifft), region)
+        lib.srsran_ofdm_set_normalize(C.byref(ifft), True)
+        assert lib.srsran_ofdm_rx_init_mbsfn(C.byref(fft), capi.CP_EXT, O.P(t_in), O.P(re_out), prb) == 0
+        lib.srsran_ofdm_set_non_mbsfn_region(C.byref(fft), region)
+        lib.srsran_ofdm_set_normalize(C.byref(fft), True)
+        assert ifft.mbsfn_subframe and ifft.non_mbsfn_region == region and ifft.nof_symbols == 6
+        re = (rng.uniform(-1, 1, sf_re) + 1j * rng.uniform(-1, 1, sf_re)).astype(np.complex64)
+        re_in[:] = re
+        lib.srsran_ofdm_tx_sf(C.byref(ifft))
+        ref = O.ofdm_tx(ocfg, re[None])[0]
+        written = np.abs(t_out - (7 + 7j)) > 0
+        # the gap between the two regions is left untouched in the caller's buffer (ofdm.c:551-553)
+        ext, n0, n1 = O.orc().orc_cp_len(n, 512), O.orc().orc_cp_len(n, 160), O.orc().orc_cp_len(n, 144)
+        gap = ext - n0 if region == 1 else 2 * ext - n0 - n1
+        assert (~written).sum() == gap
+        assert np.abs(t_out[written] - ref[written]).max() < TOL
+        t_in[:] = np.where(written, t_out, 0)
+        lib.srsran_ofdm_rx_sf(C.byref(fft))
+        assert np.abs(re_out - re).max() < 1e-4
+        lib.srsran_ofdm_tx_free(C.byref(ifft))
+        lib.srsran_ofdm_rx_free(C.byref(fft))
+
+
 def test_handle_api(hiplib):
     """srsran_ofdm_{rx,tx}_init_cfg / _sf / set_prb / free on host buffers, incl. the reference's side effects"""
     import srslte_amd as S

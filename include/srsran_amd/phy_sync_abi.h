@@ -7,8 +7,9 @@
  *   srsran_pss_* : init/resize/free/reset, generate, put/get_slot, set_N_id_2, set_ema_alpha, find_pss
  *   srsran_sss_* : init/resize/free, generate, put_slot, set_N_id_2, set_threshold, m0m1_partial / _diff /
  *                  _diff_coh, N_id_1, subframe
- * Not yet provided (srsran_sync_t glue of sync.c, PSS-based CFO / channel estimate helpers, decimation):
- * see DESIGN.md "gaps".
+ *   srsran_pss_* : + filter, filter_enable, chest, cfo_compute, sic, decimated search (pss.c:536-640, filter.c)
+ *   srsran_cexptab_*, srsran_cfo_*, srsran_cp_synch_* : the helpers srsran_sync_t is built from
+ *   srsran_sync_* : the whole of sync.h (sync.c:49-850)
  */
 #ifndef SRSRAN_AMD_PHY_SYNC_ABI_H
 #define SRSRAN_AMD_PHY_SYNC_ABI_H
@@ -101,6 +102,12 @@ SRSRAN_API void srsran_pss_set_ema_alpha(srsran_pss_t* q, float alpha);
 SRSRAN_API int  srsran_pss_set_N_id_2(srsran_pss_t* q, uint32_t N_id_2);
 /* returns the peak position; *corr_peak_value = peak / side-lobe ratio (SRSRAN_PSS_RETURN_PSR, pss.h:61) */
 SRSRAN_API int  srsran_pss_find_pss(srsran_pss_t* q, const cf_t* input, float* corr_peak_value);
+/* pss.h:122-142 */
+SRSRAN_API void  srsran_pss_filter_enable(srsran_pss_t* q, bool enable);
+SRSRAN_API void  srsran_pss_filter(srsran_pss_t* q, const cf_t* input, cf_t* output);
+SRSRAN_API int   srsran_pss_chest(srsran_pss_t* q, const cf_t* input, cf_t ce[SRSRAN_PSS_LEN]);
+SRSRAN_API float srsran_pss_cfo_compute(srsran_pss_t* q, const cf_t* pss_recv);
+SRSRAN_API void  srsran_pss_sic(srsran_pss_t* q, cf_t* input);
 
 /* sss.h:44-82 */
 typedef struct SRSRAN_API {
@@ -142,6 +149,168 @@ SRSRAN_API int      srsran_sss_m0m1_diff_coh(srsran_sss_t* q, const cf_t* input,
 SRSRAN_API int      srsran_sss_m0m1_diff(srsran_sss_t* q, const cf_t* input, uint32_t* m0, float* m0_value, uint32_t* m1, float* m1_value);
 SRSRAN_API uint32_t srsran_sss_subframe(uint32_t m0, uint32_t m1);
 SRSRAN_API int      srsran_sss_N_id_1(srsran_sss_t* q, uint32_t m0, uint32_t m1, float corr);
+
+/* ---- utils/cexptab.h:36-49 ---- */
+typedef struct SRSRAN_API {
+  uint32_t size;
+  cf_t*    tab;
+} srsran_cexptab_t;
+
+SRSRAN_API int  srsran_cexptab_init(srsran_cexptab_t* nco, uint32_t size);
+SRSRAN_API void srsran_cexptab_free(srsran_cexptab_t* nco);
+SRSRAN_API void srsran_cexptab_gen(srsran_cexptab_t* nco, cf_t* x, float freq, uint32_t len);
+SRSRAN_API void srsran_cexptab_gen_direct(cf_t* x, float freq, uint32_t len);
+SRSRAN_API void srsran_cexptab_gen_sf(cf_t* x, float freq, uint32_t fft_size);
+
+/* ---- sync/cfo.h:31-60 ---- */
+#define SRSRAN_CFO_CEXPTAB_SIZE 4096
+
+typedef struct SRSRAN_API {
+  float            last_freq;
+  float            tol;
+  int              nsamples;
+  int              max_samples;
+  srsran_cexptab_t tab;
+  cf_t*            cur_cexp;
+} srsran_cfo_t;
+
+SRSRAN_API int  srsran_cfo_init(srsran_cfo_t* h, uint32_t nsamples);
+SRSRAN_API void srsran_cfo_free(srsran_cfo_t* h);
+SRSRAN_API int  srsran_cfo_resize(srsran_cfo_t* h, uint32_t samples);
+SRSRAN_API void srsran_cfo_set_tol(srsran_cfo_t* h, float tol);
+SRSRAN_API void srsran_cfo_correct(srsran_cfo_t* h, const cf_t* input, cf_t* output, float freq);
+SRSRAN_API void srsran_cfo_correct_offset(srsran_cfo_t* h, const cf_t* input, cf_t* output, float freq, int cexp_offset, int nsamples);
+
+/* ---- sync/cp.h:30-48 ---- */
+typedef struct {
+  cf_t*    corr;
+  uint32_t symbol_sz;
+  uint32_t max_symbol_sz;
+} srsran_cp_synch_t;
+
+SRSRAN_API int      srsran_cp_synch_init(srsran_cp_synch_t* q, uint32_t symbol_sz);
+SRSRAN_API void     srsran_cp_synch_free(srsran_cp_synch_t* q);
+SRSRAN_API int      srsran_cp_synch_resize(srsran_cp_synch_t* q, uint32_t symbol_sz);
+SRSRAN_API uint32_t srsran_cp_synch(srsran_cp_synch_t* q, const cf_t* input, uint32_t max_offset, uint32_t nof_symbols, uint32_t cp_len);
+SRSRAN_API cf_t     srsran_cp_synch_corr_output(srsran_cp_synch_t* q, uint32_t offset);
+
+/* ---- sync/sync.h:50-228 ---- */
+#define SRSRAN_SYNC_FFT_SZ_MIN 64
+#define SRSRAN_SYNC_FFT_SZ_MAX 2048
+
+typedef enum { SRSRAN_FDD = 0, SRSRAN_TDD = 1 } srsran_frame_type_t; /* phy_common.h:193-197 */
+typedef enum { SSS_DIFF = 0, SSS_PARTIAL_3 = 2, SSS_FULL = 1 } sss_alg_t;
+
+typedef struct SRSRAN_API {
+  srsran_pss_t      pss;
+  srsran_pss_t      pss_i[2];
+  srsran_sss_t      sss;
+  srsran_cp_synch_t cp_synch;
+  cf_t*             cfo_i_corr[2];
+  int               decimate;
+  float             threshold;
+  float             peak_value;
+  uint32_t          N_id_2;
+  uint32_t          N_id_1;
+  uint32_t          sf_idx;
+  uint32_t          fft_size;
+  uint32_t          frame_size;
+  uint32_t          max_offset;
+  uint32_t          nof_symbols;
+  uint32_t          cp_len;
+  float             current_cfo_tol;
+  sss_alg_t         sss_alg;
+  bool              detect_cp;
+  bool              sss_en;
+  srsran_cp_t       cp;
+  uint32_t          m0;
+  uint32_t          m1;
+  float             m0_value;
+  float             m1_value;
+  float             M_norm_avg;
+  float             M_ext_avg;
+  cf_t*             temp;
+
+  uint32_t max_frame_size;
+
+  srsran_frame_type_t frame_type;
+  bool                detect_frame_type;
+
+  bool cfo_cp_enable;
+  bool cfo_pss_enable;
+  bool cfo_i_enable;
+
+  bool cfo_cp_is_set;
+  bool cfo_pss_is_set;
+  bool cfo_i_initiated;
+
+  float cfo_cp_mean;
+  float cfo_pss;
+  float cfo_pss_mean;
+  int   cfo_i_value;
+
+  float cfo_ema_alpha;
+
+  uint32_t cfo_cp_nsymbols;
+
+  srsran_cfo_t cfo_corr_frame;
+  srsran_cfo_t cfo_corr_symbol;
+
+  bool sss_channel_equalize;
+  bool pss_filtering_enabled;
+  cf_t sss_filt[SRSRAN_SYMBOL_SZ_MAX];
+  cf_t pss_filt[SRSRAN_SYMBOL_SZ_MAX];
+
+  bool              sss_generated;
+  bool              sss_detected;
+  bool              sss_available;
+  float             sss_corr;
+  srsran_dft_plan_t idftp_sss;
+  cf_t              sss_recv[SRSRAN_SYMBOL_SZ_MAX];
+  cf_t              sss_signal[2][SRSRAN_SYMBOL_SZ_MAX];
+} srsran_sync_t;
+
+typedef enum {
+  SRSRAN_SYNC_FOUND         = 1,
+  SRSRAN_SYNC_FOUND_NOSPACE = 2,
+  SRSRAN_SYNC_NOFOUND       = 0,
+  SRSRAN_SYNC_ERROR         = -1
+} srsran_sync_find_ret_t;
+
+SRSRAN_API int  srsran_sync_init(srsran_sync_t* q, uint32_t frame_size, uint32_t max_offset, uint32_t fft_size);
+SRSRAN_API int  srsran_sync_init_decim(srsran_sync_t* q, uint32_t frame_size, uint32_t max_offset, uint32_t fft_size, int decimate);
+SRSRAN_API void srsran_sync_free(srsran_sync_t* q);
+SRSRAN_API int  srsran_sync_resize(srsran_sync_t* q, uint32_t frame_size, uint32_t max_offset, uint32_t fft_size);
+SRSRAN_API void srsran_sync_reset(srsran_sync_t* q);
+SRSRAN_API srsran_sync_find_ret_t srsran_sync_find(srsran_sync_t* q, const cf_t* input, uint32_t find_offset, uint32_t* peak_position);
+SRSRAN_API srsran_cp_t srsran_sync_detect_cp(srsran_sync_t* q, const cf_t* input, uint32_t peak_pos);
+SRSRAN_API void     srsran_sync_set_threshold(srsran_sync_t* q, float threshold);
+SRSRAN_API uint32_t srsran_sync_get_sf_idx(srsran_sync_t* q);
+SRSRAN_API float    srsran_sync_get_peak_value(srsran_sync_t* q);
+SRSRAN_API void     srsran_sync_set_sss_algorithm(srsran_sync_t* q, sss_alg_t alg);
+SRSRAN_API void     srsran_sync_set_em_alpha(srsran_sync_t* q, float alpha);
+SRSRAN_API int      srsran_sync_set_N_id_2(srsran_sync_t* q, uint32_t N_id_2);
+SRSRAN_API int      srsran_sync_set_N_id_1(srsran_sync_t* q, uint32_t N_id_1);
+SRSRAN_API int      srsran_sync_get_cell_id(srsran_sync_t* q);
+SRSRAN_API void     srsran_sync_set_pss_filt_enable(srsran_sync_t* q, bool enable);
+SRSRAN_API void     srsran_sync_set_sss_eq_enable(srsran_sync_t* q, bool enable);
+SRSRAN_API float    srsran_sync_get_cfo(srsran_sync_t* q);
+SRSRAN_API void     srsran_sync_cfo_reset(srsran_sync_t* q, float cfo_Hz);
+SRSRAN_API void     srsran_sync_copy_cfo(srsran_sync_t* q, srsran_sync_t* src_obj);
+SRSRAN_API void     srsran_sync_set_cfo_i_enable(srsran_sync_t* q, bool enable);
+SRSRAN_API void     srsran_sync_set_cfo_cp_enable(srsran_sync_t* q, bool enable, uint32_t nof_symbols);
+SRSRAN_API void     srsran_sync_set_cfo_pss_enable(srsran_sync_t* q, bool enable);
+SRSRAN_API void     srsran_sync_set_cfo_tol(srsran_sync_t* q, float tol);
+SRSRAN_API void     srsran_sync_set_frame_type(srsran_sync_t* q, srsran_frame_type_t frame_type);
+SRSRAN_API void     srsran_sync_set_cfo_ema_alpha(srsran_sync_t* q, float alpha);
+SRSRAN_API srsran_cp_t srsran_sync_get_cp(srsran_sync_t* q);
+SRSRAN_API void     srsran_sync_set_cp(srsran_sync_t* q, srsran_cp_t cp);
+SRSRAN_API void     srsran_sync_sss_en(srsran_sync_t* q, bool enabled);
+SRSRAN_API srsran_pss_t* srsran_sync_get_cur_pss_obj(srsran_sync_t* q);
+SRSRAN_API bool     srsran_sync_sss_detected(srsran_sync_t* q);
+SRSRAN_API float    srsran_sync_sss_correlation_peak(srsran_sync_t* q);
+SRSRAN_API bool     srsran_sync_sss_available(srsran_sync_t* q);
+SRSRAN_API void     srsran_sync_cp_en(srsran_sync_t* q, bool enabled);
 
 /* ------------------------------------------------------------------------------------------------
  * Batched cell search on device-resident captures: for every capture and every N_id_2 hypothesis, what

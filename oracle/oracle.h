@@ -145,6 +145,15 @@ int  orc_sss_m0m1_partial(const float* sss_symbol, uint32_t fft_size, uint32_t N
 int  orc_sss_m0m1(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, uint32_t M, uint32_t* m0,
                   float* m0_value, uint32_t* m1, float* m1_value, int* n_id_1, int* sf_idx);
 
+/* helpers behind srsran_sync_find: cexptab.c / cfo.c:101-113 / cp.c:60-79 / pss.c:590-640 / sync.c:451-508.
+ * cfo + cp_synch are pinned against oracle/_ref (those files build without FFTW) */
+void     orc_cexptab_gen(float* x, float freq, uint32_t len);
+void     orc_cfo_correct(const float* in, float* out, float freq, uint32_t n);
+uint32_t orc_cp_synch(const float* in, uint32_t N, uint32_t max_offset, uint32_t nof_symbols, uint32_t cp_len, float* corr);
+int      orc_pss_filter(const float* in, float* out, uint32_t N, uint32_t N_id_2, float* ce);
+float    orc_pss_cfo_compute(const float* pss_recv, uint32_t N, uint32_t N_id_2);
+int      orc_detect_cp(const float* in, uint32_t peak_pos, uint32_t N, float* m);
+
 #ifdef __cplusplus
 }
 #endif

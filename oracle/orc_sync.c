@@ -107,7 +107,7 @@ static float peak_sidelobe(const float* avg, uint32_t corr_peak_pos, uint32_t co
 int orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, uint32_t N_id_2, float* corr_out,
                  float* peak_value, float* psr)
 {
-  if (N_id_2 > 2 || fft_size > 2048 || frame_size < fft_size) {
+  if (N_id_2 > 2 || fft_size > 2048 || frame_size < 2) {
     return -1;
   }
   const uint32_t L = frame_size + fft_size; /* convolution.c:34-36 */
@@ -115,6 +115,34 @@ int orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, uin
   if (pss_time_replica(h, N_id_2, fft_size, 0)) {
     free(h);
     return -1;
+  }
+  if (frame_size < fft_size) {
+    /* pss.c:476-481: sliding dot product conv[i] = sum_n h[n] x[i+n] (input must hold frame_size+fft_size-1
+     * samples), conv_output_len = frame_size; the returned index is peak + fft_size (pss.c:530) */
+    float* avg = calloc(frame_size + 2, sizeof(float));
+    for (uint32_t i = 0; i + 1 < frame_size; i++) {
+      double re = 0, im = 0;
+      for (uint32_t n = 0; n < fft_size; n++) {
+        double hr = h[2 * n], hi = h[2 * n + 1];
+        double xr = input[2 * (i + n)], xi = input[2 * (i + n) + 1];
+        re += hr * xr - hi * xi;
+        im += hr * xi + hi * xr;
+      }
+      avg[i] = (float)(re * re + im * im);
+    }
+    uint32_t peak = max_fi(avg, frame_size - 1);
+    if (peak_value) {
+      *peak_value = avg[peak];
+    }
+    if (psr) {
+      *psr = peak_sidelobe(avg, peak, frame_size);
+    }
+    if (corr_out) {
+      memcpy(corr_out, avg, sizeof(float) * (frame_size - 1));
+    }
+    free(avg);
+    free(h);
+    return (int)peak + (int)fft_size;
   }
   /* out[i] = sum_n h[n] x[i-n]  (the FFT convolution of length L is exactly this linear convolution) */
   float* avg = calloc(L + 2, sizeof(float));
@@ -306,4 +334,185 @@ int orc_sss_m0m1(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, ui
     *n_id_1 = found;
   }
   return 0;
+}
+
+/* ------------------------------------------------------------------ helpers behind srsran_sync_find */
+
+/* cexptab.c:32-46,56-74 with SRSRAN_CFO_CEXPTAB_SIZE = 4096 (cfo.h:33): table look-up with a float phase
+ * accumulator.  x: len cf */
+void orc_cexptab_gen(float* x, float freq, uint32_t len)
+{
+  const uint32_t  size = 4096;
+  float _Complex* tab  = malloc(sizeof(float _Complex) * size);
+  for (uint32_t i = 0; i < size; i++) {
+    tab[i] = cexpf(_Complex_I * 2 * M_PI * (float)i / size);
+  }
+  float phase_inc = freq * size;
+  float phase     = 0;
+  for (uint32_t i = 0; i < len; i++) {
+    while (phase >= (float)size) {
+      phase -= (float)size;
+    }
+    while (phase < 0) {
+      phase += (float)size;
+    }
+    uint32_t idx = (uint32_t)phase;
+    x[2 * i]     = crealf(tab[idx]);
+    x[2 * i + 1] = cimagf(tab[idx]);
+    phase += phase_inc;
+  }
+  free(tab);
+}
+
+/* srsran_cfo_correct (cfo.c:97-111).  The reference is built with SRSRAN_CFO_USE_EXP_TABLE 0 (cfo.c:33), i.e. it is
+ * srsran_vec_apply_cfo (vector_simd.c:1692-1739, AVX2 + FMA): eight recursive float oscillators for samples 8m+k
+ * and a scalar one for the last n % 8 samples */
+void orc_cfo_correct(const float* in, float* out, float freq, uint32_t n)
+{
+  const float TWOPI = 2.0f * (float)M_PI;
+  uint32_t    i     = 0;
+  if (n >= 8) {
+    float pr[8], pi[8];
+    float or8 = crealf(cexpf(_Complex_I * TWOPI * freq * 8)), oi8 = cimagf(cexpf(_Complex_I * TWOPI * freq * 8));
+    for (int k = 0; k < 8; k++) {
+      float _Complex p = cexpf(_Complex_I * TWOPI * freq * k);
+      pr[k] = crealf(p);
+      pi[k] = cimagf(p);
+    }
+    for (; i + 8 <= n; i += 8) {
+      for (int k = 0; k < 8; k++) {
+        float ar = in[2 * (i + k)], ai = in[2 * (i + k) + 1];
+        out[2 * (i + k)]     = fmaf(ar, pr[k], -(ai * pi[k])); /* srsran_simd_cf_prod with LV_HAVE_FMA, simd.h:899-901 */
+        out[2 * (i + k) + 1] = fmaf(ar, pi[k], ai * pr[k]);
+        float nr = fmaf(pr[k], or8, -(pi[k] * oi8));
+        float ni = fmaf(pr[k], oi8, pi[k] * or8);
+        pr[k] = nr;
+        pi[k] = ni;
+      }
+    }
+  }
+  float _Complex osc   = cexpf(_Complex_I * TWOPI * freq);
+  float _Complex phase = cexpf(_Complex_I * TWOPI * freq * i);
+  for (; i < n; i++) {
+    float ar = in[2 * i], ai = in[2 * i + 1], pr = crealf(phase), pi = cimagf(phase);
+    out[2 * i]     = ar * pr - ai * pi;
+    out[2 * i + 1] = ar * pi + ai * pr;
+    phase = (pr * crealf(osc) - pi * cimagf(osc)) + I * (pr * cimagf(osc) + pi * crealf(osc));
+  }
+}
+
+/* srsran_cp_synch (cp.c:60-79): corr (max_offset cf, clipped to N) and the arg-max of |corr| */
+uint32_t orc_cp_synch(const float* in, uint32_t N, uint32_t max_offset, uint32_t nof_symbols, uint32_t cp_len, float* corr)
+{
+  if (max_offset > N) {
+    max_offset = N;
+  }
+  uint32_t best = 0;
+  float    bm   = -1;
+  for (uint32_t i = 0; i < max_offset; i++) {
+    float _Complex c   = 0;
+    const float*   ptr = in;
+    for (uint32_t n = 0; n < nof_symbols; n++) {
+      uint32_t       cplen = (n % 7) ? cp_len : cp_len + 1;
+      float _Complex d     = 0;
+      for (uint32_t k = 0; k < cplen; k++) {
+        float _Complex x = ptr[2 * (i + k)] + I * ptr[2 * (i + k) + 1];
+        float _Complex y = ptr[2 * (i + k + N)] + I * ptr[2 * (i + k + N) + 1];
+        d += x * conjf(y);
+      }
+      c += d / nof_symbols;
+      ptr += 2 * (N + cplen);
+    }
+    corr[2 * i]     = crealf(c);
+    corr[2 * i + 1] = cimagf(c);
+    float m         = crealf(c) * crealf(c) + cimagf(c) * cimagf(c);
+    if (m > bm) {
+      bm   = m;
+      best = i;
+    }
+  }
+  return best;
+}
+
+/* srsran_pss_filter (pss.c:590-604): DFT (mirror, dc), keep the 62 central bins, IDFT (mirror, dc), both
+ * unnormalised.  ce (optional, 62 cf): the channel estimate taken on the way (chest_on_filter) */
+int orc_pss_filter(const float* in, float* out, uint32_t N, uint32_t N_id_2, float* ce)
+{
+  float zc[2 * PSS_LEN];
+  if (orc_pss_generate(zc, N_id_2)) {
+    return -1;
+  }
+  float* f  = malloc(sizeof(float) * 2 * N);
+  float* f2 = calloc(2 * (size_t)N, sizeof(float));
+  orc_dft_c(in, f, (int)N, 0, 1, 1, 0);
+  memcpy(&f2[2 * (N / 2 - PSS_LEN / 2)], &f[2 * (N / 2 - PSS_LEN / 2)], sizeof(float) * 2 * PSS_LEN);
+  if (ce) {
+    for (int i = 0; i < PSS_LEN; i++) {
+      float _Complex a = f[2 * ((N - PSS_LEN) / 2 + i)] + I * f[2 * ((N - PSS_LEN) / 2 + i) + 1];
+      float _Complex v = a * conjf(zc[2 * i] + I * zc[2 * i + 1]);
+      ce[2 * i]        = crealf(v);
+      ce[2 * i + 1]    = cimagf(v);
+    }
+  }
+  orc_dft_c(f2, out, (int)N, 1, 1, 1, 0);
+  free(f);
+  free(f2);
+  return 0;
+}
+
+/* srsran_pss_cfo_compute (pss.c:611-640) without the optional filter */
+float orc_pss_cfo_compute(const float* pss_recv, uint32_t N, uint32_t N_id_2)
+{
+  float* h = malloc(sizeof(float) * 2 * N);
+  if (pss_time_replica(h, N_id_2, N, 0)) {
+    free(h);
+    return 0;
+  }
+  float _Complex y0 = 0, y1 = 0;
+  for (uint32_t i = 0; i < N / 2; i++) {
+    y0 += (h[2 * i] + I * h[2 * i + 1]) * (pss_recv[2 * i] + I * pss_recv[2 * i + 1]);
+    uint32_t j = i + N / 2;
+    y1 += (h[2 * j] + I * h[2 * j + 1]) * (pss_recv[2 * j] + I * pss_recv[2 * j + 1]);
+  }
+  free(h);
+  return cargf(conjf(y0) * y1) / M_PI;
+}
+
+/* srsran_sync_detect_cp (sync.c:451-508) on a fresh object (averages start at 0, CP_EMA_ALPHA 0.1):
+ * returns 0 normal / 1 extended; m[0], m[1] receive M_norm_avg, M_ext_avg */
+int orc_detect_cp(const float* in, uint32_t peak_pos, uint32_t N, float* m)
+{
+  uint32_t len[2] = {(uint32_t)orc_cp_len(N, 144), (uint32_t)orc_cp_len(N, 512)};
+  uint32_t nsym   = peak_pos / (N + len[1]);
+  if (nsym > 3) {
+    nsym = 3;
+  }
+  m[0] = m[1] = 0;
+  if (nsym == 0) {
+    return 0;
+  }
+  float R[2] = {0, 0}, C[2] = {0, 0};
+  for (int h = 0; h < 2; h++) {
+    const float* p = &in[2 * (peak_pos - nsym * (N + len[h]))];
+    for (uint32_t s = 0; s < nsym; s++) {
+      float _Complex d  = 0;
+      float          pw = 0;
+      for (uint32_t k = 0; k < len[h]; k++) {
+        float _Complex a = p[2 * (N + k)] + I * p[2 * (N + k) + 1], b = p[2 * k] + I * p[2 * k + 1];
+        d += a * conjf(b);
+        pw += crealf(b) * crealf(b) + cimagf(b) * cimagf(b);
+      }
+      R[h] += crealf(d);
+      C[h] += len[h] * (pw / len[h]);
+      p += 2 * (N + len[h]);
+    }
+    float M = C[h] > 0 ? R[h] / C[h] : 0;
+    m[h]    = 0.1f * (M / nsym) + (1 - 0.1f) * 0;
+  }
+  if (m[0] > m[1]) {
+    return 0;
+  } else if (m[0] < m[1]) {
+    return 1;
+  }
+  return R[0] > R[1] ? 0 : 1;
 }

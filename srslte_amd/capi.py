@@ -67,6 +67,43 @@ class Sss(C.Structure):
                 ("fc_tables", SssFcTables * 3), ("corr_output_m0", C.c_float * 31), ("corr_output_m1", C.c_float * 31)]
 
 
+class Cexptab(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("tab", C.c_void_p)]
+
+
+class Cfo(C.Structure):
+    _fields_ = [("last_freq", C.c_float), ("tol", C.c_float), ("nsamples", C.c_int), ("max_samples", C.c_int), ("tab", Cexptab),
+                ("cur_cexp", C.c_void_p)]
+
+
+class CpSynch(C.Structure):
+    _fields_ = [("corr", C.c_void_p), ("symbol_sz", C.c_uint32), ("max_symbol_sz", C.c_uint32)]
+
+
+class Sync(C.Structure):
+    """srsran_sync_t (sync.h:50-133)"""
+    _fields_ = [("pss", Pss), ("pss_i", Pss * 2), ("sss", Sss), ("cp_synch", CpSynch), ("cfo_i_corr", C.c_void_p * 2),
+                ("decimate", C.c_int), ("threshold", C.c_float), ("peak_value", C.c_float), ("N_id_2", C.c_uint32),
+                ("N_id_1", C.c_uint32), ("sf_idx", C.c_uint32), ("fft_size", C.c_uint32), ("frame_size", C.c_uint32),
+                ("max_offset", C.c_uint32), ("nof_symbols", C.c_uint32), ("cp_len", C.c_uint32), ("current_cfo_tol", C.c_float),
+                ("sss_alg", C.c_int), ("detect_cp", C.c_bool), ("sss_en", C.c_bool), ("cp", C.c_int), ("m0", C.c_uint32),
+                ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("M_norm_avg", C.c_float),
+                ("M_ext_avg", C.c_float), ("temp", C.c_void_p), ("max_frame_size", C.c_uint32), ("frame_type", C.c_int),
+                ("detect_frame_type", C.c_bool), ("cfo_cp_enable", C.c_bool), ("cfo_pss_enable", C.c_bool),
+                ("cfo_i_enable", C.c_bool), ("cfo_cp_is_set", C.c_bool), ("cfo_pss_is_set", C.c_bool),
+                ("cfo_i_initiated", C.c_bool), ("cfo_cp_mean", C.c_float), ("cfo_pss", C.c_float), ("cfo_pss_mean", C.c_float),
+                ("cfo_i_value", C.c_int), ("cfo_ema_alpha", C.c_float), ("cfo_cp_nsymbols", C.c_uint32),
+                ("cfo_corr_frame", Cfo), ("cfo_corr_symbol", Cfo), ("sss_channel_equalize", C.c_bool),
+                ("pss_filtering_enabled", C.c_bool), ("sss_filt", C.c_float * 4096), ("pss_filt", C.c_float * 4096),
+                ("sss_generated", C.c_bool), ("sss_detected", C.c_bool), ("sss_available", C.c_bool), ("sss_corr", C.c_float),
+                ("idftp_sss", DftPlan), ("sss_recv", C.c_float * 4096), ("sss_signal", (C.c_float * 4096) * 2)]
+
+
+SYNC_FOUND, SYNC_FOUND_NOSPACE, SYNC_NOFOUND, SYNC_ERROR = 1, 2, 0, -1
+SSS_DIFF, SSS_FULL, SSS_PARTIAL_3 = 0, 1, 2
+FDD, TDD = 0, 1
+
+
 class HipCell(C.Structure):
     _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
                 ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
@@ -242,6 +279,55 @@ def lib():
             "srsran_sss_m0m1_diff_coh": (i32, [C.POINTER(Sss), vp, vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(C.c_float)]),
             "srsran_sss_subframe": (u32, [u32, u32]),
             "srsran_sss_N_id_1": (i32, [C.POINTER(Sss), u32, u32, C.c_float]),
+            "srsran_pss_filter_enable": (None, [C.POINTER(Pss), C.c_bool]),
+            "srsran_pss_filter": (None, [C.POINTER(Pss), vp, vp]),
+            "srsran_pss_chest": (i32, [C.POINTER(Pss), vp, vp]),
+            "srsran_pss_cfo_compute": (C.c_float, [C.POINTER(Pss), vp]),
+            "srsran_pss_sic": (None, [C.POINTER(Pss), vp]),
+            "srsran_cfo_init": (i32, [C.POINTER(Cfo), u32]),
+            "srsran_cfo_free": (None, [C.POINTER(Cfo)]),
+            "srsran_cfo_resize": (i32, [C.POINTER(Cfo), u32]),
+            "srsran_cfo_set_tol": (None, [C.POINTER(Cfo), C.c_float]),
+            "srsran_cfo_correct": (None, [C.POINTER(Cfo), vp, vp, C.c_float]),
+            "srsran_cfo_correct_offset": (None, [C.POINTER(Cfo), vp, vp, C.c_float, i32, i32]),
+            "srsran_cp_synch_init": (i32, [C.POINTER(CpSynch), u32]),
+            "srsran_cp_synch_free": (None, [C.POINTER(CpSynch)]),
+            "srsran_cp_synch_resize": (i32, [C.POINTER(CpSynch), u32]),
+            "srsran_cp_synch": (u32, [C.POINTER(CpSynch), vp, u32, u32, u32]),
+            "srsran_sync_init": (i32, [C.POINTER(Sync), u32, u32, u32]),
+            "srsran_sync_init_decim": (i32, [C.POINTER(Sync), u32, u32, u32, i32]),
+            "srsran_sync_free": (None, [C.POINTER(Sync)]),
+            "srsran_sync_resize": (i32, [C.POINTER(Sync), u32, u32, u32]),
+            "srsran_sync_reset": (None, [C.POINTER(Sync)]),
+            "srsran_sync_find": (i32, [C.POINTER(Sync), vp, u32, C.POINTER(u32)]),
+            "srsran_sync_detect_cp": (i32, [C.POINTER(Sync), vp, u32]),
+            "srsran_sync_set_threshold": (None, [C.POINTER(Sync), C.c_float]),
+            "srsran_sync_get_sf_idx": (u32, [C.POINTER(Sync)]),
+            "srsran_sync_get_peak_value": (C.c_float, [C.POINTER(Sync)]),
+            "srsran_sync_set_sss_algorithm": (None, [C.POINTER(Sync), i32]),
+            "srsran_sync_set_em_alpha": (None, [C.POINTER(Sync), C.c_float]),
+            "srsran_sync_set_N_id_2": (i32, [C.POINTER(Sync), u32]),
+            "srsran_sync_set_N_id_1": (i32, [C.POINTER(Sync), u32]),
+            "srsran_sync_get_cell_id": (i32, [C.POINTER(Sync)]),
+            "srsran_sync_set_pss_filt_enable": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_sync_set_sss_eq_enable": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_sync_get_cfo": (C.c_float, [C.POINTER(Sync)]),
+            "srsran_sync_cfo_reset": (None, [C.POINTER(Sync), C.c_float]),
+            "srsran_sync_copy_cfo": (None, [C.POINTER(Sync), C.POINTER(Sync)]),
+            "srsran_sync_set_cfo_i_enable": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_sync_set_cfo_cp_enable": (None, [C.POINTER(Sync), C.c_bool, u32]),
+            "srsran_sync_set_cfo_pss_enable": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_sync_set_cfo_tol": (None, [C.POINTER(Sync), C.c_float]),
+            "srsran_sync_set_frame_type": (None, [C.POINTER(Sync), i32]),
+            "srsran_sync_set_cfo_ema_alpha": (None, [C.POINTER(Sync), C.c_float]),
+            "srsran_sync_get_cp": (i32, [C.POINTER(Sync)]),
+            "srsran_sync_set_cp": (None, [C.POINTER(Sync), i32]),
+            "srsran_sync_sss_en": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_sync_get_cur_pss_obj": (C.POINTER(Pss), [C.POINTER(Sync)]),
+            "srsran_sync_sss_detected": (C.c_bool, [C.POINTER(Sync)]),
+            "srsran_sync_sss_correlation_peak": (C.c_float, [C.POINTER(Sync)]),
+            "srsran_sync_sss_available": (C.c_bool, [C.POINTER(Sync)]),
+            "srsran_sync_cp_en": (None, [C.POINTER(Sync), C.c_bool]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
             "srsran_hip_cellsearch_free": (None, [vp]),
             "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),

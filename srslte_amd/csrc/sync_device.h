@@ -69,9 +69,32 @@ struct CellResult { // == srsran_hip_cell_t (phy_sync_abi.h)
   uint32_t sf_idx;
 };
 
+// ---- helpers of the srsran_sync_t glue
+enum { DOT_PLAIN = 0, DOT_CONJ = 1, DOT_POWER = 2 }; // sum a*b | sum a*conj(b) | mean |a|^2
+struct DotJobs {
+  const void* a[8];
+  const void* b[8];
+  int         n[8];
+  int         mode[8];
+  int         count;
+};
+hipError_t launch_cmul(const void* a, const void* b, void* out, int n, bool conj_b, hipStream_t stream);
+hipError_t launch_lincomb(const void* a, float sa, const void* b, float sb, void* out, int n, hipStream_t stream);
+hipError_t launch_dots(const DotJobs& jobs, void* d_out, hipStream_t stream); // d_out: count x cf
+hipError_t launch_cp_synch(const void* in, void* corr, int max_offset, int nof_symbols, int cp_len, int N, int* d_argmax, hipStream_t stream);
+struct CfoSeeds { // start phases of the oscillators of srsran_vec_apply_cfo, evaluated on the host with cexpf
+  float phase_re[8], phase_im[8];
+  float osc8_re, osc8_im;
+  float tail_re, tail_im;
+  float osc1_re, osc1_im;
+};
+hipError_t launch_apply_cfo(const void* x, void* z, int len, const CfoSeeds& seeds, hipStream_t stream);
+hipError_t launch_decim(const void* in, void* out, int n_out, int M, const float* taps4, hipStream_t stream);
+
 hipError_t launch_pack(const PssResult* a, const SssResult* b, CellResult* out, int n, hipStream_t stream);
 hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream);
 hipError_t launch_sss(const SssParams& p, const PssResult* d_pss, SssResult* d_res, hipStream_t stream);
+hipError_t launch_pss_direct(const PssParams& p, const void* d_replica, PssResult* d_res, hipStream_t stream);
 
 } // namespace sync
 } // namespace phyhip

@@ -6,6 +6,7 @@
 #include "hip_common.h"
 #include "srsran_amd/phy_sync_abi.h"
 #include "sync_device.h"
+#include "sync_glue.h"
 
 #include <cmath>
 #include <complex>
@@ -139,6 +140,8 @@ struct PssEngine {
   size_t   corr_stride = 0;
   float2*  d_tw = nullptr;
   float2*  d_filt = nullptr;
+  float2*  d_rep  = nullptr; // direct mode (frame_size < fft_size): the three time replicas
+  bool     direct = false;
   float*   d_corr = nullptr;
   float*   d_part_val = nullptr;
   int*     d_part_idx = nullptr;
@@ -154,6 +157,7 @@ void pss_engine_free(PssEngine* e)
   }
   (void)hipFree(e->d_tw);
   (void)hipFree(e->d_filt);
+  (void)hipFree(e->d_rep);
   (void)hipFree(e->d_corr);
   (void)hipFree(e->d_part_val);
   (void)hipFree(e->d_part_idx);
@@ -166,17 +170,18 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
   if (!device_available()) {
     return nullptr;
   }
-  if (fft_size > 2048 || fft_size < 64 || frame_size < fft_size) {
-    set_error("PSS: unsupported sizes frame=%u fft=%u (fft <= 2048, frame >= fft)", frame_size, fft_size);
+  if (fft_size > 2048 || fft_size < 64 || frame_size < 2) {
+    set_error("PSS: unsupported sizes frame=%u fft=%u (64 <= fft <= 2048)", frame_size, fft_size);
     return nullptr;
   }
   auto* e        = new PssEngine;
   e->frame_size  = frame_size;
   e->fft_size    = fft_size;
   e->max_caps    = max_caps;
+  e->direct      = frame_size < fft_size; // pss.c:476-481: sliding dot product, conv_output_len = frame_size
   e->hop         = 4096 - (int)fft_size;
-  e->n_out       = (int)(frame_size + fft_size) - 2; // pss.c:493: |.|^2 over conv_output_len - 1 entries
-  e->n_blocks    = (e->n_out + e->hop - 1) / e->hop;
+  e->n_out       = e->direct ? (int)frame_size - 1 : (int)(frame_size + fft_size) - 2; // pss.c:493: conv_output_len - 1 entries
+  e->n_blocks    = e->direct ? (e->n_out + 255) / 256 : (e->n_out + e->hop - 1) / e->hop;
   e->corr_stride = ((size_t)frame_size + fft_size + 2 + 3) & ~(size_t)3;
   std::vector<std::complex<float>> tw(4096), filt(3 * 4096);
   for (int i = 0; i < 4096; i++) {
@@ -185,7 +190,7 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
   }
   for (uint32_t h = 0; h < 3; h++) {
     pss_time_replica(h, fft_size, cfo_i, e->freq[h], e->time[h]);
-    for (int k = 0; k < 4096; k++) {
+    for (int k = 0; k < 4096 && !e->direct; k++) {
       cd acc(0, 0);
       for (uint32_t n = 0; n < fft_size; n++) {
         double a = -2.0 * M_PI * (double)(((uint64_t)k * n) & 4095) / 4096.0;
@@ -204,6 +209,12 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
             hipMemcpy(e->d_tw, tw.data(), 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(e->d_filt, filt.data(), 3 * 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemset(e->d_corr, 0, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess;
+  if (ok && e->direct) {
+    ok = hipMalloc(&e->d_rep, 3 * (size_t)fft_size * sizeof(float2)) == hipSuccess;
+    for (uint32_t h = 0; h < 3 && ok; h++) {
+      ok = hipMemcpy(e->d_rep + (size_t)h * fft_size, e->time[h].data(), fft_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+    }
+  }
   if (!ok) {
     set_error("PSS: device allocation failed");
     pss_engine_free(e);
@@ -233,6 +244,14 @@ int pss_engine_run(PssEngine* e, const void* d_in, uint32_t n_cap, int mask, int
   p.n_out       = e->n_out;
   p.n_id_2_mask = mask;
   p.ema_alpha   = ema_alpha;
+  if (e->direct) {
+    if (n_cap != 1 || mask != 1) {
+      set_error("PSS: the sliding dot-product mode (frame < fft) serves one capture and one N_id_2");
+      return SRSRAN_ERROR;
+    }
+    PHY_HIP_CHECK(sync::launch_pss_direct(p, e->d_rep + (size_t)first_filter * e->fft_size, e->d_res, st), SRSRAN_ERROR);
+    return SRSRAN_SUCCESS;
+  }
   PHY_HIP_CHECK(sync::launch_pss(p, e->d_res, st), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }
@@ -314,10 +333,13 @@ struct PssCtx {
   PssEngine*  e = nullptr;
   hipStream_t stream = nullptr;
   float2*     d_in = nullptr;
+  float2*     d_dec = nullptr; // decimated + filtered input (decimate > 1)
   cf_t*       h_in = nullptr;
   float*      h_avg = nullptr;
   sync::PssResult* h_res = nullptr;
   int         cfo_i = 0;
+  size_t      in_cap = 0;
+  bool        plans = false;   // dftp_input / idftp_input created (srsran_pss_filter and friends)
 };
 PssCtx* pctx(srsran_pss_t* q)
 {
@@ -330,6 +352,7 @@ void pctx_free(PssCtx* c)
   }
   pss_engine_free(c->e);
   (void)hipFree(c->d_in);
+  (void)hipFree(c->d_dec);
   (void)hipHostFree(c->h_in);
   (void)hipHostFree(c->h_avg);
   (void)hipHostFree(c->h_res);
@@ -361,14 +384,19 @@ int pss_setup(srsran_pss_t* q, uint32_t frame_size, uint32_t fft_size, int offse
 }
 } // namespace
 
+// 4-tap decimation low-pass of the reference (filter.c:27-62, the order-3 rows of its tables), per factor 2 / 3 / 4
+static const float kDecimTaps[3][4] = {{0.0167364016736f, 0.48326359832636f, 0.48326359832636f, 0.01673640167364f},
+                                       {0.032388663967611f, 0.467611336032389f, 0.467611336032389f, 0.032388663967611f},
+                                       {0.038579006748772f, 0.461420993251228f, 0.461420993251228f, 0.038579006748772f}};
+
 extern "C" int srsran_pss_init_fft_offset_decim(srsran_pss_t* q, uint32_t max_frame_size, uint32_t max_fft_size, int offset, int decimate)
 {
   if (q == NULL) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
   memset(q, 0, sizeof(srsran_pss_t));
-  if (decimate > 1) {
-    fprintf(stderr, "[srsran_phy_hip] srsran_pss: decimated PSS search is not implemented in the HIP engine\n");
+  if (decimate < 1 || decimate > 4) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss: decimation factor %d not supported (1..4)\n", decimate);
     return SRSRAN_ERROR;
   }
   if (!device_available()) {
@@ -379,8 +407,8 @@ extern "C" int srsran_pss_init_fft_offset_decim(srsran_pss_t* q, uint32_t max_fr
   q->max_fft_size   = max_fft_size;
   q->max_frame_size = max_frame_size;
   q->decimate       = decimate;
-  q->fft_size       = max_fft_size;
-  q->frame_size     = max_frame_size;
+  q->fft_size       = max_fft_size / decimate; // pss.c:107-111
+  q->frame_size     = max_frame_size / decimate;
   const size_t buffer_size = (size_t)max_fft_size + max_frame_size + 1;
   auto* c = new PssCtx;
   q->conv_fft.input_fft = reinterpret_cast<cf_t*>(c);
@@ -389,13 +417,26 @@ extern "C" int srsran_pss_init_fft_offset_decim(srsran_pss_t* q, uint32_t max_fr
   for (int h = 0; h < 3; h++) {
     q->pss_signal_time[h] = (cf_t*)calloc(buffer_size, sizeof(cf_t));
   }
+  if (decimate > 1) {
+    q->filter.factor       = decimate;
+    q->filter.num_taps     = 4; // filter_order 3, pss.c:121
+    q->filter.is_decimator = true;
+    q->filter.taps         = (float*)malloc(4 * sizeof(float));
+    if (q->filter.taps) {
+      memcpy(q->filter.taps, kDecimTaps[decimate - 2], 4 * sizeof(float));
+    }
+  }
+  // full-rate input: frame (+ fft in the sliding dot-product mode)
+  c->in_cap = (size_t)max_frame_size + max_fft_size;
   bool ok = q->conv_output_avg && q->conv_output_abs && q->pss_signal_time[0] && q->pss_signal_time[1] && q->pss_signal_time[2] &&
+            (decimate == 1 || q->filter.taps) &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipMalloc(&c->d_in, (size_t)max_frame_size * sizeof(float2)) == hipSuccess &&
-            hipHostMalloc(&c->h_in, (size_t)max_frame_size * sizeof(cf_t)) == hipSuccess &&
+            hipMalloc(&c->d_in, c->in_cap * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&c->d_dec, c->in_cap * sizeof(float2)) == hipSuccess &&
+            hipHostMalloc(&c->h_in, c->in_cap * sizeof(cf_t)) == hipSuccess &&
             hipHostMalloc(&c->h_avg, buffer_size * sizeof(float)) == hipSuccess &&
             hipHostMalloc(&c->h_res, 3 * sizeof(sync::PssResult)) == hipSuccess;
-  if (!ok || pss_setup(q, max_frame_size, max_fft_size, offset)) {
+  if (!ok || pss_setup(q, q->frame_size, q->fft_size, offset)) {
     srsran_pss_free(q);
     return SRSRAN_ERROR;
   }
@@ -428,9 +469,16 @@ extern "C" int srsran_pss_resize(srsran_pss_t* q, uint32_t frame_size, uint32_t 
   }
   q->N_id_2     = 10;
   q->ema_alpha  = 0.2;
-  q->fft_size   = fft_size;
-  q->frame_size = frame_size;
-  return pss_setup(q, frame_size, fft_size, offset);
+  q->fft_size   = fft_size / q->decimate; // pss.c:237-241
+  q->frame_size = frame_size / q->decimate;
+  PssCtx* c = pctx(q);
+  if (c && c->plans) {
+    if (srsran_dft_replan(&q->dftp_input, (int)q->fft_size) || srsran_dft_replan(&q->idftp_input, (int)q->fft_size)) {
+      return SRSRAN_ERROR;
+    }
+  }
+  memset((void*)q->tmp_fft2, 0, sizeof(q->tmp_fft2));
+  return pss_setup(q, q->frame_size, q->fft_size, offset);
 }
 
 extern "C" void srsran_pss_free(srsran_pss_t* q)
@@ -438,12 +486,18 @@ extern "C" void srsran_pss_free(srsran_pss_t* q)
   if (!q) {
     return;
   }
-  pctx_free(pctx(q));
+  PssCtx* c = pctx(q);
+  if (c && c->plans) {
+    srsran_dft_plan_free(&q->dftp_input);
+    srsran_dft_plan_free(&q->idftp_input);
+  }
+  pctx_free(c);
   for (int h = 0; h < 3; h++) {
     free(q->pss_signal_time[h]);
   }
   free(q->conv_output_avg);
   free(q->conv_output_abs);
+  free(q->filter.taps);
   memset(q, 0, sizeof(srsran_pss_t));
 }
 
@@ -485,14 +539,22 @@ extern "C" int srsran_pss_find_pss(srsran_pss_t* q, const cf_t* input, float* co
   if (!c || !c->e) {
     return SRSRAN_ERROR;
   }
-  if (q->frame_size < q->fft_size) {
-    fprintf(stderr, "[srsran_phy_hip] srsran_pss_find_pss: frame_size < fft_size (sliding dot-product mode) is not implemented\n");
+  const bool direct = q->frame_size < q->fft_size;
+  // samples the reference reads: frame_size * decimate (pss.c:462), or frame_size + fft_size - 1 in the
+  // sliding dot-product mode (pss.c:477-479)
+  const size_t n_in = direct ? (size_t)q->frame_size + q->fft_size - 1 : (size_t)q->frame_size * q->decimate;
+  if (n_in > c->in_cap) {
     return SRSRAN_ERROR;
   }
-  const size_t nb = (size_t)q->frame_size * sizeof(cf_t);
-  memcpy(c->h_in, input, nb);
-  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, nb, hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
-  if (pss_engine_run(c->e, c->d_in, 1, 1, (int)q->N_id_2, q->ema_alpha, c->stream)) {
+  memcpy(c->h_in, input, n_in * sizeof(cf_t));
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, n_in * sizeof(cf_t), hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
+  const float2* d_sig = c->d_in;
+  if (q->decimate > 1 && !direct) {
+    PHY_HIP_CHECK(sync::launch_decim(c->d_in, c->d_dec, (int)q->frame_size, q->decimate, q->filter.taps, c->stream), SRSRAN_ERROR);
+    d_sig = c->d_dec;
+  }
+  if (pss_engine_run(c->e, d_sig, 1, 1, (int)q->N_id_2, q->ema_alpha, c->stream)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss_find_pss: %s\n", get_error());
     return SRSRAN_ERROR;
   }
   const size_t n_avg = (size_t)c->e->n_out;
@@ -504,7 +566,111 @@ extern "C" int srsran_pss_find_pss(srsran_pss_t* q, const cf_t* input, float* co
   if (corr_peak_value) {
     *corr_peak_value = c->h_res->psr; // SRSRAN_PSS_RETURN_PSR (pss.h:61)
   }
-  return c->h_res->peak_pos;
+  uint32_t pos = (uint32_t)c->h_res->peak_pos;
+  if (q->decimate > 1) {
+    pos = (pos - (uint32_t)(q->filter.num_taps - 2)) * (uint32_t)q->decimate; // pss.c:521-525 (unsigned, as there)
+  }
+  return direct ? (int)pos + (int)q->fft_size : (int)pos;
+}
+
+// ---- PSS helpers of pss.c:536-640: channel estimate, central-band filter, half-symbol CFO, cancellation
+
+static int pss_plans(srsran_pss_t* q)
+{
+  PssCtx* c = pctx(q);
+  if (!c) {
+    return SRSRAN_ERROR;
+  }
+  if (c->plans) {
+    return SRSRAN_SUCCESS;
+  }
+  // pss.c:127-141: both plans mirror + dc, no normalisation
+  if (srsran_dft_plan(&q->dftp_input, (int)q->fft_size, SRSRAN_DFT_FORWARD, SRSRAN_DFT_COMPLEX)) {
+    return SRSRAN_ERROR;
+  }
+  if (srsran_dft_plan(&q->idftp_input, (int)q->fft_size, SRSRAN_DFT_BACKWARD, SRSRAN_DFT_COMPLEX)) {
+    srsran_dft_plan_free(&q->dftp_input);
+    return SRSRAN_ERROR;
+  }
+  for (srsran_dft_plan_t* pl : {&q->dftp_input, &q->idftp_input}) {
+    srsran_dft_plan_set_mirror(pl, true);
+    srsran_dft_plan_set_dc(pl, true);
+    srsran_dft_plan_set_norm(pl, false);
+  }
+  c->plans = true;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_pss_filter_enable(srsran_pss_t* q, bool enable)
+{
+  q->filter_pss_enable = enable;
+}
+
+extern "C" int srsran_pss_chest(srsran_pss_t* q, const cf_t* input, cf_t ce[SRSRAN_PSS_LEN])
+{
+  if (q == NULL || input == NULL) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (q->N_id_2 > 2) {
+    fprintf(stderr, "Error finding PSS peak, Must set N_id_2 first\n");
+    return SRSRAN_ERROR;
+  }
+  if (pss_plans(q)) {
+    return SRSRAN_ERROR;
+  }
+  srsran_dft_run_c(&q->dftp_input, input, q->tmp_fft);
+  return glue::prod(&q->tmp_fft[(q->fft_size - SRSRAN_PSS_LEN) / 2], q->pss_signal_freq[q->N_id_2], ce, SRSRAN_PSS_LEN, true);
+}
+
+extern "C" void srsran_pss_filter(srsran_pss_t* q, const cf_t* input, cf_t* output)
+{
+  if (pss_plans(q)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss_filter: %s\n", get_error());
+    return;
+  }
+  srsran_dft_run_c(&q->dftp_input, input, q->tmp_fft);
+  // keep the 62 PSS sub-carriers; the rest of tmp_fft2 stays zero since init / resize (pss.c:143,262)
+  memcpy(&q->tmp_fft2[q->fft_size / 2 - SRSRAN_PSS_LEN / 2], &q->tmp_fft[q->fft_size / 2 - SRSRAN_PSS_LEN / 2],
+         sizeof(cf_t) * SRSRAN_PSS_LEN);
+  if (q->chest_on_filter) {
+    glue::prod(&q->tmp_fft[(q->fft_size - SRSRAN_PSS_LEN) / 2], q->pss_signal_freq[q->N_id_2], q->tmp_ce, SRSRAN_PSS_LEN, true);
+  }
+  srsran_dft_run_c(&q->idftp_input, q->tmp_fft2, output);
+}
+
+extern "C" float srsran_pss_cfo_compute(srsran_pss_t* q, const cf_t* pss_recv)
+{
+  const cf_t* ptr = pss_recv;
+  if (q->filter_pss_enable) {
+    srsran_pss_filter(q, pss_recv, q->tmp_fft);
+    ptr = q->tmp_fft;
+  }
+  const int   half  = (int)q->fft_size / 2;
+  const cf_t* rep   = q->pss_signal_time[q->N_id_2];
+  glue::Dot   jobs[2] = {{rep, ptr, half, glue::PLAIN}, {&rep[half], &ptr[half], half, glue::PLAIN}};
+  cf_t        y[2];
+  if (glue::dots(jobs, 2, y)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_pss_cfo_compute: %s\n", get_error());
+    return 0.f;
+  }
+  return std::arg(std::conj(y[0]) * y[1]) / (float)M_PI; // pss.c:639
+}
+
+extern "C" void srsran_pss_sic(srsran_pss_t* q, cf_t* input)
+{
+  if (!q->chest_on_filter) {
+    fprintf(stderr, "Error calling srsran_pss_sic(): need to enable channel estimation on filtering\n");
+    return;
+  }
+  if (pss_plans(q)) {
+    return;
+  }
+  memset((void*)q->tmp_fft, 0, sizeof(cf_t) * q->fft_size);
+  glue::prod(q->pss_signal_freq[q->N_id_2], q->tmp_ce, &q->tmp_fft[(q->fft_size - SRSRAN_PSS_LEN) / 2], SRSRAN_PSS_LEN, false);
+  srsran_dft_run_c(&q->idftp_input, q->tmp_fft, q->tmp_fft2);
+  // input -= received replica / fft_size; the scaled replica stays in tmp_fft2 (pss.c:552-553)
+  glue::lincomb(q->tmp_fft2, 1.0f / (float)q->fft_size, q->tmp_fft2, 0.f, q->tmp_fft2, (int)q->fft_size);
+  glue::lincomb(input, 1.0f, q->tmp_fft2, -1.0f, input, (int)q->fft_size);
 }
 
 // ------------------------------------------------------------------------------------------------ SSS handle ABI

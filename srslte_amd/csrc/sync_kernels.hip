@@ -420,5 +420,256 @@ hipError_t launch_sss(const SssParams& p, const PssResult* d_pss, SssResult* d_r
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small kernels behind the srsran_sync_t glue (sync.c), srsran_cfo_t, srsran_cp_synch_t and the PSS helpers.
+// They work on one frame; none of them is a throughput path (the batched cell search above is).
+
+// srsran_vec_prod_ccc / srsran_vec_prod_conj_ccc (a * conj(b))
+__global__ void cmul_kernel(const float2* a, const float2* b, float2* out, int n, int conj_b)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float2 y = b[i];
+    if (conj_b) {
+      y.y = -y.y;
+    }
+    out[i] = cmul(a[i], y);
+  }
+}
+
+hipError_t launch_cmul(const void* a, const void* b, void* out, int n, bool conj_b, hipStream_t stream)
+{
+  hipLaunchKernelGGL(cmul_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float2*)a, (const float2*)b, (float2*)out, n,
+                     conj_b ? 1 : 0);
+  return hipGetLastError();
+}
+
+// out = sa * a + sb * b (real weights): srsran_vec_sc_prod_cfc + srsran_vec_sub_ccc of pss.c:552-553
+__global__ void lincomb_kernel(const float2* a, float sa, const float2* b, float sb, float2* out, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float2 x = a[i], y = b[i];
+    out[i] = make_float2(sa * x.x + sb * y.x, sa * x.y + sb * y.y);
+  }
+}
+
+hipError_t launch_lincomb(const void* a, float sa, const void* b, float sb, void* out, int n, hipStream_t stream)
+{
+  hipLaunchKernelGGL(lincomb_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float2*)a, sa, (const float2*)b, sb,
+                     (float2*)out, n);
+  return hipGetLastError();
+}
+
+// srsran_vec_dot_prod_ccc / _conj_ccc / avg_power_cf: one workgroup per job
+__global__ __launch_bounds__(256) void dot_kernel(const DotJobs jobs, float2* out)
+{
+  __shared__ float2 red[256];
+  const int     j = blockIdx.x, tid = threadIdx.x;
+  const float2* a = reinterpret_cast<const float2*>(jobs.a[j]);
+  const float2* b = reinterpret_cast<const float2*>(jobs.b[j]);
+  const int     n = jobs.n[j], mode = jobs.mode[j];
+  float2        acc = make_float2(0.f, 0.f);
+  for (int i = tid; i < n; i += 256) {
+    const float2 x = a[i];
+    if (mode == DOT_POWER) {
+      acc.x += x.x * x.x + x.y * x.y;
+    } else {
+      float2 y = b[i];
+      if (mode == DOT_CONJ) {
+        y.y = -y.y;
+      }
+      const float2 pr = cmul(x, y);
+      acc.x += pr.x;
+      acc.y += pr.y;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[tid].x += red[tid + s].x;
+      red[tid].y += red[tid + s].y;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float2 r = red[0];
+    if (mode == DOT_POWER) {
+      r.x /= (float)n;
+    }
+    out[j] = r;
+  }
+}
+
+hipError_t launch_dots(const DotJobs& jobs, void* d_out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(dot_kernel, dim3(jobs.count), dim3(256), 0, stream, jobs, (float2*)d_out);
+  return hipGetLastError();
+}
+
+// srsran_cp_synch (cp.c:60-79): corr[i] = mean over the symbols of sum_k x[i+k] conj(x[i+k+N]); arg-max of |corr|
+__global__ __launch_bounds__(256) void cp_synch_kernel(const float2* in, float2* corr, int max_offset, int nof_symbols, int cp_len, int N,
+                                                       int* argmax)
+{
+  __shared__ float s_v[256];
+  __shared__ int   s_i[256];
+  const int tid = threadIdx.x;
+  float best = -1.f;
+  int   besti = 0x7fffffff;
+  for (int i = tid; i < max_offset; i += 256) {
+    float2        acc = make_float2(0.f, 0.f);
+    const float2* ptr = in;
+    for (int n = 0; n < nof_symbols; n++) {
+      const int cplen = (n % 7) ? cp_len : cp_len + 1;
+      float2    d = make_float2(0.f, 0.f);
+      for (int k = 0; k < cplen; k++) {
+        const float2 x = ptr[i + k], y = ptr[i + k + N];
+        d.x += x.x * y.x + x.y * y.y;
+        d.y += x.y * y.x - x.x * y.y;
+      }
+      acc.x += d.x / (float)nof_symbols;
+      acc.y += d.y / (float)nof_symbols;
+      ptr += N + cplen;
+    }
+    corr[i] = acc;
+    const float m = acc.x * acc.x + acc.y * acc.y;
+    if (m > best) {
+      best  = m;
+      besti = i;
+    }
+  }
+  s_v[tid] = best;
+  s_i[tid] = besti;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      if (s_v[tid + s] > s_v[tid] || (s_v[tid + s] == s_v[tid] && s_i[tid + s] < s_i[tid])) {
+        s_v[tid] = s_v[tid + s];
+        s_i[tid] = s_i[tid + s];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *argmax = max_offset > 0 ? s_i[0] : 0;
+  }
+}
+
+hipError_t launch_cp_synch(const void* in, void* corr, int max_offset, int nof_symbols, int cp_len, int N, int* d_argmax, hipStream_t stream)
+{
+  hipLaunchKernelGGL(cp_synch_kernel, dim3(1), dim3(256), 0, stream, (const float2*)in, (float2*)corr, max_offset, nof_symbols, cp_len,
+                     N, d_argmax);
+  return hipGetLastError();
+}
+
+// srsran_filt_decim_cc_execute (filter.c:95-110): keep every M-th sample behind num_taps-1 zeros, then the FIR
+__global__ void decim_kernel(const float2* in, float2* out, int n_out, int M, int num_taps, float t0, float t1, float t2, float t3)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) {
+    return;
+  }
+  const float taps[4] = {t0, t1, t2, t3};
+  float2      acc     = make_float2(0.f, 0.f);
+  for (int t = 0; t < num_taps; t++) {
+    const int j = i + t - (num_taps - 1); // index into the down-sampled sequence
+    if (j >= 0) {
+      const float2 x = in[(size_t)j * M];
+      acc.x += x.x * taps[t];
+      acc.y += x.y * taps[t];
+    }
+  }
+  out[i] = acc;
+}
+
+hipError_t launch_decim(const void* in, void* out, int n_out, int M, const float* taps4, hipStream_t stream)
+{
+  hipLaunchKernelGGL(decim_kernel, dim3((n_out + 255) / 256), dim3(256), 0, stream, (const float2*)in, (float2*)out, n_out, M, 4,
+                     taps4[0], taps4[1], taps4[2], taps4[3]);
+  return hipGetLastError();
+}
+
+// srsran_pss_find_pss with frame_size < fft_size (pss.c:476-481): conv[i] = sum_n replica[n] x[i+n], then the same
+// |.|^2 / moving average / arg-max as the FFT path.  One thread per output, partial maxima per workgroup.
+__global__ __launch_bounds__(256) void pss_direct_kernel(const PssParams p, const float2* replica)
+{
+  __shared__ float s_v[256];
+  __shared__ int   s_i[256];
+  const int     tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  const float2* x   = reinterpret_cast<const float2*>(p.in);
+  float         pw  = -1.f;
+  if (i < p.n_out) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int n = 0; n < p.fft_size; n++) {
+      const float2 pr = cmul(replica[n], x[i + n]);
+      acc.x += pr.x;
+      acc.y += pr.y;
+    }
+    pw = acc.x * acc.x + acc.y * acc.y;
+    if (p.ema_alpha > 0.0f && p.ema_alpha < 1.0f) {
+      pw = pw * p.ema_alpha + p.corr[i] * (1.0f - p.ema_alpha);
+    }
+    p.corr[i] = pw;
+  }
+  s_v[tid] = pw;
+  s_i[tid] = i;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      if (s_v[tid + s] > s_v[tid] || (s_v[tid + s] == s_v[tid] && s_i[tid + s] < s_i[tid])) {
+        s_v[tid] = s_v[tid + s];
+        s_i[tid] = s_i[tid + s];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    p.part_val[blockIdx.x] = s_v[0];
+    p.part_idx[blockIdx.x] = s_i[0];
+  }
+}
+
+// p.n_blocks = ceil(n_out / 256); hypothesis slot 0 only (n_id_2_mask = 1)
+hipError_t launch_pss_direct(const PssParams& p, const void* d_replica, PssResult* d_res, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pss_direct_kernel, dim3(p.n_blocks), dim3(256), 0, stream, p, (const float2*)d_replica);
+  hipLaunchKernelGGL(pss_peak_kernel, dim3(3, 1), dim3(256), 0, stream, p, d_res);
+  return hipGetLastError();
+}
+
+// srsran_vec_apply_cfo (vector_simd.c:1692-1739, AVX2 + FMA build): z[i] = x[i] e^{j 2 pi cfo i} from EIGHT recursive
+// oscillators (lane k serves samples 8m + k, advancing by e^{j 2 pi cfo 8}) and a scalar oscillator for the last
+// len % 8 samples.  The float recursion IS the reference's result (its phase drifts from the ideal exponential), so
+// it is replayed with the same fused operations; the seeds come from the host (cexpf).
+__global__ __launch_bounds__(64) void apply_cfo_kernel(const float2* x, float2* z, int len, const CfoSeeds s)
+{
+  const int k = threadIdx.x;
+  const int nvec = len >= 8 ? (len / 8) * 8 : 0;
+  if (k < 8) {
+    float2       ph  = make_float2(s.phase_re[k], s.phase_im[k]);
+    const float2 osc = make_float2(s.osc8_re, s.osc8_im);
+    for (int i = k; i < nvec; i += 8) {
+      const float2 a = x[i];
+      z[i] = make_float2(__fmaf_rn(a.x, ph.x, -__fmul_rn(a.y, ph.y)), __fmaf_rn(a.x, ph.y, __fmul_rn(a.y, ph.x)));
+      ph   = make_float2(__fmaf_rn(ph.x, osc.x, -__fmul_rn(ph.y, osc.y)), __fmaf_rn(ph.x, osc.y, __fmul_rn(ph.y, osc.x)));
+    }
+  } else if (k == 8) {
+    float2       ph  = make_float2(s.tail_re, s.tail_im);
+    const float2 osc = make_float2(s.osc1_re, s.osc1_im);
+    for (int i = nvec; i < len; i++) {
+      const float2 a = x[i];
+      z[i] = make_float2(__fsub_rn(__fmul_rn(a.x, ph.x), __fmul_rn(a.y, ph.y)), __fadd_rn(__fmul_rn(a.x, ph.y), __fmul_rn(a.y, ph.x)));
+      ph   = make_float2(__fsub_rn(__fmul_rn(ph.x, osc.x), __fmul_rn(ph.y, osc.y)), __fadd_rn(__fmul_rn(ph.x, osc.y), __fmul_rn(ph.y, osc.x)));
+    }
+  }
+}
+
+hipError_t launch_apply_cfo(const void* x, void* z, int len, const CfoSeeds& seeds, hipStream_t stream)
+{
+  hipLaunchKernelGGL(apply_cfo_kernel, dim3(1), dim3(64), 0, stream, (const float2*)x, (float2*)z, len, seeds);
+  return hipGetLastError();
+}
+
 } // namespace sync
 } // namespace phyhip

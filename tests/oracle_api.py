@@ -224,13 +224,77 @@ def sync_subframe(cell_id, nof_prb, symbol_sz, sf5=False):
     return ofdm_tx(cfg, grid.reshape(1, -1))[0]
 
 
-def pss_find(frame, fft_size, N_id_2, want_corr=False):
+def pss_find(frame, fft_size, N_id_2, want_corr=False, frame_size=None):
+    """frame_size < fft_size: the sliding dot-product mode; `frame` must then hold frame_size + fft_size - 1 samples"""
     orc().orc_pss_find.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     frame = np.ascontiguousarray(frame, np.complex64)
+    n = frame.size if frame_size is None else frame_size
     pv, psr = C.c_float(), C.c_float()
-    corr = np.zeros(frame.size + fft_size - 2, np.float32) if want_corr else None
-    pk = orc().orc_pss_find(P(frame), frame.size, fft_size, N_id_2, P(corr) if want_corr else None, C.byref(pv), C.byref(psr))
+    corr = np.zeros(n + fft_size - 2, np.float32) if want_corr else None
+    pk = orc().orc_pss_find(P(frame), n, fft_size, N_id_2, P(corr) if want_corr else None, C.byref(pv), C.byref(psr))
     return (pk, pv.value, psr.value, corr) if want_corr else (pk, pv.value, psr.value)
+
+
+def cfo_correct(x, freq):
+    orc().orc_cfo_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_uint32]
+    x = np.ascontiguousarray(x, np.complex64)
+    out = np.zeros_like(x)
+    orc().orc_cfo_correct(P(x), P(out), freq, x.size)
+    return out
+
+
+def cp_synch(x, N, max_offset, nof_symbols, cp_len):
+    orc().orc_cp_synch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    orc().orc_cp_synch.restype = C.c_uint32
+    x = np.ascontiguousarray(x, np.complex64)
+    corr = np.zeros(min(max_offset, N), np.complex64)
+    idx = orc().orc_cp_synch(P(x), N, max_offset, nof_symbols, cp_len, P(corr))
+    return idx, corr
+
+
+def pss_filter(x, N, N_id_2, want_ce=False):
+    orc().orc_pss_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    x = np.ascontiguousarray(x, np.complex64)
+    out, ce = np.zeros(N, np.complex64), np.zeros(62, np.complex64)
+    assert orc().orc_pss_filter(P(x), P(out), N, N_id_2, P(ce) if want_ce else None) == 0
+    return (out, ce) if want_ce else out
+
+
+def pss_cfo_compute(x, N, N_id_2):
+    orc().orc_pss_cfo_compute.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    orc().orc_pss_cfo_compute.restype = C.c_float
+    return orc().orc_pss_cfo_compute(P(np.ascontiguousarray(x, np.complex64)), N, N_id_2)
+
+
+def detect_cp(x, peak_pos, N):
+    orc().orc_detect_cp.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    m = np.zeros(2, np.float32)
+    cp = orc().orc_detect_cp(P(np.ascontiguousarray(x, np.complex64)), peak_pos, N, P(m))
+    return cp, m
+
+
+def cell_signal(cell_id, nof_prb, symbol_sz, cp_ext=False, tdd=False, sf5=False, n_sf=2):
+    """n_sf subframes starting at subframe 0 (or 5) of a cell carrying only PSS and SSS (36.211 6.11): FDD: PSS in
+    the last symbol of slot 0, SSS in the one before; TDD: SSS in the last symbol of slot 1, PSS in the third symbol
+    of the next subframe.  Returns (samples, index of the first sample after the PSS symbol)."""
+    cfg = ofdm_cfg(nof_prb, symbol_sz, 1 if cp_ext else 0, 1)
+    N, nsym, sf_sz, sf_re = ofdm_geometry(cfg)
+    ns = nsym // 2
+    grids = np.zeros((n_sf, nsym, 12 * nof_prb), np.complex64)
+    k = 12 * nof_prb // 2 - 31
+    if tdd:
+        grids[0, nsym - 1, k:k + 62] = sss_seq(cell_id)[1 if sf5 else 0]
+        grids[1, 2, k:k + 62] = pss_zc(cell_id % 3)
+        pss_sf, pss_sym = 1, 2
+    else:
+        grids[0, ns - 1, k:k + 62] = pss_zc(cell_id % 3)
+        grids[0, ns - 2, k:k + 62] = sss_seq(cell_id)[1 if sf5 else 0]
+        pss_sf, pss_sym = 0, ns - 1
+    x = ofdm_tx(cfg, grids.reshape(n_sf, -1)).reshape(-1)
+    cp0 = orc().orc_cp_len(N, 512 if cp_ext else 160)
+    cp1 = orc().orc_cp_len(N, 512 if cp_ext else 144)
+    end = pss_sf * sf_sz + cp0 + N + pss_sym * (cp1 + N)
+    return x, end
 
 
 def sss_detect(symbol, fft_size, N_id_2, M):

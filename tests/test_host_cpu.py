@@ -57,6 +57,11 @@ def test_struct_layout_matches_ctypes_mirror(L):
     assert sizes["srsran_tdec_t"] == C.sizeof(capi.Tdec)
     assert sizes["srsran_ldpc_decoder_t"] == C.sizeof(capi.LdpcDecoder)
     assert sizes["srsran_crc_t"] == C.sizeof(capi.Crc)
+    assert sizes["srsran_sync_t"] == C.sizeof(capi.Sync)
+    assert sizes["srsran_cfo_t"] == C.sizeof(capi.Cfo)
+    assert sizes["srsran_cp_synch_t"] == C.sizeof(capi.CpSynch)
+    assert sizes["off_sync_cfo_corr_frame"] == capi.Sync.cfo_corr_frame.offset
+    assert sizes["off_sync_sss_signal"] == capi.Sync.sss_signal.offset
 
 
 # sizeof/offsetof recorded from the reference headers (lib/include/srsran/phy/...) with gcc 11, x86-64
@@ -64,7 +69,9 @@ REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_of
                     "srsran_ldpc_decoder_t": 88, "srsran_crc_t": 2088, "srsran_tc_interl_t": 24,
                     "off_ofdm_tmp": 224, "off_tdec_interleaver": 208, "off_tdec_n_iter": 18256, "off_ldpc_decode_c": 80,
                     "srsran_pss_t": 35248, "srsran_sss_t": 38888, "srsran_dft_precoding_t": 5336,
-                    "off_pss_conv_output_avg": 1864, "off_pss_tmp_ce": 34744, "off_sss_fc_tables": 3672}
+                    "off_pss_conv_output_avg": 1864, "off_pss_tmp_ce": 34744, "off_sss_fc_tables": 3672,
+                    "srsran_sync_t": 226864, "srsran_cfo_t": 40, "srsran_cp_synch_t": 16, "off_sync_cfo_corr_frame": 144800,
+                    "off_sync_sss_signal": 194096}
 
 
 OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n'
@@ -85,6 +92,11 @@ int main(void) {
   printf("srsran_pss_t %zu\\n", sizeof(srsran_pss_t));
   printf("srsran_sss_t %zu\\n", sizeof(srsran_sss_t));
   printf("srsran_dft_precoding_t %zu\\n", sizeof(srsran_dft_precoding_t));
+  printf("srsran_sync_t %zu\\n", sizeof(srsran_sync_t));
+  printf("srsran_cfo_t %zu\\n", sizeof(srsran_cfo_t));
+  printf("srsran_cp_synch_t %zu\\n", sizeof(srsran_cp_synch_t));
+  printf("off_sync_cfo_corr_frame %zu\\n", offsetof(srsran_sync_t, cfo_corr_frame));
+  printf("off_sync_sss_signal %zu\\n", offsetof(srsran_sync_t, sss_signal));
   printf("off_pss_conv_output_avg %zu\\n", offsetof(srsran_pss_t, conv_output_avg));
   printf("off_pss_tmp_ce %zu\\n", offsetof(srsran_pss_t, tmp_ce));
   printf("off_sss_fc_tables %zu\\n", offsetof(srsran_sss_t, fc_tables));
@@ -111,7 +123,7 @@ def test_struct_layout_matches_recorded_reference(L):
 def test_struct_layout_matches_reference():
     inc = ('#include <complex.h>\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
            '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n#include "srsran/phy/sync/pss.h"\n'
-           '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n')
+           '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n#include "srsran/phy/sync/sync.h"\n')
     theirs = _c_sizes(["-I", "/root/reference/lib/include"], inc)
     assert theirs == REFERENCE_LAYOUT
 

@@ -34,6 +34,18 @@ def test_turbo_8bit_reference_outputs():
             assert np.array_equal(got, outs[nit - 1]), (key, nit)
 
 
+def test_sync_glue_reference_outputs():
+    """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
+    d = np.load(os.path.join(G, "syncglue_ref.npz"))
+    for f, want in zip(d["cfo_freqs"], d["cfo_out"]):
+        got = O.cfo_correct(d["cfo_x"], float(f))
+        assert np.abs(got - want).max() < 2e-7, f
+    N, nsym, max_off, cp = [int(v) for v in d["cp_par"]]
+    idx, corr = O.cp_synch(d["cp_y"], N, max_off, nsym, cp)
+    assert idx == int(d["cp_idx"][0])
+    assert np.abs(corr - d["cp_corr"]).max() < 1e-4 * np.abs(d["cp_corr"]).max()
+
+
 def test_turbo_known_answer_block():
     """turbodecoder_test.h:69-125: K=504 message and its 1524 coded bits"""
     d = np.load(os.path.join(G, "turbo_ref.npz"))

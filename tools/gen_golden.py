@@ -9,6 +9,7 @@ No reference source text is stored.
   tests/golden/turbo_ref.npz   reference srsran_tdec_run_all outputs on seeded noisy LLRs; known-answer
                                K=504 message/code word; CRC32 of every QPP table the reference builds
   tests/golden/turbo8_ref.npz  reference 8-bit turbo decoders (sse8 / avx8 window) on seeded int8 LLRs
+  tests/golden/syncglue_ref.npz  reference srsran_cfo_correct / srsran_cp_synch outputs on seeded inputs
   tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
@@ -116,6 +117,39 @@ def turbo8():
     print("turbo8_ref.npz", os.path.getsize(os.path.join(OUT, "turbo8_ref.npz")))
 
 
+def syncglue():
+    """reference srsran_cfo_correct and srsran_cp_synch (cfo.c, cp.c, cexptab.c need no FFT library) on seeded inputs"""
+    d = {}
+    rng = np.random.default_rng(77)
+    n = 1920
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    d["cfo_x"] = x
+    freqs = np.array([0.0, 1.3e-4, -7.7e-4, 0.013, -0.2], np.float32)
+    d["cfo_freqs"] = freqs
+    outs = np.zeros((freqs.size, n), np.complex64)
+    h = C.create_string_buffer(256)
+    assert ref.srsran_cfo_init(h, n) == 0
+    ref.srsran_cfo_correct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+    for i, f in enumerate(freqs):
+        ref.srsran_cfo_correct(h, P(x), P(outs[i]), float(f))
+    ref.srsran_cfo_free(h)
+    d["cfo_out"] = outs
+    N, nsym, max_off = 512, 7, 200
+    cp = 36
+    y = ((rng.standard_normal(max_off + (nsym + 1) * (N + cp + 1) + N) + 1j * rng.standard_normal(max_off + (nsym + 1) * (N + cp + 1) + N)) * 0.7)
+    y = y.astype(np.complex64)
+    q = C.create_string_buffer(64)
+    assert ref.srsran_cp_synch_init(q, N) == 0
+    ref.srsran_cp_synch.restype = C.c_uint32
+    idx = ref.srsran_cp_synch(q, P(y), max_off, nsym, cp)
+    corr_ptr = C.cast(q, C.POINTER(C.c_void_p))[0]
+    corr = np.ctypeslib.as_array(C.cast(corr_ptr, C.POINTER(C.c_float)), shape=(2 * max_off,)).copy().view(np.complex64)
+    d["cp_y"], d["cp_par"], d["cp_idx"], d["cp_corr"] = y, np.array([N, nsym, max_off, cp]), np.array([idx]), corr
+    ref.srsran_cp_synch_free(q)
+    np.savez_compressed(os.path.join(OUT, "syncglue_ref.npz"), **d)
+    print("syncglue_ref.npz", os.path.getsize(os.path.join(OUT, "syncglue_ref.npz")))
+
+
 class Args(C.Structure):
     _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_uint32)]
 
@@ -171,6 +205,6 @@ def ldpc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "syncglue"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "syncglue": syncglue}[name]()

@@ -60,6 +60,14 @@ typedef struct srsran_hip_ldpc_batch srsran_hip_ldpc_batch_t;
 
 SRSRAN_API int  srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** h, srsran_basegraph_t bg, uint16_t ls,
                                              float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw);
+/* type: SRSRAN_LDPC_DECODER_F (float LLRs, ldpc_dec_f.c), _S (int16, ldpc_dec_s.c) or the int8 family _C / _C_AVX2 /
+ * _C_AVX512; all layered min-sum under the schedule of ldpc_decoder.c:44-104.  Use run_typed with LLRs of that type;
+ * llr_stride counts LLRs, not bytes. */
+SRSRAN_API int  srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** h, srsran_basegraph_t bg, uint16_t ls, float scaling_fctr,
+                                                   uint32_t max_nof_iter, uint32_t max_nof_cw, srsran_ldpc_decoder_type_t type);
+SRSRAN_API int  srsran_hip_ldpc_batch_run_typed(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride,
+                                                uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
+                                                uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream);
 SRSRAN_API void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h);
 /* d_llrs   : n_cw x (N-2Z) int8 (only the first cdwd_rm_length... all N-2Z are read, as the reference does),
  *            `llr_stride` bytes apart;  d_message: n_cw x K bytes, one bit per byte, `msg_stride` apart.

@@ -95,6 +95,13 @@ int orc_ldpc_decode_c(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof
                       uint8_t* message, uint32_t cdwd_rm_length, uint32_t crc_poly, int crc_order,
                       int8_t* soft_out);
 
+/* srsran_ldpc_decoder_decode_s / _decode_f (ldpc_dec_s.c, ldpc_dec_f.c), fixed number of iterations (no CRC entry
+ * point exists for these types, ldpc_decoder.h:111-180).  soft_out: optional liftN a-posteriori values */
+int orc_ldpc_decode_s(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const int16_t* llrs,
+                      uint8_t* message, uint32_t cdwd_rm_length, int16_t* soft_out);
+int orc_ldpc_decode_f(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const float* llrs,
+                      uint8_t* message, uint32_t cdwd_rm_length, float* soft_out);
+
 /* ldpc_enc_c.c / ldpc_encoder.c: systematic encoder, bit per byte, filler bits (value 254) allowed.
  * output: N-2Z bits (cdwd_rm_length = full) */
 int orc_ldpc_encode(const orc_ldpc_graph_t* g, const uint8_t* message, uint8_t* codeword);

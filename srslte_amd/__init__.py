@@ -113,13 +113,15 @@ class TdecBatch:
 class LdpcBatch:
     """srsran_ldpc_decoder_decode_c over a batch of code words (srsran_hip_ldpc_batch_*)."""
 
-    def __init__(self, bg, ls, scaling_fctr=0.8, max_nof_iter=0, max_nof_cw=1):
+    def __init__(self, bg, ls, scaling_fctr=0.8, max_nof_iter=0, max_nof_cw=1, dec_type=capi.LDPC_C):
+        """dec_type: capi.LDPC_C (int8 LLRs), LDPC_S (int16) or LDPC_F (float32)"""
         self.bg, self.Z = int(bg), int(ls)
         self.bgN, self.bgK = (68, 22) if bg == capi.BG1 else (52, 10)
         self.max_iter = int(max_nof_iter) if max_nof_iter else 10
+        self.dtype = {capi.LDPC_F: np.float32, capi.LDPC_S: np.int16}.get(dec_type, np.int8)
         self._h = C.c_void_p()
-        capi.check(lib().srsran_hip_ldpc_batch_create(C.byref(self._h), self.bg, self.Z, scaling_fctr, max_nof_iter,
-                                                      max_nof_cw), "ldpc_batch_create")
+        capi.check(lib().srsran_hip_ldpc_batch_create_typed(C.byref(self._h), self.bg, self.Z, scaling_fctr, max_nof_iter,
+                                                            max_nof_cw, dec_type), "ldpc_batch_create")
 
     @property
     def n_llr(self):
@@ -130,18 +132,25 @@ class LdpcBatch:
         return self.bgK * self.Z
 
     def run(self, d_llrs, llr_stride, d_msg, msg_stride, n_cw, cdwd_rm_length, d_iter_msgs=None, stream=None):
-        capi.check(lib().srsran_hip_ldpc_batch_run(self._h, _ptr(d_llrs), llr_stride, _ptr(d_msg), msg_stride, n_cw,
-                                                   cdwd_rm_length, _ptr(d_iter_msgs), stream), "ldpc_batch_run")
+        capi.check(lib().srsran_hip_ldpc_batch_run_typed(self._h, _ptr(d_llrs), llr_stride, _ptr(d_msg), msg_stride, n_cw,
+                                                         cdwd_rm_length, _ptr(d_iter_msgs), stream), "ldpc_batch_run")
 
-    def decode(self, llrs, cdwd_rm_length=None, want_iter_msgs=False):
-        llrs = np.ascontiguousarray(llrs, dtype=np.int8)
+    def decode(self, llrs, cdwd_rm_length=None, want_iter_msgs=False, want_soft=False):
+        llrs = np.ascontiguousarray(llrs, dtype=self.dtype)
         n_cw, L = llrs.shape
         assert L >= self.n_llr
         d_in = DeviceBuffer.from_numpy(llrs)
         d_out = DeviceBuffer(n_cw * self.liftK)
         mb = (self.liftK + 7) // 8
         d_it = DeviceBuffer(n_cw * self.max_iter * mb) if want_iter_msgs else None
-        self.run(d_in, L, d_out, self.liftK, n_cw, self.n_llr if cdwd_rm_length is None else cdwd_rm_length, d_it)
+        rm = self.n_llr if cdwd_rm_length is None else cdwd_rm_length
+        if want_soft:
+            d_soft = DeviceBuffer(n_cw * self.bgN * self.Z * np.dtype(self.dtype).itemsize)
+            capi.check(lib().srsran_hip_ldpc_batch_run_dbg(self._h, d_in.ptr, L, d_out.ptr, self.liftK, n_cw, rm, d_soft.ptr, None),
+                       "ldpc_batch_run_dbg")
+            capi.check(lib().srsran_hip_stream_sync(None), "sync")
+            return d_out.to_numpy(np.uint8, (n_cw, self.liftK)), d_soft.to_numpy(self.dtype, (n_cw, self.bgN * self.Z))
+        self.run(d_in, L, d_out, self.liftK, n_cw, rm, d_it)
         capi.check(lib().srsran_hip_stream_sync(None), "sync")
         out = d_out.to_numpy(np.uint8, (n_cw, self.liftK))
         if want_iter_msgs:

@@ -188,6 +188,9 @@ def lib():
             "srsran_hip_tdec_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, i32, vp]),
             "srsran_hip_tdec_batch_last_llr": (i32, [vp, vp, u32, vp]),
             "srsran_hip_ldpc_batch_create": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32]),
+            "srsran_hip_ldpc_batch_create_typed": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32, i32]),
+            "srsran_hip_ldpc_batch_run_typed": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
+            "srsran_hip_ldpc_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_free": (None, [vp]),
             "srsran_hip_ldpc_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ofdm_batch_create": (i32, [C.POINTER(vp), C.POINTER(OfdmCfg), i32]),
@@ -218,6 +221,8 @@ def lib():
             "srsran_ldpc_decoder_init": (i32, [C.POINTER(LdpcDecoder), C.POINTER(LdpcDecoderArgs)]),
             "srsran_ldpc_decoder_free": (None, [C.POINTER(LdpcDecoder)]),
             "srsran_ldpc_decoder_decode_c": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32]),
+            "srsran_ldpc_decoder_decode_f": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32]),
+            "srsran_ldpc_decoder_decode_s": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32]),
             "srsran_ldpc_decoder_decode_crc_c": (i32, [C.POINTER(LdpcDecoder), vp, vp, u32, C.POINTER(Crc)]),
             "create_compact_pcm": (i32, [vp, vp, i32, C.c_uint16]),
             "srsran_ofdm_rx_init_cfg": (i32, [C.POINTER(Ofdm), C.POINTER(OfdmCfg)]),

@@ -6,8 +6,10 @@
 namespace phyhip {
 namespace ldpc {
 
+enum { DT_I8 = 0, DT_I16 = 1, DT_F32 = 2 }; // LLR / message type: ldpc_dec_c.c, ldpc_dec_s.c, ldpc_dec_f.c
+
 struct Params {
-  const int8_t*   llrs;      // n_cw x (N-2Z) int8, llr_stride bytes apart
+  const void*     llrs;      // n_cw x (N-2Z) LLRs of type dtype, llr_stride ELEMENTS apart
   uint8_t*        msg;       // n_cw x K*Z bytes (bit per byte), msg_stride apart
   uint8_t*        iter_msgs; // optional: n_cw x max_iter x ceil(K*Z/8) packed hard decisions per iteration
   const int*      row_start; // bgM+1 : first edge of every base-graph row
@@ -23,6 +25,10 @@ struct Params {
   int             sf; // (int)(scaling_fctr * 100)
   int             n_cw;
   int             cpb; // code words per workgroup
+  int             dtype;
+  float           sf_f;     // scaling factor of the float decoder
+  void*           c2v_ws;   // int16 / float: n_cw x n_edges x Z check-to-variable messages (HBM)
+  void*           soft_out; // optional: n_cw x bgN*Z a-posteriori soft bits (parity aid)
 };
 
 hipError_t launch(const Params& p, hipStream_t stream);

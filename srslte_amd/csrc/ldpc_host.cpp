@@ -86,6 +86,9 @@ struct srsran_hip_ldpc_batch {
   int      bg = 0, Z = 0, N = 0, M = 0, K = 0, E = 0;
   int      max_iter = 0;
   int      sf       = 0;
+  float    sf_f     = 0.f;
+  int      dtype    = ldpc::DT_I8; // message type: int8 (ldpc_dec_c.c), int16 (ldpc_dec_s.c) or float (ldpc_dec_f.c)
+  void*    d_c2v    = nullptr;     // int16 / float: check-to-variable messages, max_cw x E x Z
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
   int* d_row_start = nullptr;
@@ -95,8 +98,32 @@ struct srsran_hip_ldpc_batch {
 extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran_basegraph_t bg, uint16_t ls,
                                             float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw)
 {
+  return srsran_hip_ldpc_batch_create_typed(hh, bg, ls, scaling_fctr, max_nof_iter, max_nof_cw, SRSRAN_LDPC_DECODER_C);
+}
+
+extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, srsran_basegraph_t bg, uint16_t ls,
+                                                  float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw,
+                                                  srsran_ldpc_decoder_type_t type)
+{
   if (!hh) {
     return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  int dtype;
+  switch (type) {
+    case SRSRAN_LDPC_DECODER_F:
+      dtype = ldpc::DT_F32;
+      break;
+    case SRSRAN_LDPC_DECODER_S:
+      dtype = ldpc::DT_I16;
+      break;
+    case SRSRAN_LDPC_DECODER_C:
+    case SRSRAN_LDPC_DECODER_C_AVX2:
+    case SRSRAN_LDPC_DECODER_C_AVX512:
+      dtype = ldpc::DT_I8; // one family: identical results in the reference
+      break;
+    default:
+      set_error("LDPC decoder type %d (flooded schedule) is not implemented in the HIP engine", (int)type);
+      return SRSRAN_ERROR_INVALID_INPUTS;
   }
   *hh = nullptr;
   BgDims d;
@@ -121,6 +148,8 @@ extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran
   h->E        = d.E;
   h->max_iter = max_nof_iter ? (int)max_nof_iter : 10; // ldpc_decoder.c:42,579
   h->sf       = (int)(scaling_fctr * 100);             // ldpc_dec_c.c:150 (float * int, truncated)
+  h->sf_f     = scaling_fctr;
+  h->dtype    = dtype;
   h->max_cw   = max_nof_cw;
   std::vector<uint8_t>  col(d.E);
   std::vector<uint16_t> shift(d.E);
@@ -144,6 +173,10 @@ extern "C" int srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** hh, srsran
   PHY_HIP_CHECK(hipMalloc(&h->d_edges, d.E * sizeof(int)), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_edges, ed.data(), d.E * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  if (dtype != ldpc::DT_I8) {
+    const size_t es = dtype == ldpc::DT_F32 ? 4 : 2;
+    PHY_HIP_CHECK(hipMalloc(&h->d_c2v, (size_t)(max_nof_cw ? max_nof_cw : 1) * d.E * ls * es), SRSRAN_ERROR);
+  }
   *hh = h;
   return SRSRAN_SUCCESS;
 }
@@ -155,14 +188,45 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
   }
   hipFree(h->d_row_start);
   hipFree(h->d_edges);
+  hipFree(h->d_c2v);
   delete h;
 }
+
+static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                          uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
+                          void* stream);
 
 extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride,
                                          uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
                                          uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream)
 {
-  if (!h || !d_llrs || !d_message || n_cw == 0) {
+  if (h && h->dtype != ldpc::DT_I8) {
+    set_error("ldpc batch: this object decodes %s LLRs, use srsran_hip_ldpc_batch_run_typed", h->dtype == ldpc::DT_F32 ? "float" : "int16");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, d_iter_msgs, nullptr, stream);
+}
+
+extern "C" int srsran_hip_ldpc_batch_run_typed(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride,
+                                               uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
+                                               uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream)
+{
+  return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, d_iter_msgs, nullptr, stream);
+}
+
+// debug/parity entry point (tests bind it by name): also returns the a-posteriori soft bits (n_cw x bgN*Z elements)
+extern "C" SRSRAN_API int srsran_hip_ldpc_batch_run_dbg(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride,
+                                                        uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
+                                                        uint32_t cdwd_rm_length, void* d_soft, void* stream)
+{
+  return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, nullptr, d_soft, stream);
+}
+
+static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                          uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
+                          void* stream)
+{
+  if (!h || !d_llrs || !d_message || n_cw == 0 || (h->dtype != ldpc::DT_I8 && n_cw > (h->max_cw ? h->max_cw : 1))) {
     set_error("ldpc batch: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -198,6 +262,10 @@ extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_
   p.max_iter   = h->max_iter;
   p.sf         = h->sf;
   p.n_cw       = (int)n_cw;
+  p.dtype      = h->dtype;
+  p.sf_f       = h->sf_f;
+  p.c2v_ws     = h->d_c2v;
+  p.soft_out   = d_soft;
   p.cpb        = Z <= 128 ? (int)(256 / Z) : 1;
   // keep the workgroup's LDS slab under 64 KB when several words share it
   while (p.cpb > 1 && ldpc::lds_bytes(p) > 64 * 1024) {
@@ -213,6 +281,7 @@ namespace {
 struct LdpcCtx {
   srsran_hip_ldpc_batch_t* b      = nullptr;
   hipStream_t              stream = nullptr;
+  size_t                   esz    = 1;       // bytes per LLR (1 / 2 / 4)
   int8_t*                  d_llr  = nullptr;
   uint8_t*                 d_msg  = nullptr;
   uint8_t*                 d_iter = nullptr;
@@ -263,7 +332,23 @@ void ldpc_ctx_free(void* o)
   }
 }
 
+int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc);
+
 int ldpc_decode_c(void* o, const int8_t* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc)
+{
+  return ldpc_decode_any(o, llrs, message, cdwd_rm_length, crc);
+}
+int ldpc_decode_s(void* o, const int16_t* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc)
+{
+  return ldpc_decode_any(o, llrs, message, cdwd_rm_length, crc);
+}
+int ldpc_decode_f(void* o, const float* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc)
+{
+  return ldpc_decode_any(o, llrs, message, cdwd_rm_length, crc);
+}
+
+// LDPC_DECODER_TEMPLATE (ldpc_decoder.c:44-104) for any of the three LLR types
+int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_rm_length, srsran_crc_t* crc)
 {
   auto*    q = reinterpret_cast<srsran_ldpc_decoder_t*>(o);
   LdpcCtx* c = reinterpret_cast<LdpcCtx*>(q->ptr);
@@ -273,9 +358,9 @@ int ldpc_decode_c(void* o, const int8_t* llrs, uint8_t* message, uint32_t cdwd_r
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
   const uint32_t msg_bytes = (liftK + 7) / 8;
-  memcpy(c->h_llr, llrs, n_llr);
-  PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr, hipMemcpyHostToDevice, c->stream), -1);
-  if (srsran_hip_ldpc_batch_run(c->b, c->d_llr, n_llr, c->d_msg, liftK, 1, cdwd_rm_length, crc ? c->d_iter : nullptr, c->stream)) {
+  memcpy(c->h_llr, llrs, n_llr * c->esz);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr * c->esz, hipMemcpyHostToDevice, c->stream), -1);
+  if (srsran_hip_ldpc_batch_run_typed(c->b, c->d_llr, n_llr, c->d_msg, liftK, 1, cdwd_rm_length, crc ? c->d_iter : nullptr, c->stream)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
     return -1;
   }
@@ -321,13 +406,20 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
     fprintf(stderr, "Base Graph BG%d does not exist\n", args->bg + 1);
     return -1;
   }
+  size_t esz = 1;
   switch (args->type) {
+    case SRSRAN_LDPC_DECODER_F:
+      esz = 4;
+      break;
+    case SRSRAN_LDPC_DECODER_S:
+      esz = 2;
+      break;
     case SRSRAN_LDPC_DECODER_C:
     case SRSRAN_LDPC_DECODER_C_AVX2:
     case SRSRAN_LDPC_DECODER_C_AVX512:
       break; // one family: int8 layered min-sum, identical results in the reference
     default:
-      fprintf(stderr, "[srsran_phy_hip] LDPC decoder type %d (float / int16 / flooded) is not implemented in the HIP engine\n", args->type);
+      fprintf(stderr, "[srsran_phy_hip] LDPC decoder type %d (flooded schedule) is not implemented in the HIP engine\n", args->type);
       return -1;
   }
   memset(q, 0, sizeof(*q));
@@ -360,13 +452,21 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
   auto* c = new LdpcCtx;
   q->ptr  = c;
   q->free = ldpc_ctx_free;
-  q->decode_c = ldpc_decode_c;
+  c->esz  = esz;
+  // one decode entry point per object, as init_f / init_s / init_c register them (ldpc_decoder.c:170-260)
+  if (esz == 4) {
+    q->decode_f = ldpc_decode_f;
+  } else if (esz == 2) {
+    q->decode_s = ldpc_decode_s;
+  } else {
+    q->decode_c = ldpc_decode_c;
+  }
   const uint32_t n_llr = q->liftN - 2 * q->ls, msg_bytes = (q->liftK + 7) / 8;
-  bool ok = srsran_hip_ldpc_batch_create(&c->b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, 1) == SRSRAN_SUCCESS &&
+  bool ok = srsran_hip_ldpc_batch_create_typed(&c->b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, 1, args->type) == SRSRAN_SUCCESS &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipMalloc(&c->d_llr, n_llr) == hipSuccess && hipMalloc(&c->d_msg, q->liftK) == hipSuccess &&
+            hipMalloc(&c->d_llr, n_llr * esz) == hipSuccess && hipMalloc(&c->d_msg, q->liftK) == hipSuccess &&
             hipMalloc(&c->d_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess &&
-            hipHostMalloc(&c->h_llr, n_llr) == hipSuccess && hipHostMalloc(&c->h_msg, q->liftK) == hipSuccess &&
+            hipHostMalloc(&c->h_llr, n_llr * esz) == hipSuccess && hipHostMalloc(&c->h_msg, q->liftK) == hipSuccess &&
             hipHostMalloc(&c->h_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess;
   if (!ok) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_init: %s\n", get_error());
@@ -387,7 +487,7 @@ extern "C" void srsran_ldpc_decoder_free(srsran_ldpc_decoder_t* q)
 extern "C" int srsran_ldpc_decoder_decode_f(srsran_ldpc_decoder_t* q, const float* llrs, uint8_t* message, uint32_t cdwd_rm_length)
 {
   if (!q->decode_f) {
-    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_f: float decoder not implemented in the HIP engine\n");
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_f: the object was not initialised as SRSRAN_LDPC_DECODER_F\n");
     return -1;
   }
   return q->decode_f(q, llrs, message, cdwd_rm_length, NULL);
@@ -396,7 +496,7 @@ extern "C" int srsran_ldpc_decoder_decode_f(srsran_ldpc_decoder_t* q, const floa
 extern "C" int srsran_ldpc_decoder_decode_s(srsran_ldpc_decoder_t* q, const int16_t* llrs, uint8_t* message, uint32_t cdwd_rm_length)
 {
   if (!q->decode_s) {
-    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_s: int16 decoder not implemented in the HIP engine\n");
+    fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_decode_s: the object was not initialised as SRSRAN_LDPC_DECODER_S\n");
     return -1;
   }
   return q->decode_s(q, llrs, message, cdwd_rm_length, NULL);

@@ -23,12 +23,88 @@ namespace ldpc {
 
 #define LDPC_MAX_DEG 19 // BG1 rows 0-3; BG2 max is 10
 
+// Message arithmetic of the three reference decoders (same layered schedule, ldpc_decoder.c:44-104):
+//   Pol8  : ldpc_dec_c.c   int8,  messages |.| <= 63,    soft bits +-127 = infinity
+//   Pol16 : ldpc_dec_s.c   int16, messages |.| <= 16383, soft bits +-32767 = infinity
+//   PolF  : ldpc_dec_f.c   float, no clipping; only IEEE sub / mul / add, evaluated unfused so that the
+//                          result is bit-identical to the reference's
+struct Pol8 {
+  typedef int8_t T;
+  typedef int    A;
+  static constexpr bool kC2vInLds = true;
+  static __device__ __forceinline__ A min_init() { return 127; }
+  static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_c.c:338-363
+  {
+    if (s >= 127) {
+      return 127;
+    }
+    if (s <= -127) {
+      return -127;
+    }
+    const A x = s - c;
+    return x > 63 ? 63 : (x < -63 ? -63 : x);
+  }
+  static __device__ __forceinline__ A mag(A x) { return x < 0 ? -x : x; }
+  static __device__ __forceinline__ bool neg(A x) { return x < 0; }
+  static __device__ __forceinline__ A scale(A m, int sf, float) { return m * sf / 100; } // :275-278
+  static __device__ __forceinline__ A negate(A m) { return -m; }
+  static __device__ __forceinline__ A soft(A cn, A v) // :308-315
+  {
+    const A t = cn + v;
+    return t > 63 ? 127 : (t < -63 ? -127 : t);
+  }
+};
+
+struct Pol16 {
+  typedef int16_t T;
+  typedef int     A;
+  static constexpr bool kC2vInLds = false;
+  static __device__ __forceinline__ A min_init() { return 32767; }
+  static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_s.c:338-363
+  {
+    if (s >= 32767) {
+      return 32767;
+    }
+    if (s <= -32767) {
+      return -32767;
+    }
+    const A x = s - c;
+    return x > 16383 ? 16383 : (x < -16383 ? -16383 : x);
+  }
+  static __device__ __forceinline__ A mag(A x) { return x < 0 ? -x : x; }
+  static __device__ __forceinline__ bool neg(A x) { return x < 0; }
+  static __device__ __forceinline__ A scale(A m, int sf, float) { return (A)(int16_t)(m * sf / 100); } // :275-276
+  static __device__ __forceinline__ A negate(A m) { return -m; }
+  static __device__ __forceinline__ A soft(A cn, A v) // :303-311
+  {
+    const A t = cn + v;
+    return t > 16383 ? 32767 : (t < -16383 ? -32767 : t);
+  }
+};
+
+struct PolF {
+  typedef float T;
+  typedef float A;
+  static constexpr bool kC2vInLds = false;
+  static __device__ __forceinline__ A min_init() { return INFINITY; }
+  static __device__ __forceinline__ A v2c(A s, A c) { return __fsub_rn(s, c); } // ldpc_dec_f.c:172-181
+  static __device__ __forceinline__ A mag(A x) { return fabsf(x); }
+  static __device__ __forceinline__ bool neg(A x) { return !(x >= 0); } // (v2c >= 0) ? 1 : -1
+  static __device__ __forceinline__ A scale(A m, int, float sf) { return __fmul_rn(m, sf); } // :246
+  static __device__ __forceinline__ A negate(A m) { return -m; }
+  static __device__ __forceinline__ A soft(A cn, A v) { return __fadd_rn(cn, v); } // :278
+};
+
 // One layer (base-graph row) for one lifted check node: all operand loads are issued before the first use
-// so that a layer costs two LDS round trips, not two per edge.
-template <int DEG>
-__device__ __forceinline__ void layer(int8_t* soft, int8_t* c2v, int my_edge, int e0, int c, int Z, int sf, bool active)
+// so that a layer costs two memory round trips, not two per edge.
+template <int DEG, class POL>
+__device__ __forceinline__ void layer(typename POL::T* soft, typename POL::T* c2v, int my_edge, int e0, int c, int Z, int sf,
+                                      float sf_f, bool active)
 {
-  int ed[DEG], idx[DEG], sb[DEG], co[DEG], v[DEG];
+  typedef typename POL::A A;
+  typedef typename POL::T T;
+  int ed[DEG], idx[DEG];
+  A   sb[DEG], co[DEG], v[DEG];
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     ed[i] = __builtin_amdgcn_readlane(my_edge, i);
@@ -44,21 +120,15 @@ __device__ __forceinline__ void layer(int8_t* soft, int8_t* c2v, int my_edge, in
     sb[i]  = soft[idx[i]];
     co[i]  = c2v[(e0 + i) * Z + c];
   }
-  int min0 = 127, min1 = 127, pos = -1, neg = 0;
-  // var->check (ldpc_dec_c.c:338-363) fused with the check-node scan (:245-262)
+  A    min0 = POL::min_init(), min1 = POL::min_init();
+  int  pos = -1;
+  bool neg = false;
+  // var->check fused with the check-node scan (ldpc_dec_c.c:245-262 and its _s / _f siblings)
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    int x;
-    if (sb[i] >= 127) {
-      x = 127;
-    } else if (sb[i] <= -127) {
-      x = -127;
-    } else {
-      x = sb[i] - co[i];
-      x = x > 63 ? 63 : (x < -63 ? -63 : x);
-    }
-    v[i]        = x;
-    const int a = x < 0 ? -x : x;
+    const A x = POL::v2c(sb[i], co[i]);
+    v[i]      = x;
+    const A a = POL::mag(x);
     if (a < min0) {
       min1 = min0;
       min0 = a;
@@ -66,25 +136,25 @@ __device__ __forceinline__ void layer(int8_t* soft, int8_t* c2v, int my_edge, in
     } else if (a < min1) {
       min1 = a;
     }
-    neg ^= (x < 0);
+    neg ^= POL::neg(x);
   }
-  // check->var (:265-281) and soft-bit update (:286-321)
-  const int s0 = min0 * sf / 100;
-  const int s1 = min1 * sf / 100;
+  // check->var and soft-bit update
+  const A s0 = POL::scale(min0, sf, sf_f);
+  const A s1 = POL::scale(min1, sf, sf_f);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    const int mag  = (i == pos) ? s1 : s0;
-    const int sneg = neg ^ (v[i] < 0); // sign = product of all signs * own sign (v >= 0 counts as +)
-    const int cn   = sneg ? -mag : mag;
-    c2v[(e0 + i) * Z + c] = (int8_t)cn;
-    int tt = cn + v[i];
-    tt     = tt > 63 ? 127 : (tt < -63 ? -127 : tt);
-    soft[idx[i]] = (int8_t)tt;
+    const A    mag  = (i == pos) ? s1 : s0;
+    const bool sneg = neg ^ POL::neg(v[i]); // sign = product of all signs * own sign (v >= 0 counts as +)
+    const A    cn   = sneg ? POL::negate(mag) : mag;
+    c2v[(e0 + i) * Z + c] = (T)cn;
+    soft[idx[i]]          = (T)POL::soft(cn, v[i]);
   }
 }
 
+template <class POL>
 __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
 {
+  typedef typename POL::T T;
   extern __shared__ int8_t lds[];
   const int Z   = p.Z;
   const int t   = threadIdx.x;
@@ -93,18 +163,20 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
   const int cw  = blockIdx.x * p.cpb + cwl;
   const bool active = (cwl < p.cpb) && (cw < p.n_cw);
 
-  const int liftN = p.bgN * Z;
-  const int liftK = p.bgK * Z;
-  int8_t*   soft  = lds + (size_t)cwl * (liftN + p.n_edges * Z);
-  int8_t*   c2v   = soft + liftN;
-  int*      graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * (liftN + p.n_edges * Z) + 15) & ~(size_t)15));
+  const int    liftN   = p.bgN * Z;
+  const int    liftK   = p.bgK * Z;
+  const size_t per_cw  = (size_t)liftN + (POL::kC2vInLds ? (size_t)p.n_edges * Z : 0); // elements of T in LDS per code word
+  T*           soft    = reinterpret_cast<T*>(lds) + (size_t)cwl * per_cw;
+  // check-to-variable messages: LDS for int8 (121 KB at BG1 Z=384), a per-code-word HBM slab for the wider types
+  T*   c2v   = POL::kC2vInLds ? soft + liftN : reinterpret_cast<T*>(p.c2v_ws) + (size_t)(active ? cw : 0) * p.n_edges * Z;
+  int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw * sizeof(T) + 15) & ~(size_t)15));
   for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
     graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
   }
 
   // init_ldpc_dec_c (ldpc_dec_c.c:170-188): punctured nodes 0,1 start at 0, all c2v at 0
   if (active) {
-    const int8_t* llr = p.llrs + (size_t)cw * p.llr_stride;
+    const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cw * p.llr_stride;
     soft[c]     = 0;
     soft[Z + c] = 0;
     for (int n = 2; n < p.bgN; n++) {
@@ -117,6 +189,7 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
   __syncthreads();
 
   const int      sf        = p.sf;
+  const float    sf_f      = p.sf_f;
   const int      msg_bytes = (liftK + 7) >> 3;
   // the graph description lives in LDS behind the code-word state (wave-uniform broadcast reads):
   //   row_start[l] : first edge of layer l ;  edges[e] = (col * Z) | shift << 16
@@ -134,7 +207,7 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
       switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer<D>(soft, c2v, my_edge, e0, c, Z, sf, active);                                                                \
+    layer<D, POL>(soft, c2v, my_edge, e0, c, Z, sf, sf_f, active);                                                     \
     break;
         LDPC_CASE(1)
         LDPC_CASE(2)
@@ -179,20 +252,33 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
     for (int i = c; i < liftK; i += Z) {
       m[i] = soft[i] < 0;
     }
+    if (p.soft_out) { // parity aid: a-posteriori soft bits
+      T* so = reinterpret_cast<T*>(p.soft_out) + (size_t)cw * liftN;
+      for (int n = 0; n < p.bgN; n++) {
+        so[n * Z + c] = soft[n * Z + c];
+      }
+    }
   }
+}
+
+static size_t elem_size(int dtype)
+{
+  return dtype == DT_F32 ? 4 : (dtype == DT_I16 ? 2 : 1);
 }
 
 size_t lds_bytes(const Params& p)
 {
-  return (((size_t)p.cpb * (size_t)(p.bgN + p.n_edges) * p.Z + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges) * sizeof(int);
+  const size_t per_cw = ((size_t)p.bgN + (p.dtype == DT_I8 ? (size_t)p.n_edges : 0)) * p.Z * elem_size(p.dtype);
+  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges) * sizeof(int);
 }
 
-hipError_t launch(const Params& p, hipStream_t stream)
+template <class POL>
+static hipError_t launch_pol(const Params& p, hipStream_t stream)
 {
   const size_t lds = lds_bytes(p);
   static bool  attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel<POL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       return e;
@@ -202,8 +288,22 @@ hipError_t launch(const Params& p, hipStream_t stream)
   int threads = p.cpb * p.Z;
   threads     = ((threads + 63) / 64) * 64;
   dim3 grid((p.n_cw + p.cpb - 1) / p.cpb);
-  hipLaunchKernelGGL(ldpc_layered_kernel, grid, dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL(ldpc_layered_kernel<POL>, grid, dim3(threads), lds, stream, p);
   return hipGetLastError();
+}
+
+hipError_t launch(const Params& p, hipStream_t stream)
+{
+  switch (p.dtype) {
+    case DT_I8:
+      return launch_pol<Pol8>(p, stream);
+    case DT_I16:
+      return launch_pol<Pol16>(p, stream);
+    case DT_F32:
+      return launch_pol<PolF>(p, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
 }
 
 } // namespace ldpc

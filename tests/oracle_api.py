@@ -172,6 +172,24 @@ def ldpc_decode(bg, ls, llrs, scaling_fctr, max_iter, cdwd_rm_length=None, crc=N
     return out, rets
 
 
+def ldpc_decode_fs(bg, ls, llrs, scaling_fctr, max_iter, cdwd_rm_length=None, want_soft=False):
+    """srsran_ldpc_decoder_decode_f (float32 llrs) / _decode_s (int16 llrs)"""
+    g = ldpc_graph(bg, ls)
+    K, N = g.bgK * ls, g.bgN * ls
+    llrs = np.ascontiguousarray(llrs)
+    assert llrs.dtype in (np.float32, np.int16)
+    fn = orc().orc_ldpc_decode_f if llrs.dtype == np.float32 else orc().orc_ldpc_decode_s
+    fn.argtypes = [C.POINTER(LdpcGraph), C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    n_cw = llrs.shape[0]
+    out = np.zeros((n_cw, K), np.uint8)
+    soft = np.zeros((n_cw, N), llrs.dtype)
+    for i in range(n_cw):
+        rc = fn(C.byref(g), scaling_fctr, max_iter, P(llrs[i]), P(out[i]), N - 2 * ls if cdwd_rm_length is None else cdwd_rm_length,
+                P(soft[i]))
+        assert rc == (max_iter if max_iter else 10)
+    return (out, soft) if want_soft else out
+
+
 # ------------------------------------------------------------------ OFDM helpers
 def ofdm_cfg(nof_prb, symbol_sz=0, cp_ext=0, normalize=0, freq_shift_f=0.0, rx_window_offset=0.0, keep_dc=0, mbsfn_region=0):
     return OfdmCfg(nof_prb, symbol_sz, cp_ext, normalize, freq_shift_f, rx_window_offset, keep_dc, mbsfn_region)

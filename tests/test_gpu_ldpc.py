@@ -95,7 +95,7 @@ def test_handle_api_and_crc_early_stop(hiplib):
         assert not q.ptr
     # decoder families the HIP engine does not reproduce must be refused loudly
     q = capi.LdpcDecoder()
-    args = capi.LdpcDecoderArgs(capi.LDPC_F, 0, 16, 0.8, 10)
+    args = capi.LdpcDecoderArgs(capi.LDPC_C_FLOOD, 0, 16, 0.8, 10)
     assert lib.srsran_ldpc_decoder_init(C.byref(q), C.byref(args)) == -1
 
 
@@ -126,3 +126,68 @@ def test_full_size_roundtrip_property(hiplib):
     big = np.tile(llrs, (n_cw // 4, 1))
     out = S.LdpcBatch(0, 384, 0.8, 20, n_cw).decode(big)
     assert np.array_equal(out, np.tile(msgs, (n_cw // 4, 1)))
+
+
+def _fs_llrs(bg, Z, n_cw, snr, seed, kind):
+    """float32 / int16 LLRs from the same channel as the int8 ones; int16 ones large enough to reach the 15-bit clip"""
+    _, l8 = O.ldpc_llrs(bg, Z, n_cw, snr, seed=seed, clip=127)
+    rng = np.random.default_rng(seed)
+    if kind == "f":
+        return (l8 * rng.uniform(0.3, 0.35, l8.shape)).astype(np.float32)
+    return (l8.astype(np.int32) * (180 if seed % 2 else 3)).clip(-32767, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("kind", ["f", "s"])
+@pytest.mark.parametrize("bg", [0, 1])
+def test_float_and_int16_decoders_all_lifting_sizes(hiplib, bg, kind):
+    """SRSRAN_LDPC_DECODER_F / _S (ldpc_dec_f.c, ldpc_dec_s.c): bit-exact messages AND bit-exact a-posteriori soft
+    bits (the float decoder only uses IEEE subtract / multiply / add, evaluated unfused on the device)"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    typ = capi.LDPC_F if kind == "f" else capi.LDPC_S
+    for i, Z in enumerate(ALL_LS):
+        snr, sf, nit = ((2.0, 0.8, 10), (0.0, 0.75, 5), (-2.0, 0.8, 3))[i % 3]
+        n_cw = 3 if Z > 64 else 7
+        llrs = _fs_llrs(bg, Z, n_cw, snr, Z * 2 + bg, kind)
+        ref, ref_soft = O.ldpc_decode_fs(bg, Z, llrs, sf, nit, want_soft=True)
+        out, soft = S.LdpcBatch(bg, Z, sf, nit, n_cw, typ).decode(llrs, want_soft=True)
+        assert np.array_equal(ref, out), "BG%d Z=%d: %d words differ" % (bg + 1, Z, np.any(ref != out, axis=1).sum())
+        assert np.array_equal(ref_soft.view(np.uint8), soft.view(np.uint8)), "BG%d Z=%d soft bits" % (bg + 1, Z)
+
+
+@pytest.mark.parametrize("kind", ["f", "s"])
+def test_float_and_int16_rate_matched_and_handle(hiplib, kind):
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    typ = capi.LDPC_F if kind == "f" else capi.LDPC_S
+    bg, Z = 0, 384
+    g = O.ldpc_graph(bg, Z)
+    N = g.bgN * Z
+    llrs = _fs_llrs(bg, Z, 3, 1.0, 7, kind)
+    for rm in (N - 2 * Z, 5, (g.bgK + 7) * Z + 1):
+        for sf in (0.8, 0.5, 1.0):
+            ref = O.ldpc_decode_fs(bg, Z, llrs, sf, 6, rm)
+            assert np.array_equal(ref, S.LdpcBatch(bg, Z, sf, 6, 3, typ).decode(llrs, rm)), (rm, sf)
+    # drop-in handle: one decode entry point per object type (ldpc_decoder.c:170-260)
+    q = capi.LdpcDecoder()
+    args = capi.LdpcDecoderArgs(typ, bg, Z, 0.8, 6)
+    assert lib.srsran_ldpc_decoder_init(C.byref(q), C.byref(args)) == 0
+    dec = lib.srsran_ldpc_decoder_decode_f if kind == "f" else lib.srsran_ldpc_decoder_decode_s
+    other = lib.srsran_ldpc_decoder_decode_s if kind == "f" else lib.srsran_ldpc_decoder_decode_f
+    ref = O.ldpc_decode_fs(bg, Z, llrs, 0.8, 6)
+    for i in range(3):
+        msg = np.zeros(g.bgK * Z, np.uint8)
+        assert dec(C.byref(q), O.P(llrs[i]), O.P(msg), N - 2 * Z) == 6
+        assert np.array_equal(msg, ref[i])
+    assert other(C.byref(q), O.P(llrs[0]), O.P(msg), N - 2 * Z) == -1
+    assert lib.srsran_ldpc_decoder_decode_c(C.byref(q), O.P(llrs[0]), O.P(msg), N - 2 * Z) == -1
+    lib.srsran_ldpc_decoder_free(C.byref(q))
+    # wrong entry point for the batch object type
+    b = S.LdpcBatch(bg, Z, 0.8, 6, 1, typ)
+    d = S.DeviceBuffer(N * 4)
+    assert lib.srsran_hip_ldpc_batch_run(b._h, d.ptr, N, d.ptr, N, 1, N, None, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
+    h = C.c_void_p()
+    assert lib.srsran_hip_ldpc_batch_create_typed(C.byref(h), 0, 16, 0.8, 10, 1, capi.LDPC_C_FLOOD) == capi.SRSRAN_ERROR_INVALID_INPUTS

@@ -34,6 +34,14 @@ def test_turbo_8bit_reference_outputs():
             assert np.array_equal(got, outs[nit - 1]), (key, nit)
 
 
+def test_ldpc_float_int16_reference_outputs():
+    d = np.load(os.path.join(G, "ldpc_fs_ref.npz"))
+    for key in d["cases"]:
+        bg, Z, nit, rm, sf100 = [int(v) for v in d[str(key) + "_par"]]
+        got = O.ldpc_decode_fs(bg, Z, d[str(key) + "_llr"], sf100 / 100.0, nit, rm)
+        assert np.array_equal(np.packbits(got, axis=1), d[str(key) + "_out"]), key
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

@@ -11,6 +11,7 @@ No reference source text is stored.
   tests/golden/turbo8_ref.npz  reference 8-bit turbo decoders (sse8 / avx8 window) on seeded int8 LLRs
   tests/golden/syncglue_ref.npz  reference srsran_cfo_correct / srsran_cp_synch outputs on seeded inputs
   tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
+  tests/golden/ldpc_fs_ref.npz reference float / int16 LDPC decoder outputs on seeded LLRs
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -117,6 +118,36 @@ def turbo8():
     print("turbo8_ref.npz", os.path.getsize(os.path.join(OUT, "turbo8_ref.npz")))
 
 
+def ldpc_fs():
+    """reference float (type 0) and int16 (type 1) layered decoders on seeded LLRs"""
+    d = {}
+    cases = []
+    for bg, Z in ((0, 384), (1, 384), (0, 2), (1, 9), (0, 112), (1, 208), (0, 24)):
+        for snr, sf, nit in ((2.0, 0.8, 10), (0.0, 0.75, 4)):
+            g = O.ldpc_graph(bg, Z)
+            K, N = g.bgK * Z, g.bgN * Z
+            _, l8 = O.ldpc_llrs(bg, Z, 2, snr, seed=Z + bg * 1000 + 5, clip=127)
+            rng = np.random.default_rng(Z)
+            rm = N - 2 * Z if nit == 10 else (g.bgK + 9) * Z + 3
+            for typ, llrs in ((0, (l8 * rng.uniform(0.3, 0.35, l8.shape)).astype(np.float32)),
+                              (1, (l8.astype(np.int32) * 180).clip(-32767, 32767).astype(np.int16))):
+                dec = C.create_string_buffer(4096)
+                a = Args(typ, bg, Z, sf, nit)
+                assert ref.srsran_ldpc_decoder_init(dec, C.byref(a)) == 0
+                o = np.zeros((2, K), np.uint8)
+                fn = ref.srsran_ldpc_decoder_decode_f if typ == 0 else ref.srsran_ldpc_decoder_decode_s
+                for i in range(2):
+                    assert fn(dec, P(llrs[i]), P(o[i]), rm) == nit
+                ref.srsran_ldpc_decoder_free(dec)
+                key = "t%d_bg%d_z%d_it%d" % (typ, bg, Z, nit)
+                d[key + "_llr"], d[key + "_out"] = llrs, np.packbits(o, axis=1)
+                d[key + "_par"] = np.array([bg, Z, nit, rm, int(sf * 100)], dtype=np.int32)
+                cases.append(key)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "ldpc_fs_ref.npz"), **d)
+    print("ldpc_fs_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_fs_ref.npz")))
+
+
 def syncglue():
     """reference srsran_cfo_correct and srsran_cp_synch (cfo.c, cp.c, cexptab.c need no FFT library) on seeded inputs"""
     d = {}
@@ -205,6 +236,6 @@ def ldpc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "syncglue"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "syncglue": syncglue}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue}[name]()

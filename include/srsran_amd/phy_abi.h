@@ -60,6 +60,10 @@ typedef struct SRSRAN_API {
 } srsran_dft_plan_t;
 
 SRSRAN_API int  srsran_dft_plan(srsran_dft_plan_t* plan, int dft_points, srsran_dft_dir_t dir, srsran_dft_mode_t type);
+/* real <-> half-complex (FFTW_R2HC / FFTW_HC2R layout), dft.h:76,88,121 */
+SRSRAN_API int  srsran_dft_plan_r(srsran_dft_plan_t* plan, int dft_points, srsran_dft_dir_t dir);
+SRSRAN_API int  srsran_dft_replan_r(srsran_dft_plan_t* plan, int new_dft_points);
+SRSRAN_API void srsran_dft_run_r(srsran_dft_plan_t* plan, const float* in, float* out);
 SRSRAN_API int  srsran_dft_plan_c(srsran_dft_plan_t* plan, int dft_points, srsran_dft_dir_t dir);
 SRSRAN_API int  srsran_dft_plan_guru_c(srsran_dft_plan_t* plan, int dft_points, srsran_dft_dir_t dir, cf_t* in_buffer,
                                        cf_t* out_buffer, int istride, int ostride, int how_many, int idist, int odist);

@@ -239,6 +239,9 @@ def lib():
             "srsran_ofdm_set_freq_shift": (i32, [C.POINTER(Ofdm), C.c_float]),
             "srsran_ofdm_set_normalize": (None, [C.POINTER(Ofdm), C.c_bool]),
             "srsran_dft_plan_c": (i32, [C.POINTER(DftPlan), i32, i32]),
+            "srsran_dft_plan_r": (i32, [C.POINTER(DftPlan), i32, i32]),
+            "srsran_dft_replan_r": (i32, [C.POINTER(DftPlan), i32]),
+            "srsran_dft_run_r": (None, [C.POINTER(DftPlan), vp, vp]),
             "srsran_dft_plan": (i32, [C.POINTER(DftPlan), i32, i32, i32]),
             "srsran_dft_plan_guru_c": (i32, [C.POINTER(DftPlan), i32, i32, vp, vp, i32, i32, i32, i32, i32]),
             "srsran_dft_replan": (i32, [C.POINTER(DftPlan), i32]),

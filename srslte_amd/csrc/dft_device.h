@@ -18,10 +18,13 @@ struct Params {
   int         radix[16];
   int         backward;
   int         mirror, dc, db;
-  float       norm; // 1/sqrt(N) or 0
+  float       norm; // 1/sqrt(N) or 0 (real transforms: 1/N, dft_fftw.c:375)
+  int         real_mode; // 0 complex; 1 real -> half-complex (FFTW_R2HC); 2 half-complex -> real (FFTW_HC2R)
 };
 
 hipError_t launch(const Params& p, hipStream_t stream);
+hipError_t launch_large_twiddle(void* y, int N1, int N2, bool backward, hipStream_t stream);
+hipError_t launch_large_reorder(const void* in, void* out, int N, bool backward, bool dc, hipStream_t stream);
 
 } // namespace dft
 } // namespace phyhip

@@ -26,6 +26,12 @@ struct DftCtx {
   cf_t*       h_out = nullptr; // pinned staging
   size_t      cap_in = 0, cap_out = 0;
   hipStream_t stream = nullptr;
+  // N > 4096: four-step decomposition N = N1 * N2, both <= 4096 (N1 transforms of length N2 after N2 of length N1)
+  int     N1 = 0, N2 = 0;
+  int     npass1 = 0, npass2 = 0, radix1[16] = {}, radix2[16] = {};
+  float2* d_tw1 = nullptr;
+  float2* d_tw2 = nullptr;
+  float2* d_tmp[2] = {nullptr, nullptr};
   // guru geometry
   cf_t* g_in = nullptr;
   cf_t* g_out = nullptr;
@@ -50,15 +56,85 @@ void factorize(int N, int* radix, int* npass)
   *npass = (n == 1) ? np : 0; // anything else: direct evaluation
 }
 
+int upload_twiddles(float2** d, int N)
+{
+  std::vector<std::complex<float>> tw(N);
+  for (int i = 0; i < N; i++) {
+    double a = -2.0 * M_PI * (double)i / (double)N;
+    tw[i]    = std::complex<float>((float)cos(a), (float)sin(a));
+  }
+  (void)hipFree(*d);
+  *d = nullptr;
+  PHY_HIP_CHECK(hipMalloc(d, N * sizeof(float2)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpy(*d, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+bool smooth(int n)
+{
+  for (int f : {2, 3, 5}) {
+    while (n % f == 0) {
+      n /= f;
+    }
+  }
+  return n == 1;
+}
+
+// N > DFT_MAX_POINTS: split N = N1 * N2 with both factors within the single-kernel range, preferring factors the
+// Stockham passes handle (2^a 3^b 5^c) over ones that fall back to direct evaluation
+int ctx_set_large(DftCtx* c, int N)
+{
+  int best = 0;
+  for (int pass = 0; pass < 2 && !best; pass++) {
+    for (int d = DFT_MAX_POINTS; d >= 2; d--) {
+      if (N % d == 0 && N / d <= DFT_MAX_POINTS && (pass == 1 || (smooth(d) && smooth(N / d)))) {
+        best = d;
+        break;
+      }
+    }
+    if (!best && pass == 0) {
+      for (int d = DFT_MAX_POINTS; d >= 2; d--) { // at least one smooth factor
+        if (N % d == 0 && N / d <= DFT_MAX_POINTS && smooth(d)) {
+          best = d;
+          break;
+        }
+      }
+    }
+  }
+  if (!best) {
+    set_error("DFT length %d has no factorisation N1 x N2 with both factors <= %d", N, DFT_MAX_POINTS);
+    fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  c->N  = N;
+  c->N1 = best;
+  c->N2 = N / best;
+  factorize(c->N1, c->radix1, &c->npass1);
+  factorize(c->N2, c->radix2, &c->npass2);
+  if (upload_twiddles(&c->d_tw1, c->N1) || upload_twiddles(&c->d_tw2, c->N2)) {
+    return SRSRAN_ERROR;
+  }
+  for (auto& t : c->d_tmp) {
+    (void)hipFree(t);
+    t = nullptr;
+    PHY_HIP_CHECK(hipMalloc(&t, (size_t)N * sizeof(float2)), SRSRAN_ERROR);
+  }
+  return SRSRAN_SUCCESS;
+}
+
 int ctx_set_size(DftCtx* c, int N)
 {
-  if (N <= 0 || N > DFT_MAX_POINTS) {
-    set_error("DFT length %d is outside the range supported by the HIP engine (1..%d)", N, DFT_MAX_POINTS);
+  if (N <= 0 || (long)N > (long)DFT_MAX_POINTS * DFT_MAX_POINTS) {
+    set_error("DFT length %d is outside the range supported by the HIP engine (1..%d^2)", N, DFT_MAX_POINTS);
     fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
     return SRSRAN_ERROR;
   }
   if (c->N == N) {
     return SRSRAN_SUCCESS;
+  }
+  c->N1 = c->N2 = 0;
+  if (N > DFT_MAX_POINTS) {
+    return ctx_set_large(c, N);
   }
   c->N = N;
   factorize(N, c->radix, &c->npass);
@@ -112,6 +188,10 @@ void ctx_free(DftCtx* c)
     return;
   }
   (void)hipFree(c->d_tw);
+  (void)hipFree(c->d_tw1);
+  (void)hipFree(c->d_tw2);
+  (void)hipFree(c->d_tmp[0]);
+  (void)hipFree(c->d_tmp[1]);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_out);
   (void)hipHostFree(c->h_in);
@@ -142,7 +222,54 @@ void fill_params(dft::Params* p, const DftCtx* c, const void* d_in, void* d_out,
   p->mirror   = mirror;
   p->dc       = dc;
   p->db       = db;
-  p->norm     = norm ? 1.0f / sqrtf((float)c->N) : 0.0f;
+  p->norm      = norm ? 1.0f / sqrtf((float)c->N) : 0.0f;
+  p->real_mode = 0;
+}
+
+// N = N1 * N2 > 4096: x[n1 N2 + n2] -> N2 transforms of length N1 (stride N2) -> twiddle w_N^(k1 n2) -> N1 transforms
+// of length N2 -> X[k1 + N1 k2].  mirror / dc act on the full length through a separate re-ordering pass.
+int run_large(const DftCtx* c, const float2* d_in, float2* d_out, bool backward, bool mirror, bool dc, bool norm, bool db,
+              hipStream_t st)
+{
+  const float2* src = d_in;
+  if (mirror && backward) {
+    PHY_HIP_CHECK(dft::launch_large_reorder(d_in, c->d_tmp[1], c->N, true, dc, st), SRSRAN_ERROR);
+    src = c->d_tmp[1];
+  }
+  dft::Params p = {};
+  p.in       = src;
+  p.out      = c->d_tmp[0];
+  p.twiddle  = c->d_tw1;
+  p.N        = c->N1;
+  p.npass    = c->npass1;
+  memcpy(p.radix, c->radix1, sizeof(p.radix));
+  p.how_many = c->N2;
+  p.istride  = c->N2;
+  p.ostride  = c->N2;
+  p.idist    = 1;
+  p.odist    = 1;
+  p.backward = backward;
+  PHY_HIP_CHECK(dft::launch(p, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(dft::launch_large_twiddle(c->d_tmp[0], c->N1, c->N2, backward, st), SRSRAN_ERROR);
+  const bool post = mirror && !backward;
+  p.in       = c->d_tmp[0];
+  p.out      = post ? c->d_tmp[1] : d_out;
+  p.twiddle  = c->d_tw2;
+  p.N        = c->N2;
+  p.npass    = c->npass2;
+  memcpy(p.radix, c->radix2, sizeof(p.radix));
+  p.how_many = c->N1;
+  p.istride  = 1;
+  p.ostride  = c->N1;
+  p.idist    = c->N2;
+  p.odist    = 1;
+  p.norm     = norm ? 1.0f / sqrtf((float)c->N) : 0.0f;
+  p.db       = db;
+  PHY_HIP_CHECK(dft::launch(p, st), SRSRAN_ERROR);
+  if (post) {
+    PHY_HIP_CHECK(dft::launch_large_reorder(c->d_tmp[1], d_out, c->N, false, dc, st), SRSRAN_ERROR);
+  }
+  return SRSRAN_SUCCESS;
 }
 
 DftCtx* ctx_of(srsran_dft_plan_t* plan)
@@ -188,8 +315,47 @@ extern "C" int srsran_dft_plan(srsran_dft_plan_t* plan, const int dft_points, sr
   if (mode == SRSRAN_DFT_COMPLEX) {
     return srsran_dft_plan_c(plan, dft_points, dir);
   }
-  fprintf(stderr, "[srsran_phy_hip] srsran_dft_plan: real (r2r) transforms are not implemented in the HIP engine\n");
-  return -1;
+  return srsran_dft_plan_r(plan, dft_points, dir);
+}
+
+// dft_fftw.c:255-277: real <-> half-complex transform (FFTW_R2HC forward, FFTW_HC2R backward)
+extern "C" int srsran_dft_plan_r(srsran_dft_plan_t* plan, const int dft_points, srsran_dft_dir_t dir)
+{
+  DftCtx* c = ctx_new(dft_points);
+  if (!c) {
+    return -1;
+  }
+  plan->in  = calloc((size_t)dft_points, sizeof(float));
+  plan->out = calloc((size_t)dft_points, sizeof(float));
+  plan->p   = c;
+  plan_defaults(plan, dft_points, dir, false);
+  plan->mode = SRSRAN_REAL;
+  return 0;
+}
+
+extern "C" int srsran_dft_replan_r(srsran_dft_plan_t* plan, const int new_dft_points)
+{
+  return srsran_dft_replan_c(plan, new_dft_points); // same engine; the transform kind is a run-time flag
+}
+
+extern "C" void srsran_dft_run_r(srsran_dft_plan_t* plan, const float* in, float* out)
+{
+  DftCtx* c = ctx_of(plan);
+  if (!c || c->N1 || ctx_reserve(c, plan->size, plan->size)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_dft_run_r: plan not initialised (real transforms: up to %d points)\n", DFT_MAX_POINTS);
+    return;
+  }
+  const size_t bytes = (size_t)plan->size * sizeof(float);
+  memcpy(c->h_in, in, bytes);
+  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
+  dft::Params p;
+  fill_params(&p, c, c->d_in, c->d_out, !plan->forward, false, false, false, plan->db);
+  p.real_mode = plan->forward ? 1 : 2;
+  p.norm      = plan->norm ? 1.0f / (float)plan->size : 0.0f; // dft_fftw.c:374-377: 1/N, not 1/sqrt(N)
+  PHY_HIP_CHECK_VOID(dft::launch(p, c->stream));
+  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+  PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_out, bytes);
 }
 
 extern "C" int srsran_dft_replan_c(srsran_dft_plan_t* plan, const int new_dft_points)
@@ -211,7 +377,7 @@ extern "C" int srsran_dft_replan(srsran_dft_plan_t* plan, const int new_dft_poin
     if (plan->mode == SRSRAN_DFT_COMPLEX) {
       return srsran_dft_replan_c(plan, new_dft_points);
     }
-    return -1;
+    return srsran_dft_replan_r(plan, new_dft_points);
   }
   fprintf(stderr, "DFT: Error calling replan: new_dft_points (%d) must be lower or equal dft_size passed initially (%d)\n",
           new_dft_points, plan->init_size);
@@ -302,10 +468,18 @@ static void run_contiguous(srsran_dft_plan_t* plan, const cf_t* in, cf_t* out, b
   memcpy(c->h_out, out, bytes);
   PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
   PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_out, c->h_out, bytes, hipMemcpyHostToDevice, c->stream));
-  dft::Params p;
-  fill_params(&p, c, c->d_in, c->d_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
-              options && plan->db);
-  PHY_HIP_CHECK_VOID(dft::launch(p, c->stream));
+  if (c->N1) {
+    if (run_large(c, c->d_in, c->d_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
+                  options && plan->db, c->stream)) {
+      fprintf(stderr, "[srsran_phy_hip] srsran_dft_run: %s\n", get_error());
+      return;
+    }
+  } else {
+    dft::Params p;
+    fill_params(&p, c, c->d_in, c->d_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
+                options && plan->db);
+    PHY_HIP_CHECK_VOID(dft::launch(p, c->stream));
+  }
   PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_out, bytes);
@@ -326,7 +500,7 @@ extern "C" void srsran_dft_run(srsran_dft_plan_t* plan, const void* in, void* ou
   if (plan->mode == SRSRAN_DFT_COMPLEX) {
     srsran_dft_run_c(plan, (const cf_t*)in, (cf_t*)out);
   } else {
-    fprintf(stderr, "[srsran_phy_hip] srsran_dft_run: real transforms are not implemented in the HIP engine\n");
+    srsran_dft_run_r(plan, (const float*)in, (float*)out);
   }
 }
 
@@ -338,6 +512,26 @@ extern "C" void srsran_dft_run_guru_c(srsran_dft_plan_t* plan)
   }
   DftCtx* c = ctx_of(plan);
   if (!c || !c->g_in || !c->g_out) {
+    return;
+  }
+  if (c->N1) {
+    // one contiguous transform longer than 4096 points goes through the four-step path
+    if (c->how_many != 1 || c->istride != 1 || c->ostride != 1) {
+      fprintf(stderr, "[srsran_phy_hip] srsran_dft_run_guru_c: strided / batched plans are limited to %d points\n", DFT_MAX_POINTS);
+      return;
+    }
+    const size_t bytes = (size_t)plan->size * sizeof(cf_t);
+    if (ctx_reserve(c, plan->size, plan->size)) {
+      return;
+    }
+    memcpy(c->h_in, c->g_in, bytes);
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
+    if (run_large(c, c->d_in, c->d_out, !plan->forward, false, false, false, false, c->stream)) {
+      return;
+    }
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
+    memcpy(c->g_out, c->h_out, bytes);
     return;
   }
   const int    N       = plan->size;
@@ -384,6 +578,10 @@ extern "C" int srsran_hip_dft_batch_create(srsran_hip_dft_batch_t** hh, int dft_
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
   *hh       = nullptr;
+  if (dft_points > DFT_MAX_POINTS) {
+    set_error("dft batch: batched transforms are limited to %d points", DFT_MAX_POINTS);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
   DftCtx* c = ctx_new(dft_points);
   if (!c) {
     return SRSRAN_ERROR;

@@ -128,9 +128,21 @@ __global__ __launch_bounds__(256) void dft_kernel(const Params p)
   const float2* in = reinterpret_cast<const float2*>(p.in) + (long)blockIdx.x * p.idist;
   float2*       out = reinterpret_cast<float2*>(p.out) + (long)blockIdx.x * p.odist;
 
+  // real transforms (srsran_dft_run_r, dft_fftw.c:365-384; FFTW's r2r half-complex layout: hc[k] = Re X[k] for
+  // k <= N/2, hc[N-k] = Im X[k] for 0 < k < N/2): evaluated through the complex engine
+  const float* rin  = reinterpret_cast<const float*>(p.in) + (long)blockIdx.x * p.idist;
+  float*       rout = reinterpret_cast<float*>(p.out) + (long)blockIdx.x * p.odist;
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    const int s = pre_index(p, n);
-    a[n]        = s < 0 ? make_float2(0.f, 0.f) : in[(long)s * p.istride];
+    if (p.real_mode == 1) {
+      a[n] = make_float2(rin[n], 0.f);
+    } else if (p.real_mode == 2) {
+      const int k = n <= N / 2 ? n : N - n; // Hermitian symmetry: X[N-k] = conj(X[k])
+      float     re = rin[k], im = (k == 0 || 2 * k == N) ? 0.f : rin[N - k];
+      a[n]         = make_float2(re, n <= N / 2 ? im : -im);
+    } else {
+      const int s = pre_index(p, n);
+      a[n]        = s < 0 ? make_float2(0.f, 0.f) : in[(long)s * p.istride];
+    }
   }
   __syncthreads();
   if (p.npass > 0) {
@@ -162,6 +174,24 @@ __global__ __launch_bounds__(256) void dft_kernel(const Params p)
     a         = b;
     b         = t;
   }
+  if (p.real_mode) {
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      float v;
+      if (p.real_mode == 1) {
+        v = j <= N / 2 ? a[j].x : a[N - j].y;
+      } else {
+        v = a[j].x;
+      }
+      if (p.norm != 0.0f) {
+        v *= p.norm;
+      }
+      if (p.db) {
+        v = 10.0f * log10f(v); // srsran_convert_power_to_dB
+      }
+      rout[j] = v;
+    }
+    return;
+  }
   for (int j = threadIdx.x; j < N; j += blockDim.x) {
     const int s = post_index(p, j);
     if (s >= 0) {
@@ -175,6 +205,62 @@ __global__ __launch_bounds__(256) void dft_kernel(const Params p)
       out[(long)j * p.ostride] = v;
     }
   }
+}
+
+// ---- N > 4096: four-step decomposition N = N1 * N2 driven from the host (dft_host.cpp) with the kernel above for
+// the two sets of short transforms; these two kernels supply the twiddle step and the mirror / dc re-ordering
+// of srsran_dft_run_c on the full length.
+
+// y[k1 * N2 + n2] *= e^{-+ j 2 pi k1 n2 / N}
+__global__ void large_twiddle_kernel(float2* y, int N1, int N2, int backward)
+{
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long N = (long)N1 * N2;
+  if (i >= N) {
+    return;
+  }
+  const long k1 = i / N2, n2 = i - k1 * N2;
+  double     sn, cs;
+  sincospi(-2.0 * (double)((k1 * n2) % N) / (double)N, &sn, &cs);
+  if (backward) {
+    sn = -sn;
+  }
+  const float2 v = y[i];
+  y[i] = make_float2((float)(v.x * cs - v.y * sn), (float)(v.x * sn + v.y * cs));
+}
+
+// copy_pre (backward) or copy_post (forward) of dft_fftw.c:297-320 on N elements
+__global__ void large_reorder_kernel(const float2* in, float2* out, int N, int backward, int dc)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) {
+    return;
+  }
+  Params q;
+  q.N        = N;
+  q.mirror   = 1;
+  q.dc       = dc;
+  q.backward = backward;
+  const int s = backward ? pre_index(q, j) : post_index(q, j);
+  if (backward) {
+    out[j] = s < 0 ? make_float2(0.f, 0.f) : in[s];
+  } else if (s >= 0) {
+    out[j] = in[s];
+  }
+}
+
+hipError_t launch_large_twiddle(void* y, int N1, int N2, bool backward, hipStream_t stream)
+{
+  const long N = (long)N1 * N2;
+  hipLaunchKernelGGL(large_twiddle_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, (float2*)y, N1, N2, backward ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_large_reorder(const void* in, void* out, int N, bool backward, bool dc, hipStream_t stream)
+{
+  hipLaunchKernelGGL(large_reorder_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float2*)in, (float2*)out, N,
+                     backward ? 1 : 0, dc ? 1 : 0);
+  return hipGetLastError();
 }
 
 hipError_t launch(const Params& p, hipStream_t stream)

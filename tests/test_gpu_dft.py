@@ -58,8 +58,7 @@ def test_replan_and_limits(hiplib):
     hiplib.srsran_dft_run_c(C.byref(plan), O.P(x), O.P(y))
     assert _err(y, _oracle(x, 512, 0, 0, 0, 0)) < TOL
     hiplib.srsran_dft_plan_free(C.byref(plan))
-    assert hiplib.srsran_dft_plan_c(C.byref(plan), 8192, 0) == -1  # beyond the engine's range: loud failure
-    assert hiplib.srsran_dft_plan(C.byref(plan), 64, 0, 1) == -1  # real transforms are not provided
+    assert hiplib.srsran_dft_plan_c(C.byref(plan), 2 * 4099, 0) == -1  # > 4096 with a prime factor > 4096: loud failure
 
 
 def test_guru_strided_batch(hiplib):
@@ -145,3 +144,75 @@ def test_batch_sc_fdma_config4(hiplib):
     for i in (0, 311, how - 1):
         assert _err(y[i], _oracle(x[i], n, 1, 0, 0, 1)) < TOL
     hiplib.srsran_hip_dft_batch_free(h)
+
+
+@pytest.mark.parametrize("n", [8, 12, 62, 127, 128, 1200, 2048, 4096])
+def test_real_plans(hiplib, n):
+    """srsran_dft_plan_r / srsran_dft_run_r (dft_fftw.c:255-277,365-384): FFTW's real <-> half-complex transforms.
+    The reference delegates the layout to FFTW (hc[k] = Re X[k], k <= n/2; hc[n-k] = Im X[k], 0 < k < n/2)."""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    X = np.fft.fft(x.astype(np.float64))
+    hc = np.zeros(n)
+    hc[:n // 2 + 1] = X[:n // 2 + 1].real
+    for k in range(1, (n + 1) // 2):
+        hc[n - k] = X[k].imag
+    fwd, bwd = capi.DftPlan(), capi.DftPlan()
+    assert lib.srsran_dft_plan_r(C.byref(fwd), n, capi.DFT_FORWARD) == 0
+    assert lib.srsran_dft_plan(C.byref(bwd), n, capi.DFT_BACKWARD, 1) == 0  # SRSRAN_REAL through the generic entry
+    out = np.zeros(n, np.float32)
+    lib.srsran_dft_run_r(C.byref(fwd), O.P(x), O.P(out))
+    assert np.abs(out - hc).max() < 1e-4 * np.sqrt(n) * max(1.0, np.abs(hc).max() / np.sqrt(n))
+    back = np.zeros(n, np.float32)
+    lib.srsran_dft_run_r(C.byref(bwd), O.P(hc.astype(np.float32)), O.P(back))
+    assert np.abs(back / n - x).max() < 1e-4  # unnormalised inverse: n * x
+    lib.srsran_dft_plan_set_norm(C.byref(bwd), True)  # real transforms scale by 1/n, not 1/sqrt(n) (dft_fftw.c:375)
+    lib.srsran_dft_run(C.byref(bwd), O.P(hc.astype(np.float32)), O.P(back))
+    assert np.abs(back - x).max() < 1e-4
+    if n >= 16:
+        assert lib.srsran_dft_replan(C.byref(fwd), n // 2) == 0
+        lib.srsran_dft_run_r(C.byref(fwd), O.P(x[:n // 2].copy()), O.P(out))
+        assert abs(out[0] - x[:n // 2].sum()) < 1e-3
+    lib.srsran_dft_plan_free(C.byref(fwd))
+    lib.srsran_dft_plan_free(C.byref(bwd))
+
+
+@pytest.mark.parametrize("n", [8192, 9728, 30720, 65536, 309248, 5 * 4093])
+def test_large_lengths_four_step(hiplib, n):
+    """N > 4096 (e.g. the reference's PSS convolution lengths frame + fft: 9728 = 2^9 19, 309248 = 2^11 151): four-step
+    decomposition N1 x N2 on top of the single-kernel engine, with the mirror / dc / norm options of srsran_dft_run_c"""
+    from srslte_amd import capi
+
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for backward, mirror, dc, norm in ((0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0), (1, 1, 1, 1), (0, 1, 0, 1)):
+        plan = capi.DftPlan()
+        assert hiplib.srsran_dft_plan_c(C.byref(plan), n, backward) == 0
+        hiplib.srsran_dft_plan_set_mirror(C.byref(plan), bool(mirror))
+        hiplib.srsran_dft_plan_set_dc(C.byref(plan), bool(dc))
+        hiplib.srsran_dft_plan_set_norm(C.byref(plan), bool(norm))
+        y = np.full(n, 9 + 9j, np.complex64)
+        hiplib.srsran_dft_run_c(C.byref(plan), O.P(x), O.P(y))
+        X = x.astype(np.complex128)
+        if mirror and backward:  # copy_pre, dft_fftw.c:297-308
+            h = n // 2
+            t = np.zeros(n, np.complex128)
+            t[dc:n - h] = X[h:n - dc]
+            t[n - h:] = X[:h]
+            X = t
+        Y = np.fft.ifft(X) * n if backward else np.fft.fft(X)
+        if norm:
+            Y = Y / np.sqrt(n)
+        want = Y
+        if mirror and not backward:  # copy_post, :310-320
+            h = (n + 1) // 2
+            want = np.full(n, 9 + 9j, np.complex128)
+            want[:n - h] = Y[h:]
+            want[n - h:n - dc] = Y[dc:h]
+        scale = np.sqrt(np.mean(np.abs(want) ** 2))
+        assert np.abs(y - want).max() < 2e-4 * max(1.0, scale), (n, backward, mirror, dc, norm)
+        hiplib.srsran_dft_plan_free(C.byref(plan))

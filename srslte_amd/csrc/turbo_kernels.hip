@@ -394,6 +394,78 @@ __device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32
   }
 }
 
+// Fast input extraction for natural-order int16 LLRs [s p0 p1]xK (what srsran_tdec_run_all gets with
+// srsran_tdec_force_not_sb): the stream is sub-block major (the 3W LLRs of a sub-block are contiguous) while the
+// decoder wants step-major data spread over lanes, so every code block of the wave is staged through LDS in chunks of
+// NBK 8-step blocks: the 64 lanes copy the NB contiguous runs of 48*NBK bytes with 8-byte loads (each wave-level load
+// covers >= 256 contiguous bytes), then lane (p', g) assembles the blocked dwords of sub-block pair p' for two blocks
+// and stores them into the slots of the lane that owns that pair.  Needs W % 8 == 0 and 8-byte aligned code blocks.
+template <int LPC, class AR>
+__device__ __forceinline__ void extract_input_natural16(const short* in_wave, uint32_t in_stride, int n_cb_left, uint32_t K,
+                                                        uint32_t long_sb, uint32_t nblk, int lane, uint32_t* S, uint32_t* P0,
+                                                        uint32_t* P1, short* TL_wave, uint2* stage)
+{
+  constexpr int NB  = 2 * LPC;
+  constexpr int CPW = 64 / LPC;
+  constexpr int NBK = 256 / NB;  // blocks per chunk: NB runs of 48*NBK bytes = 12 KB of LDS
+  constexpr int RS  = 6 * NBK + 1; // run stride in the LDS image, in 8-byte units (+1: spreads the LDS banks)
+  const int     pp  = lane % LPC, g = lane / LPC;
+  for (int cw = 0; cw < CPW; cw++) {
+    const short* in = in_wave + (size_t)(cw < n_cb_left ? cw : n_cb_left - 1) * in_stride;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += NBK) {
+      const int nbt = (int)(nblk - b0) < NBK ? (int)(nblk - b0) : NBK; // blocks in this chunk
+      const int rl  = 6 * nbt;                                           // run length in 8-byte units
+      for (int i = lane; i < NB * rl; i += 64) {
+        const int    d = i / rl, o = i - d * rl;
+        const uint2* src = reinterpret_cast<const uint2*>(in + 3 * ((size_t)d * long_sb + (size_t)b0 * 8)) + o;
+        stage[d * RS + o] = *src;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int lb = g * 2 + h; // NBK * LPC / 64 == 2 blocks per lane
+        if (lb < nbt) {
+          short r[2][24];
+#pragma unroll
+          for (int dd = 0; dd < 2; dd++) {
+            const uint2* q = stage + (2 * pp + dd) * RS + lb * 6;
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+              const uint2 v    = q[t];
+              r[dd][4 * t]     = (short)(v.x & 0xffffu);
+              r[dd][4 * t + 1] = (short)(v.x >> 16);
+              r[dd][4 * t + 2] = (short)(v.y & 0xffffu);
+              r[dd][4 * t + 3] = (short)(v.y >> 16);
+            }
+          }
+          uint32_t sv[8], y0[8], y1[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            sv[j] = (uint32_t)(uint16_t)AR::conv_in(r[0][3 * j]) | ((uint32_t)(uint16_t)AR::conv_in(r[1][3 * j]) << 16);
+            y0[j] = (uint32_t)(uint16_t)AR::conv_in(r[0][3 * j + 1]) | ((uint32_t)(uint16_t)AR::conv_in(r[1][3 * j + 1]) << 16);
+            y1[j] = (uint32_t)(uint16_t)AR::conv_in(r[0][3 * j + 2]) | ((uint32_t)(uint16_t)AR::conv_in(r[1][3 * j + 2]) << 16);
+          }
+          const uint32_t slot = (b0 + lb) * 64 + cw * LPC + pp;
+          store_block(S, slot, sv);
+          store_block(P0, slot, y0);
+          store_block(P1, slot, y1);
+        }
+      }
+    }
+  }
+  // tail LLRs: lane cw * LPC of every code block
+  if (pp == 0) {
+    const short* in = in_wave + (size_t)(g < n_cb_left ? g : n_cb_left - 1) * in_stride;
+    short*       TL = TL_wave + 16 * g;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      TL[i]     = AR::conv_in(in[3 * K + 2 * i]);
+      TL[3 + i] = AR::conv_in(in[3 * K + 2 * i + 1]);
+      TL[6 + i] = AR::conv_in(in[3 * K + 6 + 2 * i]);
+      TL[9 + i] = AR::conv_in(in[3 * K + 6 + 2 * i + 1]);
+    }
+  }
+}
+
 template <int LPC, class AR>
 __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 {
@@ -431,7 +503,12 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 
   // ---- phase 0: input extraction
   if (p.n_begin == 0) {
-    if (p.in_is8) {
+    const bool fast = !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
+    if (fast) {
+      const int first = blockIdx.x * CPW;
+      extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
+                                       S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
+    } else if (p.in_is8) {
       const signed char* in = reinterpret_cast<const signed char*>(p.input) + (size_t)cb * p.in_stride;
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     } else {

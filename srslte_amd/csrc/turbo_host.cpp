@@ -335,6 +335,9 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     p.n_cb       = (int)n_cb;
     p.sb_layout  = sb_layout;
     p.in_is8     = in_is8 ? 1 : 0;
+    if (getenv("TDEC_DBG_EXTRACT_ONLY")) {
+      p.n_end = 0; // development aid: input extraction + decision only
+    }
     PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   } else {
     turbo::GenParams p;

@@ -73,12 +73,8 @@ struct Ar16 {
   static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return sub(m1, m0); }
   static __device__ __forceinline__ short tadd(short a, short b) { return (short)(a + b); } // tail trellis, plain adds
   static __device__ __forceinline__ short conv_in(int v) { return (short)v; }
-  // extrinsic exchange (turbodecoder_iter.h:108,115 = srsran_vec_sub_sss, wrapping): the stored word is the
-  // processed value; the raw decoder output the decision needs is recovered as E1 + A1 (exact, wrapping)
-  static __device__ __forceinline__ s2 ex_lo(s2 v) { return v; }
-  static __device__ __forceinline__ s2 ex_pack(s2 raw, s2 proc) { return proc; }
+  // extrinsic exchange (turbodecoder_iter.h:108,115): srsran_vec_sub_sss, wrapping
   static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return a - b; }
-  static __device__ __forceinline__ s2 decide(s2 e1, s2 a1, uint32_t n_end) { return n_end >= 2 ? e1 + a1 : e1; }
 };
 
 // Arithmetic of the 8-bit window decoders (WINIMP_IS_SSE8 / AVX8, turbodecoder_win.h:154-300): saturating int8
@@ -110,13 +106,8 @@ struct Ar8 {
     return z > 127 ? (short)127 : (short)(signed char)z;
   }
   static __device__ __forceinline__ short conv_in(int v) { return (short)(signed char)v; } // convert_16_to_8
-  // srsran_vec_sub_bbb saturates (and wraps in the ragged tail of the vector loop), so the raw value cannot
-  // be recovered by adding back: a stored word carries the raw output in its high byte and the processed
-  // one in its low byte
-  static __device__ __forceinline__ s2 ex_lo(s2 v) { return sext8(v); }
-  static __device__ __forceinline__ s2 ex_pack(s2 raw, s2 proc) { return (raw << 8) | (proc & splat(0xff)); }
+  // srsran_vec_sub_bbb: saturating, except in the ragged tail of its 32-byte vector loop where it wraps
   static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return wrap ? sext8(a - b) : clamp8(a - b); }
-  static __device__ __forceinline__ s2 decide(s2 e1, s2 a1, uint32_t n_end) { return ((n_end & 1) ? e1 : a1) >> 8; }
 };
 
 // one backward step, turbodecoder_win.h:626-652
@@ -410,16 +401,70 @@ __device__ __forceinline__ void extract_input_natural16(const short* in_wave, ui
   constexpr int NBK = 256 / NB;  // blocks per chunk: NB runs of 48*NBK bytes = 12 KB of LDS
   constexpr int RS  = 6 * NBK + 1; // run stride in the LDS image, in 8-byte units (+1: spreads the LDS banks)
   const int     pp  = lane % LPC, g = lane / LPC;
-  for (int cw = 0; cw < CPW; cw++) {
-    const short* in = in_wave + (size_t)(cw < n_cb_left ? cw : n_cb_left - 1) * in_stride;
-    for (uint32_t b0 = 0; b0 < nblk; b0 += NBK) {
-      const int nbt = (int)(nblk - b0) < NBK ? (int)(nblk - b0) : NBK; // blocks in this chunk
-      const int rl  = 6 * nbt;                                           // run length in 8-byte units
-      for (int i = lane; i < NB * rl; i += 64) {
-        const int    d = i / rl, o = i - d * rl;
-        const uint2* src = reinterpret_cast<const uint2*>(in + 3 * ((size_t)d * long_sb + (size_t)b0 * 8)) + o;
-        stage[d * RS + o] = *src;
+  // chunks are (code block, block range) pairs; the loads of the next chunk are in flight while the current one is
+  // re-distributed (24 8-byte loads per lane and chunk: NB * 6 * NBK / 64)
+  constexpr int NLD = NB * 6 * NBK / 64;
+  const uint32_t nchunk = (nblk + NBK - 1) / NBK, total = CPW * nchunk;
+  auto chunk_src = [&](uint32_t c, const short*& in, uint32_t& b0, int& nbt) {
+    const int cw = (int)(c % CPW); // block range outermost: the 8 code blocks' 128-byte pieces of a 1 KB line are written back to back
+    in           = in_wave + (size_t)(cw < n_cb_left ? cw : n_cb_left - 1) * in_stride;
+    b0           = (c / CPW) * NBK;
+    nbt          = (int)(nblk - b0) < NBK ? (int)(nblk - b0) : NBK;
+  };
+  auto issue_chunk = [&](uint32_t c, uint2(&rg)[NLD]) {
+    const short* in;
+    uint32_t     b0;
+    int          nbt;
+    chunk_src(c, in, b0, nbt);
+    if (nbt == NBK) { // full chunk: the run length is a compile-time constant (no integer division by a variable)
+      constexpr int rl = 6 * NBK;
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int i = t * 64 + lane, d = i / rl, o = i - d * rl;
+        rg[t]       = *(reinterpret_cast<const uint2*>(in + 3 * ((size_t)d * long_sb + (size_t)b0 * 8)) + o);
       }
+    } else {
+      const int rl = 6 * nbt; // run length in 8-byte units
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int i = t * 64 + lane;
+        if (i < NB * rl) {
+          const int d = i / rl, o = i - d * rl;
+          rg[t]       = *(reinterpret_cast<const uint2*>(in + 3 * ((size_t)d * long_sb + (size_t)b0 * 8)) + o);
+        }
+      }
+    }
+  };
+  uint2 rg[NLD];
+  issue_chunk(0, rg);
+  for (uint32_t c = 0; c < total; c++) {
+    const short* in;
+    uint32_t     b0;
+    int          nbt;
+    chunk_src(c, in, b0, nbt);
+    const int cw = (int)(c % CPW);
+    if (nbt == NBK) {
+      constexpr int rl = 6 * NBK;
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int i = t * 64 + lane, d = i / rl, o = i - d * rl;
+        stage[d * RS + o] = rg[t];
+      }
+    } else {
+      const int rl = 6 * nbt;
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int i = t * 64 + lane;
+        if (i < NB * rl) {
+          const int d = i / rl, o = i - d * rl;
+          stage[d * RS + o] = rg[t];
+        }
+      }
+    }
+    if (c + 1 < total) {
+      issue_chunk(c + 1, rg);
+    }
+    {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int lb = g * 2 + h; // NBK * LPC / 64 == 2 blocks per lane
@@ -496,7 +541,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   uint32_t* P0  = ws + AWG;
   uint32_t* P1  = ws + 2 * AWG;
   uint32_t* A1  = ws + 3 * AWG;
-  uint32_t* E1  = ws + 4 * AWG;
+  uint32_t* D   = ws + 4 * AWG; // decision LLRs of the last half iteration of a launch
   uint32_t* A2  = ws + 5 * AWG;
   uint32_t* CK  = ws + 6 * AWG;
   short*    TL  = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * 64 * 8) + 16 * (lane / LPC); // 12 tail LLRs per block
@@ -565,7 +610,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         ys[j] = from_u(q.y[j]);
         ap[j] = splat(0);
         if (has_app) {
-          ap[j] = AR::ex_lo(from_u(ar[j]));
+          ap[j] = from_u(ar[j]);
           xs[j] = AR::add(ap[j], xs[j]);
         }
       }
@@ -681,10 +726,14 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 
     const uint32_t* lut = dec1 ? p.deint : p.inter; // per (step, destination lane): row | source sub-blocks
     uint32_t*       dst = dec1 ? A2 : A1;
-    // ext1 -= app1 of the next half iteration (turbodecoder_iter.h:115) is applied here, always: the
-    // kernel is resumable and cannot know whether another half iteration follows; the raw LLRs the
-    // decision needs are recovered as E1 + A1 (exact, wrapping).
+    // The subtractions of the NEXT half iteration (turbodecoder_iter.h:108,115) are applied on the way out:
+    //   decoder 1: ext1 -= app1 (the a-priori it just used) before the interleaved copy goes to A2
+    //   decoder 2: app1 = ext2 - ext1 ... and the ext1 value an output pairs with after de-interleaving is the very
+    //              A2 value it had as systematic input at the same step and lane (app2[i] = ext1[inter[i]]), so the
+    //              difference is formed before the permutation and no ext1 array is exchanged at all.
+    // The raw SISO output is only needed by the hard decision: the LAST half iteration of a launch files it in D.
     const bool fuse = dec1 && n >= 2;
+    const bool last = n + 1 == p.n_end;
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
     load_block(CK, 64 + lane, ck);
@@ -692,18 +741,12 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     for (uint32_t b = 0; b < nblk; b++) {
       const int len = (long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
       s2        xs[8], ys[8], ap[8];
-      uint32_t  eg[8];
       if (b + 1 < nblk) {
         issue(b + 1, nxt);
         load_block(CK, (b + 2) * 64 + lane, ckn);
         load_lut(lut, (b + 1) * LPC + pl, trn);
       }
       prep(cur, xs, ys, ap);
-      if (!dec1) {
-        // decoder 2 hands app1 - ext1 to decoder 1.  Decoder 1 filed its ext1 row under the row number its
-        // interleaved image got (below), so the 8 rows needed here are the 8 consecutive rows of this block
-        issue_rows(E1, b, lane, eg);
-      }
       // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point into
       // this lane's private LDS slots (registers are needed for the prefetched operands)
       {
@@ -727,11 +770,11 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           }
         }
       }
-      uint32_t outv[8], e1v[8];
+      uint32_t outv[8], rawv[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         outv[j] = 0;
-        e1v[j]  = 0;
+        rawv[j] = 0;
         if (j < len) {
           const uint4 b0 = Bl[j][0][lane], b1 = Bl[j][1][lane];
           const s2    B[8] = {from_u(b0.x), from_u(b0.y), from_u(b0.z), from_u(b0.w),
@@ -744,32 +787,27 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           s2 proc = llr;
           if (fuse) {
             proc = AR::ex_sub(llr, ap[j], k == wrap_row);
+          } else if (!dec1) {
+            proc = AR::ex_sub(llr, xs[j], (tr[j] & 0xffffu) == wrap_row); // wrap flag: row of the DESTINATION element
           }
           outv[j] = to_u(proc);
-          if (dec1) {
-            e1v[j] = to_u(AR::ex_pack(llr, proc));
-          }
+          rawv[j] = to_u(llr);
         }
-      }
-      uint32_t egr[8];
-      if (!dec1) {
-        rows_to_lane(Tr, lane, eg, egr);
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         if (j < len) {
-          uint32_t       w   = permute_pair<LPC>(outv[j], tr[j] >> 16);
           const uint32_t row = tr[j] & 0xffffu;
-          if (dec1) {
-            // ext1 in natural lane order, filed under the row of its interleaved image: decoder 2 finds the
-            // ext1 values its step-j outputs pair with in row j
-            E1[(size_t)row * 64 + lane] = e1v[j];
-          } else {
-            // app1 - ext1 of the next half iteration (turbodecoder_iter.h:108)
-            const s2 raw = from_u(w);
-            w            = to_u(AR::ex_pack(raw, AR::ex_sub(raw, AR::ex_lo(from_u(egr[j])), row == wrap_row)));
+          dst[(size_t)row * 64 + lane] = permute_pair<LPC>(outv[j], tr[j] >> 16);
+          if (last) {
+            // what tdec_decision_byte reads (turbodecoder.c:370-378), in natural order: ext1 after decoder 1,
+            // the de-interleaved ext2 (= app1 before the subtraction) after decoder 2
+            if (dec1) {
+              D[(size_t)(b * 8 + j) * 64 + lane] = rawv[j];
+            } else {
+              D[(size_t)row * 64 + lane] = permute_pair<LPC>(rawv[j], tr[j] >> 16);
+            }
           }
-          dst[(size_t)row * 64 + lane] = w;
         }
       }
       cur = nxt;
@@ -783,30 +821,26 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   }
 
   // ---- hard decision (turbodecoder.c:370-378 + turbodecoder_win.h:973-993): bit = LLR > 0, MSB first.
-  // Source: app1 after an even number of half iterations, else ext1.  With the fused subtractions both
-  // are E1 + A1 (wrapping) once two half iterations have run; after a single one it is E1.
+  // Source: app1 after an even number of half iterations, else ext1; the last half iteration filed it in D.
   {
-    const bool both = p.n_end >= 2; // A1 has been written
     uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
     short*     o16  = (p.dec_llr && live) ? p.dec_llr + (size_t)cb * K : nullptr;
     if ((long_sb & 7) == 0) {
       const uint32_t bps   = long_sb >> 3; // bytes per sub-block
       const bool     wide  = ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0); // dword stores possible
       uint32_t       w0 = 0, w1 = 0;
+      uint32_t       t[8], tn[8];
+      issue_rows(D, 0, lane, t);
       for (uint32_t b = 0; b < nblk; b++) {
-        uint32_t r[8], r2[8], trd[8];
-        load_lut(p.deint, b * LPC + pl, trd); // ext1 of natural row k is filed under row deint(k)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          r[j] = E1[(size_t)(trd[j] & 0xffffu) * 64 + lane];
+        if (b + 1 < nblk) {
+          issue_rows(D, b + 1, lane, tn);
         }
-        if (both) {
-          load_rows(A1, b, lane, r2);
-        }
+        uint32_t r[8];
+        rows_to_lane(Tr, lane, t, r);
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          s2 v = AR::decide(from_u(r[j]), both ? from_u(r2[j]) : splat(0), p.n_end);
+          const s2 v = from_u(r[j]);
           b0 |= (v.x > 0 ? 0x80u : 0u) >> j;
           b1 |= (v.y > 0 ? 0x80u : 0u) >> j;
           if (o16) { // parity aid: decision LLRs in natural order
@@ -828,22 +862,21 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
           out[(2 * pl) * bps + b]     = (uint8_t)b0;
           out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
         }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          t[j] = tn[j];
+        }
       }
     } else {
-      const short* se = reinterpret_cast<const short*>(E1);
-      const short* sa = reinterpret_cast<const short*>(A1);
+      const short* sd = reinterpret_cast<const short*>(D);
       for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
         uint32_t byte = 0;
-        for (int t = 0; t < 8; t++) {
-          uint32_t nn = jb * 8 + t;
+        for (int tt = 0; tt < 8; tt++) {
+          uint32_t nn = jb * 8 + tt;
           uint32_t d = nn / long_sb, k = nn % long_sb;
           uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
-          // ext1 of natural row k is filed under row deint(k); the table is blocked [k/8][lane of the block][k%8]
-          uint32_t kr = p.deint[((k >> 3) * LPC + (d >> 1)) * 8 + (k & 7)] & 0xffffu;
-          uint32_t ee = (kr * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
-          s2 ve = {se[ee], 0}, va = {both ? sa[e] : (short)0, 0};
-          short v = AR::decide(ve, va, p.n_end).x;
-          byte |= (v > 0 ? 0x80u : 0u) >> t;
+          short    v = sd[e];
+          byte |= (v > 0 ? 0x80u : 0u) >> tt;
           if (o16) {
             o16[nn] = v;
           }

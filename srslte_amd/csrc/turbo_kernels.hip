@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         }
       }
     };
-    Ops cur, nxt;
+    Ops cur, nxt, nx2; // the two main passes keep TWO blocks in flight: HBM latency under load exceeds one block of compute
 
     s2 o[8];
     // ================= backward recursion (turbodecoder_win.h:551-681)
@@ -659,9 +659,12 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       store_block(CK, nblk * 64 + lane, ck);
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
+    if (nblk > 1) {
+      issue(nblk - 2, nxt);
+    }
     for (int b = (int)nblk - 1; b >= 0; b--) {
-      if (b > 0) {
-        issue(b - 1, nxt);
+      if (b > 1) {
+        issue(b - 2, nx2);
       }
       s2 xs[8], ys[8], ap[8];
       prep(cur, xs, ys, ap);
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         }
       }
       cur = nxt;
+      nxt = nx2;
     }
     __syncthreads(); // orders this lane's check-point stores before its loads below
 
@@ -738,11 +742,16 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     uint32_t ck[8], tr[8], ckn[8], trn[8];
     load_block(CK, 64 + lane, ck);
     load_lut(lut, pl, tr);
+    if (nblk > 1) {
+      issue(1, nxt);
+    }
     for (uint32_t b = 0; b < nblk; b++) {
       const int len = (long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
       s2        xs[8], ys[8], ap[8];
+      if (b + 2 < nblk) {
+        issue(b + 2, nx2);
+      }
       if (b + 1 < nblk) {
-        issue(b + 1, nxt);
         load_block(CK, (b + 2) * 64 + lane, ckn);
         load_lut(lut, (b + 1) * LPC + pl, trn);
       }
@@ -811,6 +820,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
         }
       }
       cur = nxt;
+      nxt = nx2;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         ck[i] = ckn[i];

@@ -32,17 +32,13 @@ struct Pol8 {
   typedef int8_t T;
   typedef int    A;
   static constexpr bool kC2vInLds = true;
+  static constexpr bool kIntegerFast = true;
   static __device__ __forceinline__ A min_init() { return 127; }
   static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_c.c:338-363
   {
-    if (s >= 127) {
-      return 127;
-    }
-    if (s <= -127) {
-      return -127;
-    }
-    const A x = s - c;
-    return x > 63 ? 63 : (x < -63 ? -63 : x);
+    const A x = min(max(s - c, -63), 63);
+    const A i = min(max(s, -127), 127); // +-127 propagates as infinity
+    return (s >= 127 || s <= -127) ? i : x;
   }
   static __device__ __forceinline__ A mag(A x) { return x < 0 ? -x : x; }
   static __device__ __forceinline__ bool neg(A x) { return x < 0; }
@@ -59,6 +55,7 @@ struct Pol16 {
   typedef int16_t T;
   typedef int     A;
   static constexpr bool kC2vInLds = false;
+  static constexpr bool kIntegerFast = true;
   static __device__ __forceinline__ A min_init() { return 32767; }
   static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_s.c:338-363
   {
@@ -86,6 +83,7 @@ struct PolF {
   typedef float T;
   typedef float A;
   static constexpr bool kC2vInLds = false;
+  static constexpr bool kIntegerFast = false;
   static __device__ __forceinline__ A min_init() { return INFINITY; }
   static __device__ __forceinline__ A v2c(A s, A c) { return __fsub_rn(s, c); } // ldpc_dec_f.c:172-181
   static __device__ __forceinline__ A mag(A x) { return fabsf(x); }
@@ -119,6 +117,32 @@ __device__ __forceinline__ void layer(typename POL::T* soft, typename POL::T* c2
     idx[i] = (ed[i] & 0xffff) + j;
     sb[i]  = soft[idx[i]];
     co[i]  = c2v[(e0 + i) * Z + c];
+  }
+  if constexpr (POL::kIntegerFast) {
+    // integer decoders: the same update written for the VALU -- second minimum as a median (v_med3_i32), sign
+    // product as the XOR of the messages' sign bits, conditional negation as (m ^ s) - s
+    int min0 = POL::min_init(), min1 = POL::min_init(), pos = -1, sgn = 0;
+#pragma unroll
+    for (int i = 0; i < DEG; i++) {
+      const int x = POL::v2c(sb[i], co[i]);
+      v[i]        = x;
+      const int a = x < 0 ? -x : x;
+      pos         = a < min0 ? i : pos;                 // strict: the first minimum keeps the position
+      min1        = max(min(a, min1), min(max(a, min1), min0)); // second smallest of {a, min0, min1}
+      min0        = min(a, min0);
+      sgn ^= x;
+    }
+    const int s0 = POL::scale(min0, sf, sf_f);
+    const int s1 = POL::scale(min1, sf, sf_f);
+#pragma unroll
+    for (int i = 0; i < DEG; i++) {
+      const int mag = (i == pos) ? s1 : s0;
+      const int m   = (sgn ^ v[i]) >> 31; // all ones when the product of the OTHER signs is negative
+      const int cn  = (mag ^ m) - m;
+      c2v[(e0 + i) * Z + c] = (T)cn;
+      soft[idx[i]]          = (T)POL::soft(cn, v[i]);
+    }
+    return;
   }
   A    min0 = POL::min_init(), min1 = POL::min_init();
   int  pos = -1;
@@ -196,14 +220,22 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
   const int* row_start = graph;
   const int* edges     = graph + 48;
 
+  // the description of a layer (first edge, degree, one edge word per lane) is fetched one layer ahead, so that its
+  // two dependent LDS round trips overlap the arithmetic of the current layer instead of heading every layer
+  const int lane = t & 63;
+  int       e0n  = __builtin_amdgcn_readfirstlane(row_start[0]);
+  int       degn = __builtin_amdgcn_readfirstlane(row_start[1]) - e0n;
+  int       edgn = edges[e0n + (lane < degn ? lane : 0)];
   for (int it = 0; it < p.max_iter; it++) {
     for (int l = 0; l < p.n_layers; l++) {
       // wave-uniform by construction; readfirstlane tells the compiler so (scalar switch, scalar addressing)
-      const int e0  = __builtin_amdgcn_readfirstlane(row_start[l]);
-      const int deg = __builtin_amdgcn_readfirstlane(row_start[l + 1]) - e0;
-      // one LDS read per wave fetches the whole row description; v_readlane broadcasts it into SGPRs
-      const int lane   = t & 63;
-      const int my_edge = edges[e0 + (lane < deg ? lane : 0)];
+      const int e0 = e0n, deg = degn, my_edge = edgn;
+      {
+        const int ln = l + 1 < p.n_layers ? l + 1 : 0;
+        e0n          = __builtin_amdgcn_readfirstlane(row_start[ln]);
+        degn         = __builtin_amdgcn_readfirstlane(row_start[ln + 1]) - e0n;
+        edgn         = edges[e0n + (lane < degn ? lane : 0)];
+      }
       switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \

@@ -27,10 +27,12 @@ struct Params {
   int             cpb; // code words per workgroup
   int             dtype;
   float           sf_f;     // scaling factor of the float decoder
-  void*           c2v_ws;   // int16 / float: n_cw x n_edges x Z check-to-variable messages (HBM)
+  void*           c2v_ws;   // LDPC_MAX_SLOTS x cpb x n_edges x Z check-to-variable messages (HBM, L2 / Infinity Cache resident)
   void*           soft_out; // optional: n_cw x bgN*Z a-posteriori soft bits (parity aid)
 };
 
+#define LDPC_MAX_SLOTS 4096 // resident workgroup slots (256 CUs x up to 4); each owns one c2v slab per code word it holds
+int        grid_slots(const Params& p);
 hipError_t launch(const Params& p, hipStream_t stream);
 size_t     lds_bytes(const Params& p);
 

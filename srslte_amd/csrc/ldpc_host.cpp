@@ -173,9 +173,13 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   PHY_HIP_CHECK(hipMalloc(&h->d_edges, d.E * sizeof(int)), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_edges, ed.data(), d.E * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
-  if (dtype != ldpc::DT_I8) {
-    const size_t es = dtype == ldpc::DT_F32 ? 4 : 2;
-    PHY_HIP_CHECK(hipMalloc(&h->d_c2v, (size_t)(max_nof_cw ? max_nof_cw : 1) * d.E * ls * es), SRSRAN_ERROR);
+  {
+    // one slab of check-to-variable messages per resident workgroup slot and code word it holds (<= 256 / Z words)
+    const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
+    const size_t cpb = ls <= 128 ? 256 / ls : 1;
+    size_t       slots = ((size_t)(max_nof_cw ? max_nof_cw : 1) + cpb - 1) / cpb;
+    slots              = slots < LDPC_MAX_SLOTS ? slots : LDPC_MAX_SLOTS;
+    PHY_HIP_CHECK(hipMalloc(&h->d_c2v, slots * cpb * d.E * ls * es), SRSRAN_ERROR);
   }
   *hh = h;
   return SRSRAN_SUCCESS;
@@ -226,7 +230,7 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
                           void* stream)
 {
-  if (!h || !d_llrs || !d_message || n_cw == 0 || (h->dtype != ldpc::DT_I8 && n_cw > (h->max_cw ? h->max_cw : 1))) {
+  if (!h || !d_llrs || !d_message || n_cw == 0 || n_cw > (h->max_cw ? h->max_cw : 1)) {
     set_error("ldpc batch: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

@@ -29,9 +29,10 @@ namespace ldpc {
 //   PolF  : ldpc_dec_f.c   float, no clipping; only IEEE sub / mul / add, evaluated unfused so that the
 //                          result is bit-identical to the reference's
 struct Pol8 {
-  typedef int8_t T;
-  typedef int    A;
-  static constexpr bool kC2vInLds = true;
+  typedef int8_t  T;
+  typedef int16_t TS; // soft bits are kept as int16 in LDS: byte-wide LDS writes of 4 lanes into one dword serialise
+  typedef int     A;
+  static constexpr bool kC2vInLds = false; // see the kernel: the HBM/L2 slab wins over LDS residency through occupancy
   static constexpr bool kIntegerFast = true;
   static __device__ __forceinline__ A min_init() { return 127; }
   static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_c.c:338-363
@@ -53,6 +54,7 @@ struct Pol8 {
 
 struct Pol16 {
   typedef int16_t T;
+  typedef int16_t TS;
   typedef int     A;
   static constexpr bool kC2vInLds = false;
   static constexpr bool kIntegerFast = true;
@@ -81,6 +83,7 @@ struct Pol16 {
 
 struct PolF {
   typedef float T;
+  typedef float TS;
   typedef float A;
   static constexpr bool kC2vInLds = false;
   static constexpr bool kIntegerFast = false;
@@ -96,11 +99,12 @@ struct PolF {
 // One layer (base-graph row) for one lifted check node: all operand loads are issued before the first use
 // so that a layer costs two memory round trips, not two per edge.
 template <int DEG, class POL>
-__device__ __forceinline__ void layer(typename POL::T* soft, typename POL::T* c2v, int my_edge, int e0, int c, int Z, int sf,
+__device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c2v, int my_edge, int e0, int c, int Z, int sf,
                                       float sf_f, bool active)
 {
-  typedef typename POL::A A;
-  typedef typename POL::T T;
+  typedef typename POL::A  A;
+  typedef typename POL::T  T;
+  typedef typename POL::TS TS;
   int ed[DEG], idx[DEG];
   A   sb[DEG], co[DEG], v[DEG];
 #pragma unroll
@@ -140,7 +144,7 @@ __device__ __forceinline__ void layer(typename POL::T* soft, typename POL::T* c2
       const int m   = (sgn ^ v[i]) >> 31; // all ones when the product of the OTHER signs is negative
       const int cn  = (mag ^ m) - m;
       c2v[(e0 + i) * Z + c] = (T)cn;
-      soft[idx[i]]          = (T)POL::soft(cn, v[i]);
+      soft[idx[i]]          = (TS)POL::soft(cn, v[i]);
     }
     return;
   }
@@ -171,32 +175,46 @@ __device__ __forceinline__ void layer(typename POL::T* soft, typename POL::T* c2
     const bool sneg = neg ^ POL::neg(v[i]); // sign = product of all signs * own sign (v >= 0 counts as +)
     const A    cn   = sneg ? POL::negate(mag) : mag;
     c2v[(e0 + i) * Z + c] = (T)cn;
-    soft[idx[i]]          = (T)POL::soft(cn, v[i]);
+    soft[idx[i]]          = (TS)POL::soft(cn, v[i]);
   }
 }
 
 template <class POL>
 __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
 {
-  typedef typename POL::T T;
+  typedef typename POL::T  T;
+  typedef typename POL::TS TS;
   extern __shared__ int8_t lds[];
   const int Z   = p.Z;
   const int t   = threadIdx.x;
   const int cwl = t / Z;
   const int c   = t - cwl * Z;
-  const int cw  = blockIdx.x * p.cpb + cwl;
-  const bool active = (cwl < p.cpb) && (cw < p.n_cw);
-
-  const int    liftN   = p.bgN * Z;
-  const int    liftK   = p.bgK * Z;
-  const size_t per_cw  = (size_t)liftN + (POL::kC2vInLds ? (size_t)p.n_edges * Z : 0); // elements of T in LDS per code word
-  T*           soft    = reinterpret_cast<T*>(lds) + (size_t)cwl * per_cw;
-  // check-to-variable messages: LDS for int8 (121 KB at BG1 Z=384), a per-code-word HBM slab for the wider types
-  T*   c2v   = POL::kC2vInLds ? soft + liftN : reinterpret_cast<T*>(p.c2v_ws) + (size_t)(active ? cw : 0) * p.n_edges * Z;
-  int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw * sizeof(T) + 15) & ~(size_t)15));
+  const int liftN = p.bgN * Z;
+  const int liftK = p.bgK * Z;
+  // Check-to-variable messages live in a slab per RESIDENT workgroup slot, not per code word: a workgroup walks
+  // over code words (grid-stride) and re-uses its slab, so the slabs of all resident workgroups (~60 MB for BG1
+  // Z=384 int8) stay in L2 / Infinity Cache.  Keeping them in LDS instead (121 KB for int8) would allow a single
+  // 6-wave workgroup per CU, 2 + 2 + 1 + 1 waves on the four SIMDs; measured 74 ms against 62 ms for the int16
+  // decoder that cannot do it.  With only the soft bits in LDS two workgroups share a CU, 3 waves per SIMD.
+  const size_t per_cw = (size_t)liftN; // soft bits (elements of TS) in LDS per code word
+  TS*          soft   = reinterpret_cast<TS*>(lds) + (size_t)cwl * per_cw;
+  T*   c2v   = reinterpret_cast<T*>(p.c2v_ws) + ((size_t)blockIdx.x * p.cpb + (cwl < p.cpb ? cwl : 0)) * p.n_edges * Z;
+  int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw * sizeof(TS) + 15) & ~(size_t)15));
   for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
     graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
   }
+  const int      sf        = p.sf;
+  const float    sf_f      = p.sf_f;
+  const int      msg_bytes = (liftK + 7) >> 3;
+  // the graph description lives in LDS behind the code-word state (wave-uniform broadcast reads):
+  //   row_start[l] : first edge of layer l ;  edges[e] = (col * Z) | shift << 16
+  const int* row_start = graph;
+  const int* edges     = graph + 48;
+
+  for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
+  const int  cw     = cw0 + cwl;
+  const bool active = (cwl < p.cpb) && (cw < p.n_cw);
+  __syncthreads(); // the previous code word's message extraction has finished reading soft[]
 
   // init_ldpc_dec_c (ldpc_dec_c.c:170-188): punctured nodes 0,1 start at 0, all c2v at 0
   if (active) {
@@ -211,14 +229,6 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
     }
   }
   __syncthreads();
-
-  const int      sf        = p.sf;
-  const float    sf_f      = p.sf_f;
-  const int      msg_bytes = (liftK + 7) >> 3;
-  // the graph description lives in LDS behind the code-word state (wave-uniform broadcast reads):
-  //   row_start[l] : first edge of layer l ;  edges[e] = (col * Z) | shift << 16
-  const int* row_start = graph;
-  const int* edges     = graph + 48;
 
   // the description of a layer (first edge, degree, one edge word per lane) is fetched one layer ahead, so that its
   // two dependent LDS round trips overlap the arithmetic of the current layer instead of heading every layer
@@ -287,20 +297,48 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
     if (p.soft_out) { // parity aid: a-posteriori soft bits
       T* so = reinterpret_cast<T*>(p.soft_out) + (size_t)cw * liftN;
       for (int n = 0; n < p.bgN; n++) {
-        so[n * Z + c] = soft[n * Z + c];
+        so[n * Z + c] = (T)soft[n * Z + c];
       }
     }
   }
+  } // code words of this workgroup
 }
+
+size_t lds_bytes(const Params& p);
 
 static size_t elem_size(int dtype)
 {
   return dtype == DT_F32 ? 4 : (dtype == DT_I16 ? 2 : 1);
 }
 
+// Workgroups launched: exactly as many as are resident at once (CUs x workgroups per CU by waves and LDS), so that
+// every slot walks over the same number of code words and no partial round is left at the end (measured on BG1 Z=384:
+// 512-768 slots 61 ms, 1024 slots 77 ms, 256 slots 81 ms).
+int grid_slots(const Params& p)
+{
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    int             dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int waves  = (p.cpb * p.Z + 63) / 64;
+  int       per_cu = 16 / waves;
+  const int by_lds = (int)((160 * 1024) / lds_bytes(p));
+  per_cu           = per_cu < by_lds ? per_cu : by_lds;
+  per_cu           = per_cu < 1 ? 1 : per_cu;
+  int slots        = cus * per_cu;
+  slots            = slots > LDPC_MAX_SLOTS ? LDPC_MAX_SLOTS : slots;
+  if (const char* e = getenv("LDPC_SLOTS")) { // development knob
+    slots = atoi(e) > 0 && atoi(e) <= LDPC_MAX_SLOTS ? atoi(e) : slots;
+  }
+  const int groups = (p.n_cw + p.cpb - 1) / p.cpb;
+  return groups < slots ? groups : slots;
+}
+
 size_t lds_bytes(const Params& p)
 {
-  const size_t per_cw = ((size_t)p.bgN + (p.dtype == DT_I8 ? (size_t)p.n_edges : 0)) * p.Z * elem_size(p.dtype);
+  const size_t per_cw = (size_t)p.bgN * p.Z * (p.dtype == DT_F32 ? 4 : 2); // soft bits: int16 (int8 and int16 decoders) or float
   return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges) * sizeof(int);
 }
 
@@ -319,7 +357,7 @@ static hipError_t launch_pol(const Params& p, hipStream_t stream)
   }
   int threads = p.cpb * p.Z;
   threads     = ((threads + 63) / 64) * 64;
-  dim3 grid((p.n_cw + p.cpb - 1) / p.cpb);
+  dim3 grid(grid_slots(p));
   hipLaunchKernelGGL(ldpc_layered_kernel<POL>, grid, dim3(threads), lds, stream, p);
   return hipGetLastError();
 }

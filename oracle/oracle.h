@@ -63,6 +63,13 @@ int orc_tdec_run_all(const int16_t* input, uint8_t* output, uint32_t nof_iterati
 int orc_tdec_run_all_8bit(const int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb,
                           int impl, int sb_layout, int16_t* dec_llr);
 
+/* turbo rate de-matching, receive side (rm_turbo.c:175-273,390-478).  nof_sb: 0 = natural buffer [d0 d1 d2] x (K+4);
+ * 8 / 16 / 32 = the sub-block layout of the window decoders (syst @0, parity0 @K+32, parity1 @2(K+32), tail @3(K+32)).
+ * table: 3K+12 entries.  rx: output (3K+12, or 3(K+32)+12 for a sub-block layout) is accumulated into (HARQ combining). */
+int orc_rm_turbo_deinter(uint16_t* table, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb);
+int orc_rm_turbo_rx(const int16_t* input, int16_t* output, uint32_t in_len, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb);
+int orc_rm_turbo_rx_8bit(const int8_t* input, int8_t* output, uint32_t in_len, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb);
+
 /* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
 int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);
 

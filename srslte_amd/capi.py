@@ -336,6 +336,14 @@ def lib():
             "srsran_sync_sss_correlation_peak": (C.c_float, [C.POINTER(Sync)]),
             "srsran_sync_sss_available": (C.c_bool, [C.POINTER(Sync)]),
             "srsran_sync_cp_en": (None, [C.POINTER(Sync), C.c_bool]),
+            "srsran_rm_turbo_rx_lut": (i32, [vp, vp, u32, u32, u32]),
+            "srsran_rm_turbo_rx_lut_": (i32, [vp, vp, u32, u32, u32, C.c_bool]),
+            "srsran_rm_turbo_rx_lut_8bit": (i32, [vp, vp, u32, u32, u32]),
+            "srsran_rm_turbo_gentables": (None, []),
+            "srsran_rm_turbo_free_tables": (None, []),
+            "srsran_hip_rm_turbo_table": (i32, [vp, u32, u32, u32]),
+            "srsran_hip_rm_turbo_rx_batch": (i32, [vp, u32, u32, vp, u32, u32, u32, u32, u32, vp]),
+            "srsran_hip_rm_turbo_rx_batch_8bit": (i32, [vp, u32, u32, vp, u32, u32, u32, u32, u32, vp]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
             "srsran_hip_cellsearch_free": (None, [vp]),
             "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),

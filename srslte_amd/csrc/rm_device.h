@@ -1,0 +1,27 @@
+// rm_device.h -- kernel parameter blocks and launchers of rm_kernels.hip (turbo rate de-matching, CRC)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace phyhip {
+namespace rm {
+
+// one rate-matched code block: out[table[k]] += sum_m in[k + m * out_len]  (k + m * out_len < in_len)
+struct RxJob {
+  uint32_t in_offset;  // first soft bit of this code block in the input stream (elements)
+  uint32_t in_len;     // number of received soft bits E
+  uint32_t out_offset; // start of this code block's soft buffer (elements)
+  uint32_t out_len;    // 3K + 12
+  uint32_t table;      // offset of the position table of (K, rv, layout) in the table pool (uint16 elements)
+};
+
+// d_jobs: device array of n_jobs descriptors.  elem8: int8 soft bits (wrapping), else int16.
+hipError_t launch_rx(const void* d_in, void* d_out, const uint16_t* d_tables, const RxJob* d_jobs, int n_jobs, bool elem8,
+                     hipStream_t stream);
+
+// uniform batch: job b = `first` with offsets advanced by b * (in_stride, out_stride); no descriptor array
+hipError_t launch_rx_uniform(const void* d_in, void* d_out, const uint16_t* d_table, const RxJob& first, uint32_t in_stride,
+                             uint32_t out_stride, int n_jobs, bool elem8, hipStream_t stream);
+
+} // namespace rm
+} // namespace phyhip

@@ -1,0 +1,221 @@
+// rm_host.cpp -- host side of the turbo rate de-matching: position tables, device table pool, drop-in + batch API.
+//
+// Mirrors (interface + behaviour) lib/src/phy/fec/turbo/rm_turbo.c of the reference.  The position tables are
+// derived here from TS 36.212 5.1.4.1 directly (sub-block interleavers, bit collection into the circular buffer,
+// selection from k0 skipping the <NULL> entries) rather than from the reference's table builders; the oracle pins
+// both against the compiled reference.
+#include "hip_common.h"
+#include "rm_device.h"
+#include "srsran_amd/phy_sch_abi.h"
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+using namespace phyhip;
+
+namespace {
+
+const uint8_t kColPerm[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30,
+                              1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31}; // 36.212 table 5.1.4-1
+
+// positions, in the receiver's buffer, of the 3(K+4) soft bits of one redundancy version in transmission order
+//   natural buffer (nof_sb == 0): stream s in {0,1,2}, index i in [0, K+4)  ->  3 i + s
+//   decoder layout (nof_sb > 0) : i < K: s (K+32) + (i mod W) nof_sb + i / W with W = K / nof_sb; tail: 3 (K+32) + ...
+std::vector<uint16_t> build_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
+{
+  const int D = (int)K + 4, R = (D + 31) / 32, Kp = 32 * R, ND = Kp - D;
+  // circular buffer w: stream / index of every entry, -1 = <NULL>
+  std::vector<int> w(3 * Kp, -1);
+  for (int k = 0; k < Kp; k++) {
+    const int col = kColPerm[k / R], row = k % R;
+    const int y01 = col + 32 * row;            // sub-block interleaver of d0 and d1
+    const int y2  = (col + 32 * row + 1) % Kp; // and of d2
+    if (y01 >= ND) {
+      w[k]          = 3 * (y01 - ND);
+      w[Kp + 2 * k] = 3 * (y01 - ND) + 1;
+    }
+    if (y2 >= ND) {
+      w[Kp + 2 * k + 1] = 3 * (y2 - ND) + 2;
+    }
+  }
+  const int Ncb = 3 * Kp;
+  const int k0  = R * (2 * ((Ncb + 8 * R - 1) / (8 * R)) * (int)rv + 2);
+  std::vector<uint16_t> t;
+  t.reserve(3 * D);
+  for (int j = 0; (int)t.size() < 3 * D; j++) {
+    const int v = w[(k0 + j) % Ncb];
+    if (v < 0) {
+      continue;
+    }
+    if (!nof_sb) {
+      t.push_back((uint16_t)v);
+    } else if ((uint32_t)v < 3 * K) {
+      const uint32_t s = (uint32_t)v % 3, i = (uint32_t)v / 3, W = K / nof_sb;
+      t.push_back((uint16_t)(s * (K + 32) + (i % W) * nof_sb + i / W));
+    } else {
+      t.push_back((uint16_t)((uint32_t)v - 3 * K + 3 * (K + 32)));
+    }
+  }
+  return t;
+}
+
+// device pool of tables, built on first use
+struct TablePool {
+  std::mutex                       mu;
+  std::map<uint32_t, uint16_t*>    dev;  // key = K | rv << 16 | nof_sb << 20
+  ~TablePool()
+  {
+    for (auto& kv : dev) {
+      (void)hipFree(kv.second);
+    }
+  }
+};
+TablePool g_pool;
+
+const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
+{
+  const uint32_t              key = K | (rv << 16) | (nof_sb << 20);
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto                        it = g_pool.dev.find(key);
+  if (it != g_pool.dev.end()) {
+    return it->second;
+  }
+  std::vector<uint16_t> t = build_table(K, rv, nof_sb);
+  uint16_t*             d = nullptr;
+  if (hipMalloc(&d, t.size() * sizeof(uint16_t)) != hipSuccess ||
+      hipMemcpy(d, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("rm_turbo: cannot place the table of K=%u rv=%u on the device", K, rv);
+    (void)hipFree(d);
+    return nullptr;
+  }
+  g_pool.dev[key] = d;
+  return d;
+}
+
+int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out, uint32_t out_stride, uint32_t n_cb, uint32_t K,
+             uint32_t rv, uint32_t nof_sb, bool elem8, hipStream_t st)
+{
+  const int idx = srsran_cbsegm_cbindex(K);
+  if (!d_in || !d_out || n_cb == 0 || rv > 3 || idx < 0 || (uint32_t)srsran_cbsegm_cbsize(idx) != K ||
+      (nof_sb && (K % nof_sb || (nof_sb != 8 && nof_sb != 16 && nof_sb != 32)))) {
+    set_error("rm_turbo batch: invalid arguments (K=%u rv=%u nof_sb=%u)", K, rv, nof_sb);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  const uint16_t* tab = table_on_device(K, rv, nof_sb);
+  if (!tab) {
+    return SRSRAN_ERROR;
+  }
+  const rm::RxJob first = {0, in_len, 0, 3 * K + 12, 0};
+  PHY_HIP_CHECK(rm::launch_rx_uniform(d_in, d_out, tab, first, in_stride, out_stride, (int)n_cb, elem8, st), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+// host-pointer form: one code block
+template <typename T>
+int rx_host(const T* input, T* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv, uint32_t nof_sb)
+{
+  if (rv >= 4 || cb_idx >= 188) {
+    printf("Invalid inputs rv_idx=%d, cb_idx=%d\n", rv, cb_idx);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  const uint32_t K = (uint32_t)srsran_cbsegm_cbsize(cb_idx);
+  const size_t   n_out = nof_sb ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
+  T *            d_in = nullptr, *d_out = nullptr;
+  int            rc   = SRSRAN_ERROR;
+  if (hipMalloc(&d_in, (in_len ? in_len : 1) * sizeof(T)) == hipSuccess && hipMalloc(&d_out, n_out * sizeof(T)) == hipSuccess &&
+      hipMemcpy(d_in, input, in_len * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(d_out, output, n_out * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) {
+    rc = in_len ? rx_batch(d_in, in_len, in_len, d_out, (uint32_t)n_out, 1, K, rv, nof_sb, sizeof(T) == 1, nullptr) : SRSRAN_SUCCESS;
+    if (rc == SRSRAN_SUCCESS && (hipDeviceSynchronize() != hipSuccess ||
+                                 hipMemcpy(output, d_out, n_out * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess)) {
+      rc = SRSRAN_ERROR;
+    }
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (rc != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_rx_lut: %s\n", get_error());
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" void srsran_rm_turbo_gentables(void) {}
+
+extern "C" void srsran_rm_turbo_free_tables(void)
+{
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  for (auto& kv : g_pool.dev) {
+    (void)hipFree(kv.second);
+  }
+  g_pool.dev.clear();
+}
+
+extern "C" int srsran_rm_turbo_rx_lut_(int16_t* input, int16_t* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv_idx,
+                                       bool enable_input_tdec)
+{
+  // rm_turbo.c:412-421: the decoder layout is used when the 16-bit AUTO decoder for this K is a window decoder
+  const uint32_t nsb = (enable_input_tdec && cb_idx < 188) ? srsran_tdec_autoimp_get_subblocks((uint32_t)srsran_cbsegm_cbsize(cb_idx)) : 0;
+  return rx_host(input, output, in_len, cb_idx, rv_idx, nsb);
+}
+
+extern "C" int srsran_rm_turbo_rx_lut(int16_t* input, int16_t* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv_idx)
+{
+  return srsran_rm_turbo_rx_lut_(input, output, in_len, cb_idx, rv_idx, true);
+}
+
+extern "C" int srsran_rm_turbo_rx_lut_8bit(int8_t* input, int8_t* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv_idx)
+{
+  const uint32_t nsb = cb_idx < 188 ? srsran_tdec_autoimp_get_subblocks_8bit((uint32_t)srsran_cbsegm_cbsize(cb_idx)) : 0;
+  return rx_host(input, output, in_len, cb_idx, rv_idx, nsb);
+}
+
+extern "C" int srsran_hip_rm_turbo_rx_batch(const int16_t* d_input, uint32_t in_stride, uint32_t in_len, int16_t* d_softbuf,
+                                            uint32_t out_stride, uint32_t n_cb, uint32_t long_cb, uint32_t rv_idx,
+                                            uint32_t nof_sb, void* stream)
+{
+  return rx_batch(d_input, in_stride, in_len, d_softbuf, out_stride, n_cb, long_cb, rv_idx, nof_sb, false, (hipStream_t)stream);
+}
+
+extern "C" int srsran_hip_rm_turbo_rx_batch_8bit(const int8_t* d_input, uint32_t in_stride, uint32_t in_len, int8_t* d_softbuf,
+                                                 uint32_t out_stride, uint32_t n_cb, uint32_t long_cb, uint32_t rv_idx,
+                                                 uint32_t nof_sb, void* stream)
+{
+  return rx_batch(d_input, in_stride, in_len, d_softbuf, out_stride, n_cb, long_cb, rv_idx, nof_sb, true, (hipStream_t)stream);
+}
+
+// the position table itself (host memory, 3K+12 entries): what the reference keeps in its static deinterleaver /
+// deinterleaver_sb arrays (rm_turbo.c:77-101)
+extern "C" int srsran_hip_rm_turbo_table(uint16_t* table, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb)
+{
+  const int idx = srsran_cbsegm_cbindex(long_cb);
+  if (!table || rv_idx > 3 || idx < 0 || (uint32_t)srsran_cbsegm_cbsize(idx) != long_cb ||
+      (nof_sb && (long_cb % nof_sb || (nof_sb != 8 && nof_sb != 16 && nof_sb != 32)))) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  std::vector<uint16_t> t = build_table(long_cb, rv_idx, nof_sb);
+  memcpy(table, t.data(), t.size() * sizeof(uint16_t));
+  return SRSRAN_SUCCESS;
+}
+
+// used by the transport-block decoder (sch_host.cpp): device table of (K, rv, layout)
+namespace phyhip {
+namespace rm {
+const uint16_t* device_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
+{
+  return table_on_device(K, rv, nof_sb);
+}
+std::vector<uint16_t> host_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
+{
+  return build_table(K, rv, nof_sb);
+}
+} // namespace rm
+} // namespace phyhip

@@ -74,7 +74,7 @@ REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_of
                     "off_sync_sss_signal": 194096}
 
 
-OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n'
+OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n'
 
 
 def _c_sizes(flags, include, extra=""):
@@ -160,6 +160,24 @@ def test_host_tables_match_oracle(L):
         assert L.srsran_symbol_sz(prb) == O.orc().orc_symbol_sz(prb)
         if prb:
             assert L.srsran_symbol_sz_power2(prb) == O.orc().orc_symbol_sz_power2(prb)
+
+
+def test_rate_matching_tables_match_oracle(L):
+    """the position tables (derived from TS 36.212 5.1.4.1 in the product) equal the restated reference builders
+    (rm_turbo.c:175-273) for every block size, redundancy version and receiver layout"""
+    orc = O.orc()
+    orc.orc_rm_turbo_deinter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    for K in O.tc_sizes():
+        for rv in range(4):
+            for nsb in (0, 8, 16, 32):
+                if nsb and K % nsb:
+                    assert L.srsran_hip_rm_turbo_table(O.P(np.zeros(3 * K + 12, np.uint16)), K, rv, nsb) == -2
+                    continue
+                a, b = np.zeros(3 * K + 12, np.uint16), np.zeros(3 * K + 12, np.uint16)
+                assert L.srsran_hip_rm_turbo_table(O.P(a), K, rv, nsb) == 0
+                assert orc.orc_rm_turbo_deinter(O.P(b), K, rv, nsb) == 0
+                assert np.array_equal(a, b), (K, rv, nsb)
+    assert L.srsran_hip_rm_turbo_table(O.P(a), 41, 0, 0) == -2 and L.srsran_hip_rm_turbo_table(O.P(a), 40, 4, 0) == -2
 
 
 def test_no_gpu_means_loud_failure(L):

@@ -42,6 +42,24 @@ def test_ldpc_float_int16_reference_outputs():
         assert np.array_equal(np.packbits(got, axis=1), d[str(key) + "_out"]), key
 
 
+def test_rate_dematching_reference_outputs():
+    """srsran_rm_turbo_rx_lut_ (natural and decoder layouts) and _8bit of the compiled reference, 288 cases"""
+    d = np.load(os.path.join(G, "rm_ref.npz"))
+    L = O.orc()
+    for fn in (L.orc_rm_turbo_rx, L.orc_rm_turbo_rx_8bit):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    pi = pb = 0
+    for (K, rv, E, mode), crc in zip(d["recs"], d["out_crc"]):
+        K, rv, E = int(K), int(rv), int(E)
+        n_out = 3 * (K + 32) + 12
+        dt = np.int8 if mode == 2 else np.int16
+        x, o = d["in"][pi:pi + E].astype(dt), d["base"][pb:pb + n_out].astype(dt)
+        pi, pb = pi + E, pb + n_out
+        nsb = 0 if mode == 0 else (L.orc_tdec_autoimp_subblocks(K) if mode == 1 else L.orc_tdec_autoimp_subblocks_8bit(K))
+        assert (L.orc_rm_turbo_rx_8bit if mode == 2 else L.orc_rm_turbo_rx)(O.P(x), O.P(o), E, K, rv, nsb) == 0
+        assert zlib.crc32(o.tobytes()) == crc, (K, rv, E, mode)
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

@@ -12,6 +12,7 @@ No reference source text is stored.
   tests/golden/syncglue_ref.npz  reference srsran_cfo_correct / srsran_cp_synch outputs on seeded inputs
   tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
   tests/golden/ldpc_fs_ref.npz reference float / int16 LDPC decoder outputs on seeded LLRs
+  tests/golden/rm_ref.npz      reference srsran_rm_turbo_rx_lut_ / _8bit: seeded inputs, CRC32 of the resulting soft buffers
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -148,6 +149,36 @@ def ldpc_fs():
     print("ldpc_fs_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_fs_ref.npz")))
 
 
+def rm():
+    """reference srsran_rm_turbo_rx_lut_ / _8bit outputs on seeded soft bits (soft buffer pre-loaded, as after an earlier HARQ round)"""
+    ref.srsran_rm_turbo_gentables()
+    ref.srsran_rm_turbo_rx_lut_.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_bool]
+    rng = np.random.default_rng(21)
+    sizes = O.tc_sizes()
+    recs, ins, outs, bases = [], [], [], []
+    for ci in (0, 3, 40, 59, 100, 125, 156, 187):
+        K = sizes[ci]
+        for rv in range(4):
+            for E in (K // 2 + 5, 3 * K + 100, 7 * K + 33):
+                for mode in (0, 1, 2):  # natural int16, decoder layout int16, int8
+                    dt = np.int8 if mode == 2 else np.int16
+                    amp = 60 if mode == 2 else 3000
+                    x = rng.integers(-amp, amp, E).astype(dt)
+                    base = rng.integers(-amp // 8, amp // 8, 3 * (K + 32) + 12).astype(dt)
+                    o = base.copy()
+                    if mode == 2:
+                        assert ref.srsran_rm_turbo_rx_lut_8bit(P(x), P(o), E, ci, rv) == 0
+                    else:
+                        assert ref.srsran_rm_turbo_rx_lut_(P(x), P(o), E, ci, rv, bool(mode)) == 0
+                    recs.append((K, rv, E, mode))
+                    ins.append(x.astype(np.int16))
+                    bases.append(base.astype(np.int16))
+                    outs.append(zlib.crc32(o.tobytes()))
+    d = {"recs": np.array(recs, np.int32), "in": np.concatenate(ins), "base": np.concatenate(bases), "out_crc": np.array(outs, np.uint32)}
+    np.savez_compressed(os.path.join(OUT, "rm_ref.npz"), **d)
+    print("rm_ref.npz", os.path.getsize(os.path.join(OUT, "rm_ref.npz")))
+
+
 def syncglue():
     """reference srsran_cfo_correct and srsran_cp_synch (cfo.c, cp.c, cexptab.c need no FFT library) on seeded inputs"""
     d = {}
@@ -236,6 +267,6 @@ def ldpc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm}[name]()

@@ -43,7 +43,7 @@ def test_ldpc_float_int16_reference_outputs():
 
 
 def test_rate_dematching_reference_outputs():
-    """srsran_rm_turbo_rx_lut_ (natural and decoder layouts) and _8bit of the compiled reference, 288 cases"""
+    """srsran_rm_turbo_rx_lut_ (natural and decoder layouts) and _8bit of the compiled reference"""
     d = np.load(os.path.join(G, "rm_ref.npz"))
     L = O.orc()
     for fn in (L.orc_rm_turbo_rx, L.orc_rm_turbo_rx_8bit):

@@ -37,6 +37,45 @@ SRSRAN_API int srsran_hip_rm_turbo_rx_batch_8bit(const int8_t* d_input, uint32_t
                                                  uint32_t out_stride, uint32_t n_cb, uint32_t long_cb, uint32_t rv_idx,
                                                  uint32_t nof_sb, void* stream);
 
+/* ---- transport-block decoding: decode_tb / decode_tb_cb of lib/src/phy/phch/sch.c:370-560 for a batch of blocks,
+ * device resident.  Per code block: rate de-matching into its soft buffer (HARQ combining), turbo half iterations with
+ * a CRC check after each one (CRC24B, or CRC24A when the block has a single code block) and early stop; then the
+ * CRC24A of the whole block.  Differences from the reference's srsran_softbuffer_rx_t bookkeeping: the soft buffers, the
+ * per-code-block CRC flags and the decoded bytes are arrays the CALLER keeps between HARQ rounds (a code block whose flag
+ * is set is skipped and its bytes are expected to still be in d_data). */
+#define SRSRAN_HIP_SOFTBUFFER_CB_SIZE 18600 /* int16 per code-block slot (SOFTBUFFER_SIZE, softbuffer.h) */
+
+typedef struct {
+  uint32_t tbs;         /* transport block size in bits; srsran_cbsegm must need no filler bits (sch.c:521) */
+  uint32_t Qm;          /* bits per modulation symbol */
+  uint32_t rv;          /* redundancy version 0..3 */
+  uint32_t nof_e_bits;  /* soft bits of this block */
+  uint32_t e_offset;    /* first soft bit in d_e_bits */
+  uint32_t data_offset; /* first decoded byte in d_data; tbs/8 + 6 bytes are written */
+  uint32_t first_cb;    /* first code-block slot (soft buffer, cb_crc) of this block */
+} srsran_hip_tb_t;
+
+typedef struct {
+  int32_t  crc_ok;         /* SRSRAN_SUCCESS or SRSRAN_ERROR: what decode_tb returns */
+  float    avg_iterations; /* sch.c:485: half iterations per code block of the block */
+  uint32_t nof_cb;
+} srsran_hip_tb_result_t;
+
+typedef struct srsran_hip_sch srsran_hip_sch_t;
+
+SRSRAN_API int  srsran_hip_sch_create(srsran_hip_sch_t** h);
+SRSRAN_API void srsran_hip_sch_free(srsran_hip_sch_t* h);
+/* cb_crc: host array of flags per code-block slot, read and updated.  results: host array, n_tb entries.
+ * Synchronises the stream before returning (the flags and results are host data). */
+SRSRAN_API int  srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
+                                      uint32_t max_iterations, int16_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
+                                      srsran_hip_tb_result_t* results, void* stream);
+/* srsran_cbsegm (cbsegm.h:32-45, cbsegm.c:62-117) */
+typedef struct SRSRAN_API {
+  uint32_t F, C, K1, K2, K1_idx, K2_idx, C1, C2, tbs, L_tb, L_cb, Z;
+} srsran_cbsegm_t;
+SRSRAN_API int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs);
+
 #ifdef __cplusplus
 }
 #endif

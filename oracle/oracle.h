@@ -70,6 +70,14 @@ int orc_rm_turbo_deinter(uint16_t* table, uint32_t long_cb, uint32_t rv_idx, uin
 int orc_rm_turbo_rx(const int16_t* input, int16_t* output, uint32_t in_len, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb);
 int orc_rm_turbo_rx_8bit(const int8_t* input, int8_t* output, uint32_t in_len, uint32_t long_cb, uint32_t rv_idx, uint32_t nof_sb);
 
+/* srsran_cbsegm (cbsegm.c:62-117) and decode_tb / decode_tb_cb (sch.c:370-560) for one transport block: rate de-matching
+ * into per-code-block soft buffers (18600 int16 each), turbo half iterations with CRC early stop, transport-block CRC.
+ * The loop itself cannot be pinned against the compiled reference (sch.c drags in the whole PHY channel layer); every
+ * step it is made of is. */
+int orc_cbsegm(uint32_t tbs, uint32_t* C, uint32_t* K1, uint32_t* K2, uint32_t* C1, uint32_t* C2, uint32_t* F);
+int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const int16_t* e_bits, int16_t* softbuf,
+                      uint8_t* cb_crc, uint8_t* cb_data, uint32_t max_iterations, uint8_t* data, float* avg_iterations);
+
 /* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
 int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);
 

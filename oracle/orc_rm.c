@@ -137,3 +137,113 @@ int orc_rm_turbo_rx_8bit(const int8_t* input, int8_t* output, uint32_t in_len, u
   free(t);
   return 0;
 }
+
+/* ------------------------------------------------------------------ transport block (sch.c:370-560) */
+
+/* srsran_cbsegm, cbsegm.c:62-117 */
+int orc_cbsegm(uint32_t tbs, uint32_t* C, uint32_t* K1, uint32_t* K2, uint32_t* C1, uint32_t* C2, uint32_t* F)
+{
+  *C = *K1 = *K2 = *C1 = *C2 = *F = 0;
+  if (tbs == 0) {
+    return 0;
+  }
+  uint32_t B = tbs + 24, Bp;
+  if (B <= 6144) {
+    *C = 1;
+    Bp = B;
+  } else {
+    *C = (B + (6144 - 24) - 1) / (6144 - 24);
+    Bp = B + 24 * (*C);
+  }
+  int idx1 = orc_tc_cb_index((Bp - 1) / (*C) + 1);
+  if (idx1 < 0) {
+    return -1;
+  }
+  *K1 = (uint32_t)orc_tc_cb_size(idx1);
+  if (*C == 1) {
+    *C1 = 1;
+  } else {
+    *K2 = (uint32_t)orc_tc_cb_size(idx1 > 0 ? idx1 - 1 : idx1);
+    *C2 = (*K1 != *K2) ? ((*C) * (*K1) - Bp) / (*K1 - *K2) : 0;
+    *C1 = *C - *C2;
+  }
+  *F = (*C1) * (*K1) + (*C2) * (*K2) - Bp;
+  return 0;
+}
+
+static uint32_t crc_bytes(uint32_t poly, const uint8_t* data, uint32_t nbits)
+{
+  uint8_t* bits = malloc(nbits);
+  for (uint32_t i = 0; i < nbits; i++) {
+    bits[i] = (data[i / 8] >> (7 - (i % 8))) & 1;
+  }
+  uint32_t c = orc_crc_bits(poly, 24, bits, (int)nbits); /* srsran_crc_checksum_byte, crc.c:147-161 */
+  free(bits);
+  return c;
+}
+
+/* decode_tb + decode_tb_cb for one transport block, 16-bit LLRs, window decoders (K > 400).
+ *   softbuf : C slots of 18600 int16 (accumulated into), cb_crc: C flags (read and updated)
+ *   cb_data : C x 768 bytes, the decoded code blocks kept between HARQ rounds (softbuffer->data)
+ *   data    : tbs/8 + 6 bytes
+ * returns 0 (SRSRAN_SUCCESS) or -1; *avg_iterations as sch.c:485 */
+int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const int16_t* e_bits, int16_t* softbuf,
+                      uint8_t* cb_crc, uint8_t* cb_data, uint32_t max_iterations, uint8_t* data, float* avg_iterations)
+{
+  uint32_t C, K1, K2, C1, C2, F;
+  if (orc_cbsegm(tbs, &C, &K1, &K2, &C1, &C2, &F) || F || Qm == 0) {
+    return -2;
+  }
+  float it = 0;
+  for (uint32_t i = 0; i < C; i++) {
+    uint32_t K    = i < C1 ? K1 : K2;
+    uint32_t rlen = C == 1 ? K : K - 24;
+    if (cb_crc[i]) {
+      memcpy(&data[i * rlen / 8], &cb_data[(size_t)i * 768], rlen / 8); /* sch.c:466-471 */
+      continue;
+    }
+    uint32_t Gp = nof_e_bits / Qm, gamma = Gp % C, n_e = Qm * (Gp / C);
+    uint32_t rp = i * n_e, n_e2 = n_e;
+    if (i > C - gamma) {
+      n_e2 = n_e + Qm;
+      rp   = (C - gamma) * n_e + (i - (C - gamma)) * n_e2;
+    }
+    int16_t* sb  = softbuf + (size_t)i * 18600;
+    uint32_t nsb = orc_tdec_autoimp_subblocks(K);
+    if (!nsb || orc_rm_turbo_rx(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
+      return -2;
+    }
+    uint8_t* out = &data[i * rlen / 8];
+    uint32_t noi = 0;
+    int      ok  = 0;
+    do {
+      noi++;
+      /* srsran_tdec_iteration noi times from the start = the state after noi half iterations */
+      if (orc_tdec_run_all(sb, out, noi, K, ORC_TDEC_AUTO, 1, NULL, NULL)) {
+        return -2;
+      }
+      it += 1;
+      ok = crc_bytes(C > 1 ? 0x1800063 : 0x1864CFB, out, C > 1 ? K : tbs + 24) == 0;
+    } while (noi < max_iterations && !ok);
+    if (ok) {
+      cb_crc[i] = 1;
+    }
+  }
+  *avg_iterations = it / (float)C;
+  int all = 1;
+  for (uint32_t i = 0; i < C; i++) {
+    all = all && cb_crc[i];
+  }
+  if (!all) { /* sch.c:478-485: keep the good code blocks for the next HARQ round */
+    for (uint32_t i = 0; i < C; i++) {
+      if (cb_crc[i]) {
+        uint32_t K = i < C1 ? K1 : K2, rlen = C == 1 ? K : K - 24;
+        memcpy(&cb_data[(size_t)i * 768], &data[i * rlen / 8], rlen / 8);
+      }
+    }
+    return -1;
+  }
+  uint32_t par_rx = crc_bytes(0x1864CFB, data, tbs);
+  uint32_t par_tx = ((uint32_t)data[tbs / 8] << 16) | ((uint32_t)data[tbs / 8 + 1] << 8) | data[tbs / 8 + 2];
+  return (par_rx == par_tx && par_rx) ? 0 : -1;
+}

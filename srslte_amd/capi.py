@@ -104,6 +104,22 @@ SSS_DIFF, SSS_FULL, SSS_PARTIAL_3 = 0, 1, 2
 FDD, TDD = 0, 1
 
 
+class HipTb(C.Structure):
+    _fields_ = [("tbs", C.c_uint32), ("Qm", C.c_uint32), ("rv", C.c_uint32), ("nof_e_bits", C.c_uint32), ("e_offset", C.c_uint32),
+                ("data_offset", C.c_uint32), ("first_cb", C.c_uint32)]
+
+
+class HipTbResult(C.Structure):
+    _fields_ = [("crc_ok", C.c_int32), ("avg_iterations", C.c_float), ("nof_cb", C.c_uint32)]
+
+
+class Cbsegm(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs", "L_tb", "L_cb", "Z")]
+
+
+SOFTBUFFER_CB_SIZE = 18600
+
+
 class HipCell(C.Structure):
     _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
                 ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
@@ -344,6 +360,10 @@ def lib():
             "srsran_hip_rm_turbo_table": (i32, [vp, u32, u32, u32]),
             "srsran_hip_rm_turbo_rx_batch": (i32, [vp, u32, u32, vp, u32, u32, u32, u32, u32, vp]),
             "srsran_hip_rm_turbo_rx_batch_8bit": (i32, [vp, u32, u32, vp, u32, u32, u32, u32, u32, vp]),
+            "srsran_hip_sch_create": (i32, [C.POINTER(vp)]),
+            "srsran_hip_sch_free": (None, [vp]),
+            "srsran_hip_sch_decode": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
+            "srsran_cbsegm": (i32, [C.POINTER(Cbsegm), u32]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
             "srsran_hip_cellsearch_free": (None, [vp]),
             "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),

@@ -15,6 +15,16 @@ struct RxJob {
   uint32_t table;      // offset of the position table of (K, rv, layout) in the table pool (uint16 elements)
 };
 
+struct TbCrcJob {
+  uint32_t data_offset; // first byte of the transport block
+  uint32_t tbs;         // payload bits (multiple of 8); the 3 parity bytes follow
+};
+struct TbCrcResult {
+  uint32_t par_rx; // CRC24A of the payload
+  uint32_t par_tx; // the received parity bytes
+};
+hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, TbCrcResult* d_res, hipStream_t stream);
+
 // d_jobs: device array of n_jobs descriptors.  elem8: int8 soft bits (wrapping), else int16.
 hipError_t launch_rx(const void* d_in, void* d_out, const uint16_t* d_tables, const RxJob* d_jobs, int n_jobs, bool elem8,
                      hipStream_t stream);

@@ -65,3 +65,72 @@ hipError_t launch_rx_uniform(const void* d_in, void* d_out, const uint16_t* d_ta
 
 } // namespace rm
 } // namespace phyhip
+
+namespace phyhip {
+namespace rm {
+
+// ---- transport-block CRC (decode_tb, sch.c:540-560): CRC24A over the tbs payload bits, compared with the three
+// parity bytes that follow.  One workgroup per block: every lane runs the bit-serial CRC (crc.c:92-140) of its chunk,
+// shifts it to its place by x^(8 * bytes behind the chunk) mod g (square-and-multiply) and the partial checksums
+// are XOR-ed.
+__device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b, uint32_t poly)
+{
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+    r ^= ((b >> i) & 1u) ? a : 0u;
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const TbCrcJob* jobs, uint32_t poly_full, TbCrcResult* res)
+{
+  __shared__ uint32_t red[256];
+  const TbCrcJob jb   = jobs[blockIdx.x];
+  const uint32_t poly = poly_full & 0xffffffu;
+  const uint8_t* d    = data + jb.data_offset;
+  const uint32_t nb   = jb.tbs / 8;
+  const uint32_t c    = (nb + 255) / 256;
+  const uint32_t lo = threadIdx.x * c, hi = lo + c < nb ? lo + c : nb;
+  uint32_t       crc = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t byte = d[i];
+    for (int b = 7; b >= 0; b--) {
+      crc = ((crc << 1) & 0xffffffu) ^ ((((crc >> 23) ^ (byte >> b)) & 1u) ? poly : 0u);
+    }
+  }
+  if (lo < nb) {
+    uint32_t e = 8 * (nb - hi), result = 1, base = 2; // x^e mod g
+    while (e) {
+      if (e & 1) {
+        result = gf_mulmod(result, base, poly);
+      }
+      base = gf_mulmod(base, base, poly);
+      e >>= 1;
+    }
+    crc = gf_mulmod(crc, result, poly);
+  }
+  red[threadIdx.x] = crc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x] ^= red[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t par_rx = red[0];
+    const uint32_t par_tx = ((uint32_t)d[nb] << 16) | ((uint32_t)d[nb + 1] << 8) | (uint32_t)d[nb + 2];
+    res[blockIdx.x].par_rx = par_rx;
+    res[blockIdx.x].par_tx = par_tx;
+  }
+}
+
+hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, TbCrcResult* d_res, hipStream_t stream)
+{
+  hipLaunchKernelGGL(tb_crc_kernel, dim3(n_jobs), dim3(256), 0, stream, d_data, d_jobs, poly, d_res);
+  return hipGetLastError();
+}
+
+} // namespace rm
+} // namespace phyhip

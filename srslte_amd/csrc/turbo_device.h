@@ -6,6 +6,15 @@
 namespace phyhip {
 namespace turbo {
 
+// optional per-code-block placement (transport-block decoding): where the LLRs of a block start, where its hard bits
+// go and how many of its K/8 bytes are written (sch.c:424: all but the last block of a transport block drop their CRC)
+struct CbDesc {
+  uint32_t in_off;    // elements from WinParams::input
+  uint32_t out_off;   // bytes from WinParams::output
+  uint32_t out_bytes; // <= K/8
+  uint32_t reserved;
+};
+
 struct WinParams {
   const short*    input;   // n_cb code blocks, in_stride elements apart (int8 elements when in_is8)
   uint8_t*        output;  // n_cb x K/8 bytes, out_stride apart
@@ -22,6 +31,12 @@ struct WinParams {
   int             n_cb;
   int             sb_layout;
   int             in_is8;
+  // early stop on CRC (decode_tb_cb, sch.c:420-454): generator incl. the x^24 term, 0 = off
+  const CbDesc*   desc;     // optional, n_cb entries
+  uint32_t        crc_poly;
+  const uint32_t* crc_mult; // nb multipliers x^(W (nb-1-d)) mod g
+  int*            noi;      // out: half iterations run per code block
+  uint8_t*        crc_ok;   // out: 1 = CRC matched
 };
 
 struct GenParams {
@@ -54,6 +69,15 @@ static inline size_t gen_ws_shorts(uint32_t K)
 }
 
 hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream);
+} // namespace turbo
+} // namespace phyhip
+struct srsran_hip_tdec_batch;
+namespace phyhip {
+namespace turbo {
+// host side (turbo_host.cpp), used by the transport-block decoder
+int batch_run_early_stop(srsran_hip_tdec_batch* h, const void* d_input, bool in_is8, const CbDesc* d_desc, uint8_t* d_output,
+                         uint32_t n_cb, uint32_t max_iterations, int sb_layout, uint32_t crc_poly, int* d_noi, uint8_t* d_crc_ok,
+                         hipStream_t stream);
 hipError_t launch_gen(const GenParams& p, hipStream_t stream);
 uint32_t   win_elem_index(int nb, uint32_t k, uint32_t d);
 

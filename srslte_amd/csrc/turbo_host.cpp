@@ -146,6 +146,8 @@ struct srsran_hip_tdec_batch {
   uint16_t* d_deinter16 = nullptr;
   // optional parity aid
   short* d_dec_llr = nullptr;
+  // early stop on CRC: multipliers x^(W (nb-1-d)) mod g for the generators used so far
+  std::map<uint32_t, uint32_t*> crc_mult;
 };
 
 // which decoder the reference runs: sub-block count and arithmetic (turbodecoder.c:381-441,455-512)
@@ -293,6 +295,9 @@ extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
   hipFree(h->d_inter16);
   hipFree(h->d_deinter16);
   hipFree(h->d_dec_llr);
+  for (auto& kv : h->crc_mult) {
+    hipFree(kv.second);
+  }
   delete h;
 }
 
@@ -319,7 +324,7 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     PHY_HIP_CHECK(hipMalloc(&h->d_dec_llr, (size_t)h->K * h->max_cb * sizeof(short)), SRSRAN_ERROR);
   }
   if (h->nb) {
-    turbo::WinParams p;
+    turbo::WinParams p = {};
     p.input      = d_input;
     p.output     = d_output;
     p.dec_llr    = want_llr ? h->d_dec_llr : nullptr;
@@ -340,7 +345,7 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     }
     PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   } else {
-    turbo::GenParams p;
+    turbo::GenParams p = {};
     p.input      = d_input;
     p.output     = d_output;
     p.dec_llr    = want_llr ? h->d_dec_llr : nullptr;
@@ -406,6 +411,72 @@ extern "C" SRSRAN_API int srsran_hip_tdec_batch_run_dbg_8bit(srsran_hip_tdec_bat
 {
   return tdec_batch_run_range(h, d_input, true, in_stride, d_output, out_stride, n_cb, n_begin, n_end, sb_layout, true,
                               (hipStream_t)stream);
+}
+
+// x^e mod g over GF(2), g of degree 24 given with its x^24 term
+static uint32_t xpow_mod(uint64_t e, uint32_t poly)
+{
+  auto mul = [&](uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+    for (int i = 23; i >= 0; i--) {
+      r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? (poly & 0xffffffu) : 0u);
+      if ((b >> i) & 1u) {
+        r ^= a;
+      }
+    }
+    return r;
+  };
+  uint32_t result = 1, base = 2; // the polynomials 1 and x
+  while (e) {
+    if (e & 1) {
+      result = mul(result, base);
+    }
+    base = mul(base, base);
+    e >>= 1;
+  }
+  return result;
+}
+
+// Transport-block decoding (sch_host.cpp): all half iterations up to max_iterations with the per-block CRC early
+// stop of decode_tb_cb (sch.c:420-454).  Window decoders only; d_desc places every block's input / output.
+int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* d_input, bool in_is8, const turbo::CbDesc* d_desc,
+                                        uint8_t* d_output, uint32_t n_cb, uint32_t max_iterations, int sb_layout, uint32_t crc_poly,
+                                        int* d_noi, uint8_t* d_crc_ok, hipStream_t stream)
+{
+  if (!h || !h->nb || !d_input || !d_output || !d_desc || n_cb == 0 || n_cb > h->max_cb || max_iterations == 0 || !crc_poly) {
+    set_error("tdec early stop: invalid arguments (window decoders only)");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  uint32_t*& d_mult = h->crc_mult[crc_poly];
+  if (!d_mult) {
+    std::vector<uint32_t> m(h->nb);
+    const uint64_t        W = h->K / h->nb;
+    for (int d = 0; d < h->nb; d++) {
+      m[d] = xpow_mod(W * (uint64_t)(h->nb - 1 - d), crc_poly);
+    }
+    PHY_HIP_CHECK(hipMalloc(&d_mult, m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(d_mult, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  }
+  turbo::WinParams p = {};
+  p.input      = static_cast<const short*>(d_input);
+  p.output     = d_output;
+  p.ws         = h->d_ws;
+  p.deint      = h->d_deint;
+  p.inter      = h->d_inter;
+  p.ws_stride  = h->ws_stride;
+  p.K          = h->K;
+  p.n_begin    = 0;
+  p.n_end      = max_iterations;
+  p.n_cb       = (int)n_cb;
+  p.sb_layout  = sb_layout;
+  p.in_is8     = in_is8 ? 1 : 0;
+  p.desc       = d_desc;
+  p.crc_poly   = crc_poly;
+  p.crc_mult   = d_mult;
+  p.noi        = d_noi;
+  p.crc_ok     = d_crc_ok;
+  PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ handle ABI

@@ -548,16 +548,16 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 
   // ---- phase 0: input extraction
   if (p.n_begin == 0) {
-    const bool fast = !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
+    const bool fast = !p.desc && !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
     if (fast) {
       const int first = blockIdx.x * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
                                        S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
     } else if (p.in_is8) {
-      const signed char* in = reinterpret_cast<const signed char*>(p.input) + (size_t)cb * p.in_stride;
+      const signed char* in = reinterpret_cast<const signed char*>(p.input) + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     } else {
-      const short* in = p.input + (size_t)cb * p.in_stride;
+      const short* in = p.input + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     }
   }
@@ -567,6 +567,113 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   __syncthreads();
 
   // ---- half iterations (turbodecoder_iter.h:72-141)
+  // ---- hard decision (turbodecoder.c:370-378 + turbodecoder_win.h:973-993): bit = LLR > 0, MSB first.
+  // Source: app1 after an even number of half iterations, else ext1; the last half iteration filed it in D.
+  // With a CRC generator the checksum of the K hard bits is formed on the way (sch.c:430-447: zero means the code
+  // block is good): every lane runs the bit-serial CRC of its two sub-blocks, the 16 partial checksums are shifted
+  // to their place by multiplication with x^(W (NB-1-d)) mod g and XOR-ed across the lanes of the code block.
+  uint8_t*       out       = p.output + (p.desc ? (size_t)p.desc[cb].out_off : (size_t)cb * p.out_stride);
+  const uint32_t out_bytes = p.desc ? p.desc[cb].out_bytes : K / 8;
+  auto decide = [&](bool write) -> uint32_t {
+    short*         o16   = (p.dec_llr && live && write) ? p.dec_llr + (size_t)cb * K : nullptr;
+    const bool     whole = (long_sb & 7) == 0;
+    const uint32_t bps   = long_sb >> 3; // bytes per sub-block
+    const uint32_t poly  = p.crc_poly & 0xffffffu;
+    uint32_t       c0 = 0, c1 = 0;
+    if (whole || p.crc_poly) {
+      const bool wide = whole && ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0) && out_bytes == K / 8;
+      uint32_t   w0 = 0, w1 = 0;
+      uint32_t   t[8], tn[8];
+      issue_rows(D, 0, lane, t);
+      for (uint32_t b = 0; b < nblk; b++) {
+        if (b + 1 < nblk) {
+          issue_rows(D, b + 1, lane, tn);
+        }
+        uint32_t r[8];
+        rows_to_lane(Tr, lane, t, r);
+        uint32_t b0 = 0, b1 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (b * 8 + j < long_sb) {
+            const s2       v  = from_u(r[j]);
+            const uint32_t x0 = v.x > 0 ? 1u : 0u, x1 = v.y > 0 ? 1u : 0u;
+            b0 |= (x0 << 7) >> j;
+            b1 |= (x1 << 7) >> j;
+            if (p.crc_poly) { // crc.c:92-140, MSB first, zero initial state
+              c0 = ((c0 << 1) & 0xffffffu) ^ ((((c0 >> 23) ^ x0) & 1u) ? poly : 0u);
+              c1 = ((c1 << 1) & 0xffffffu) ^ ((((c1 >> 23) ^ x1) & 1u) ? poly : 0u);
+            }
+            if (o16 && whole) { // parity aid: decision LLRs in natural order
+              o16[(2 * pl) * long_sb + b * 8 + j]     = v.x;
+              o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
+            }
+          }
+        }
+        if (whole && write && live) {
+          if (wide) {
+            w0 |= b0 << (8 * (b & 3));
+            w1 |= b1 << (8 * (b & 3));
+            if ((b & 3) == 3) {
+              *reinterpret_cast<uint32_t*>(out + (2 * pl) * bps + (b & ~3u))     = w0;
+              *reinterpret_cast<uint32_t*>(out + (2 * pl + 1) * bps + (b & ~3u)) = w1;
+              w0 = w1 = 0;
+            }
+          } else {
+            if ((2 * pl) * bps + b < out_bytes) {
+              out[(2 * pl) * bps + b] = (uint8_t)b0;
+            }
+            if ((2 * pl + 1) * bps + b < out_bytes) {
+              out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          t[j] = tn[j];
+        }
+      }
+    }
+    if (!whole && write) {
+      const short* sd = reinterpret_cast<const short*>(D);
+      for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
+        uint32_t byte = 0;
+        for (int tt = 0; tt < 8; tt++) {
+          uint32_t nn = jb * 8 + tt;
+          uint32_t d = nn / long_sb, k = nn % long_sb;
+          uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
+          short    v = sd[e];
+          byte |= (v > 0 ? 0x80u : 0u) >> tt;
+          if (o16) {
+            o16[nn] = v;
+          }
+        }
+        if (live && jb < out_bytes) {
+          out[jb] = (uint8_t)byte;
+        }
+      }
+    }
+    uint32_t crc = 0;
+    if (p.crc_poly) {
+      auto mulmod = [&](uint32_t a, uint32_t m) { // a(x) m(x) mod g(x), all below x^24
+        uint32_t r = 0;
+#pragma unroll 4
+        for (int i = 23; i >= 0; i--) {
+          r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+          r ^= ((m >> i) & 1u) ? a : 0u;
+        }
+        return r;
+      };
+      crc = mulmod(c0, p.crc_mult[2 * pl]) ^ mulmod(c1, p.crc_mult[2 * pl + 1]);
+#pragma unroll
+      for (int off = LPC / 2; off > 0; off >>= 1) {
+        crc ^= __shfl_xor(crc, off, LPC);
+      }
+    }
+    return crc;
+  };
+  bool     done = false; // early stop: the CRC of this code block has matched
+  uint32_t noi  = 0;     // half iterations run for this code block in this launch (sch.c:424: cb_noi)
+
   for (uint32_t n = p.n_begin; n < p.n_end; n++) {
     const bool      dec1    = !(n & 1);
     const bool      has_app = dec1 && n > 0;
@@ -737,7 +844,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     //              difference is formed before the permutation and no ext1 array is exchanged at all.
     // The raw SISO output is only needed by the hard decision: the LAST half iteration of a launch files it in D.
     const bool fuse = dec1 && n >= 2;
-    const bool last = n + 1 == p.n_end;
+    const bool last = (n + 1 == p.n_end) || p.crc_poly; // with early stop every half iteration may be the last
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
     load_block(CK, 64 + lane, ck);
@@ -828,74 +935,28 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       }
     }
     __syncthreads();
-  }
-
-  // ---- hard decision (turbodecoder.c:370-378 + turbodecoder_win.h:973-993): bit = LLR > 0, MSB first.
-  // Source: app1 after an even number of half iterations, else ext1; the last half iteration filed it in D.
-  {
-    uint8_t*   out  = p.output + (size_t)cb * p.out_stride;
-    short*     o16  = (p.dec_llr && live) ? p.dec_llr + (size_t)cb * K : nullptr;
-    if ((long_sb & 7) == 0) {
-      const uint32_t bps   = long_sb >> 3; // bytes per sub-block
-      const bool     wide  = ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0); // dword stores possible
-      uint32_t       w0 = 0, w1 = 0;
-      uint32_t       t[8], tn[8];
-      issue_rows(D, 0, lane, t);
-      for (uint32_t b = 0; b < nblk; b++) {
-        if (b + 1 < nblk) {
-          issue_rows(D, b + 1, lane, tn);
-        }
-        uint32_t r[8];
-        rows_to_lane(Tr, lane, t, r);
-        uint32_t b0 = 0, b1 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const s2 v = from_u(r[j]);
-          b0 |= (v.x > 0 ? 0x80u : 0u) >> j;
-          b1 |= (v.y > 0 ? 0x80u : 0u) >> j;
-          if (o16) { // parity aid: decision LLRs in natural order
-            o16[(2 * pl) * long_sb + b * 8 + j]     = v.x;
-            o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
-          }
-        }
-        if (wide) {
-          w0 |= b0 << (8 * (b & 3));
-          w1 |= b1 << (8 * (b & 3));
-          if ((b & 3) == 3) {
-            if (live) {
-              *reinterpret_cast<uint32_t*>(out + (2 * pl) * bps + (b & ~3u))     = w0;
-              *reinterpret_cast<uint32_t*>(out + (2 * pl + 1) * bps + (b & ~3u)) = w1;
-            }
-            w0 = w1 = 0;
-          }
-        } else if (live) {
-          out[(2 * pl) * bps + b]     = (uint8_t)b0;
-          out[(2 * pl + 1) * bps + b] = (uint8_t)b1;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          t[j] = tn[j];
-        }
+    if (p.crc_poly) {
+      // decode_tb_cb (sch.c:420-454): hard bits + CRC after every half iteration; a code block stops at its first
+      // match (its bits are written then and never again), the wave stops when all its code blocks have
+      const bool     fin = n + 1 == p.n_end;
+      const bool     wr  = !done; // bits of the last half iteration THIS code block took part in
+      const uint32_t crc = decide(wr);
+      if (!done) {
+        noi++;
+        done = crc == 0;
       }
-    } else {
-      const short* sd = reinterpret_cast<const short*>(D);
-      for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
-        uint32_t byte = 0;
-        for (int tt = 0; tt < 8; tt++) {
-          uint32_t nn = jb * 8 + tt;
-          uint32_t d = nn / long_sb, k = nn % long_sb;
-          uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
-          short    v = sd[e];
-          byte |= (v > 0 ? 0x80u : 0u) >> tt;
-          if (o16) {
-            o16[nn] = v;
-          }
-        }
-        if (live) {
-          out[jb] = (uint8_t)byte;
-        }
+      __syncthreads();
+      if (__all(done || !live) || fin) {
+        break;
       }
     }
+  }
+
+  if (!p.crc_poly) {
+    decide(true);
+  } else if (p.noi && live && pl == 0) {
+    p.noi[cb_raw]    = (int)noi;
+    p.crc_ok[cb_raw] = done ? 1 : 0;
   }
 }
 

@@ -120,6 +120,70 @@ def turbo_llrs_8bit(K, n_cb, esn0_db, seed, scale=12.0):
     return msgs, np.clip(llr, -127, 127).astype(np.int8)
 
 
+CRC24A, CRC24B = 0x1864CFB, 0x1800063
+
+
+def crc_attach(bits, poly):
+    c = orc().orc_crc_bits(poly, 24, P(np.ascontiguousarray(bits, np.uint8)), bits.size)
+    return np.concatenate([bits, np.array([(c >> (23 - i)) & 1 for i in range(24)], np.uint8)])
+
+
+def cbsegm(tbs):
+    v = [C.c_uint32() for _ in range(6)]
+    orc().orc_cbsegm.argtypes = [C.c_uint32] + [C.POINTER(C.c_uint32)] * 6
+    assert orc().orc_cbsegm(tbs, *[C.byref(x) for x in v]) == 0
+    return dict(zip(("C", "K1", "K2", "C1", "C2", "F"), [x.value for x in v]))
+
+
+def rm_table(K, rv, nsb=0):
+    orc().orc_rm_turbo_deinter.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    t = np.zeros(3 * K + 12, np.uint16)
+    assert orc().orc_rm_turbo_deinter(P(t), K, rv, nsb) == 0
+    return t
+
+
+def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0):
+    """transmit side of one transport block (36.212 5.1.1-5.1.5 as sch.c encode_tb does it: CRC24A, segmentation,
+    CRC24B per block, turbo code, rate matching of redundancy version rv, concatenation) + BPSK over AWGN.
+    Returns (int16 soft bits e, payload bytes incl. the CRC24A)"""
+    s = cbsegm(tbs)
+    assert s["F"] == 0
+    payload = rng.integers(0, 2, tbs).astype(np.uint8)
+    b = crc_attach(payload, CRC24A)
+    e, pos = [], 0
+    Gp = nof_e_bits // Qm
+    gamma, n_e = Gp % s["C"], Qm * (Gp // s["C"])
+    for i in range(s["C"]):
+        K = s["K1"] if i < s["C1"] else s["K2"]
+        rlen = K if s["C"] == 1 else K - 24
+        cb = b[pos:pos + rlen]
+        pos += rlen
+        if s["C"] > 1:
+            cb = crc_attach(cb, CRC24B)
+        d = turbo_encode(cb)
+        E = n_e if i <= s["C"] - gamma - 1 else n_e + (Qm if gamma else 0)  # transmit-side split (sch.c:296-300)
+        t = rm_table(K, rv)
+        e.append(d[t[np.arange(E) % t.size]])
+    tx = np.concatenate(e).astype(np.float64)
+    sigma = 10 ** (-esn0_db / 20)
+    y = (2.0 * tx - 1.0) + sigma * rng.standard_normal(tx.size)
+    pad = np.zeros(nof_e_bits - tx.size)
+    return np.clip(np.round(scale * np.concatenate([y, pad])), -32768, 32767).astype(np.int16), np.packbits(b)
+
+
+def sch_decode_tb(tbs, Qm, rv, e_bits, softbuf, cb_crc, max_iterations, cb_data=None):
+    """oracle decode_tb: returns (ret, data bytes, avg_iterations); softbuf [C, 18600] int16 and cb_crc [C] uint8 are updated.
+    cb_data [C, 768] uint8: decoded code blocks kept between HARQ rounds (softbuffer->data)"""
+    f = orc().orc_sch_decode_tb
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                  C.c_void_p, C.c_void_p]
+    data = np.zeros(tbs // 8 + 6, np.uint8)
+    cb_data = np.zeros((cb_crc.size, 768), np.uint8) if cb_data is None else cb_data
+    avg = C.c_float()
+    ret = f(tbs, Qm, rv, e_bits.size, P(e_bits), P(softbuf), P(cb_crc), P(cb_data), max_iterations, P(data), C.byref(avg))
+    return ret, data, avg.value
+
+
 def natural_to_sb_layout(llr_nat, K, nb):
     """what srsran_rm_turbo_rx_lut hands to the window decoders (rm_turbo.c:260-273,
     turbodecoder_iter.h:88-102): syst @0, parity0 @K+32, parity1 @2(K+32) in [step][sub-block] order,

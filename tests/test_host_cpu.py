@@ -180,6 +180,23 @@ def test_rate_matching_tables_match_oracle(L):
     assert L.srsran_hip_rm_turbo_table(O.P(a), 41, 0, 0) == -2 and L.srsran_hip_rm_turbo_table(O.P(a), 40, 4, 0) == -2
 
 
+def test_cbsegm_matches_oracle_and_reference(L):
+    """srsran_cbsegm (cbsegm.c:62-117): product, oracle and (dev container) the compiled reference agree"""
+    from srslte_amd import capi
+
+    ref = C.CDLL(O.REF_LIB) if (O.have_ref() and os.path.isdir("/root/reference")) else None
+    rng = np.random.default_rng(2)
+    for tbs in [0, 16, 40, 6120, 6128, 6144, 12216, 12240, 75376, 97896, 149776] + [int(8 * v) for v in rng.integers(1, 18000, 300)]:
+        s = capi.Cbsegm()
+        assert L.srsran_cbsegm(C.byref(s), tbs) == 0
+        o = O.cbsegm(tbs)
+        assert (s.C, s.K1, s.K2, s.C1, s.C2, s.F) == (o["C"], o["K1"], o["K2"], o["C1"], o["C2"], o["F"]), tbs
+        if ref is not None:
+            r = capi.Cbsegm()
+            assert ref.srsran_cbsegm(C.byref(r), tbs) == 0
+            assert [getattr(s, f) for f, _ in capi.Cbsegm._fields_[:11]] == [getattr(r, f) for f, _ in capi.Cbsegm._fields_[:11]], tbs
+
+
 def test_no_gpu_means_loud_failure(L):
     """the product path must not fall back to the CPU: without a device every create/init fails"""
     from srslte_amd import capi

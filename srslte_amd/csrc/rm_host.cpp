@@ -81,8 +81,14 @@ const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
   if (it != g_pool.dev.end()) {
     return it->second;
   }
-  std::vector<uint16_t> t = build_table(K, rv, nof_sb);
-  uint16_t*             d = nullptr;
+  // the device holds the INVERSE table (soft-buffer position -> index of the transmitted bit, 0xffff = none): the
+  // kernel is driven from the output side (unit-stride read-modify-write of the soft buffer)
+  const std::vector<uint16_t> fwd = build_table(K, rv, nof_sb);
+  std::vector<uint16_t>       t(nof_sb ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12, 0xffffu);
+  for (size_t k = 0; k < fwd.size(); k++) {
+    t[fwd[k]] = (uint16_t)k;
+  }
+  uint16_t* d = nullptr;
   if (hipMalloc(&d, t.size() * sizeof(uint16_t)) != hipSuccess ||
       hipMemcpy(d, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("rm_turbo: cannot place the table of K=%u rv=%u on the device", K, rv);
@@ -110,7 +116,8 @@ int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out,
     return SRSRAN_ERROR;
   }
   const rm::RxJob first = {0, in_len, 0, 3 * K + 12, 0};
-  PHY_HIP_CHECK(rm::launch_rx_uniform(d_in, d_out, tab, first, in_stride, out_stride, (int)n_cb, elem8, st), SRSRAN_ERROR);
+  const uint32_t  span  = nof_sb ? 3 * (K + 32) + 12 : 3 * K + 12;
+  PHY_HIP_CHECK(rm::launch_rx_gather(d_in, d_out, tab, span, nullptr, first, in_stride, out_stride, (int)n_cb, elem8, st), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }
 

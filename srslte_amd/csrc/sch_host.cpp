@@ -13,7 +13,7 @@ using namespace phyhip;
 
 namespace phyhip {
 namespace rm {
-const uint16_t* device_table(uint32_t K, uint32_t rv, uint32_t nof_sb);
+const uint16_t* device_table(uint32_t K, uint32_t rv, uint32_t nof_sb); // inverse table, see rm_host.cpp
 }
 } // namespace phyhip
 
@@ -229,7 +229,7 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
       return SRSRAN_ERROR;
     }
     // softbuffer += rate-matched soft bits (srsran_rm_turbo_rx_lut, sch.c:414), in the decoder's sub-block layout
-    PHY_HIP_CHECK(rm::launch_rx(d_e_bits, d_softbuf, tab, d_jobs + at, (int)m, false, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, false, st), SRSRAN_ERROR);
     if (turbo::batch_run_early_stop(dec, d_softbuf, false, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {
       return SRSRAN_ERROR;
     }

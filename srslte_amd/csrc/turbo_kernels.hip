@@ -511,6 +511,52 @@ __device__ __forceinline__ void extract_input_natural16(const short* in_wave, ui
   }
 }
 
+// Fast input extraction for the rm_turbo sub-block layout (int16): element (step k, sub-block d) of stream a sits at
+// in[a (K+32) + k NB + d], i.e. the 8 steps of a block are 8 * NB contiguous int16 per code block and stream.  The LPC
+// lanes of a code block fetch them with two dwordx4 each (128 contiguous bytes per code block and instruction) and the
+// [step][sub-block pair] image is turned into "8 steps of pair p" through the 2 KB LDS stage.  Needs W % 8 == 0 and
+// 16-byte aligned code blocks.
+template <int LPC, class AR>
+__device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, uint32_t nblk, int lane, int pl, uint32_t* S,
+                                                   uint32_t* P0, uint32_t* P1, short* TL, uint32_t* stage)
+{
+  constexpr int  NB  = 2 * LPC;
+  const int      cbw = lane / LPC;
+  uint32_t*      dst[3] = {S, P0, P1};
+  uint4*         st4 = reinterpret_cast<uint4*>(stage);
+  for (uint32_t b = 0; b < nblk; b++) {
+    uint4 v[3][2];
+#pragma unroll
+    for (int a3 = 0; a3 < 3; a3++) {
+      const uint4* q = reinterpret_cast<const uint4*>(in + (size_t)a3 * (K + 32) + (size_t)b * 8 * NB);
+      v[a3][0]       = q[pl];
+      v[a3][1]       = q[LPC + pl];
+    }
+#pragma unroll
+    for (int a3 = 0; a3 < 3; a3++) {
+      st4[cbw * 2 * LPC + pl]       = v[a3][0];
+      st4[cbw * 2 * LPC + LPC + pl] = v[a3][1];
+      uint32_t r[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t w = stage[cbw * 8 * LPC + j * LPC + pl];
+        r[j] = (uint32_t)(uint16_t)AR::conv_in((short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((short)(w >> 16)) << 16);
+      }
+      store_block(dst[a3], b * 64 + lane, r);
+    }
+  }
+  if (pl == 0) {
+    const uint32_t tb = 3 * (K + 32);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      TL[i]     = AR::conv_in(in[tb + 2 * i]);
+      TL[3 + i] = AR::conv_in(in[tb + 2 * i + 1]);
+      TL[6 + i] = AR::conv_in(in[tb + 6 + 2 * i]);
+      TL[9 + i] = AR::conv_in(in[tb + 6 + 2 * i + 1]);
+    }
+  }
+}
+
 template <int LPC, class AR>
 __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 {
@@ -553,6 +599,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       const int first = blockIdx.x * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
                                        S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
+    } else if (!p.in_is8 && p.sb_layout && (long_sb & 7u) == 0 &&
+               __all(((reinterpret_cast<uintptr_t>(p.input) + 2 * (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride)) & 15u) == 0)) {
+      const short* in = p.input + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
+      extract_input_sb16<LPC, AR>(in, K, nblk, lane, pl, S, P0, P1, TL, Tr);
     } else if (p.in_is8) {
       const signed char* in = reinterpret_cast<const signed char*>(p.input) + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 flavour (PUSCH/PDSCH transport blocks, 64-QAM, TBS 75,376 = 13 code blocks of 5,824 bits):
+whole-transport-block decoding on the device -- rate de-matching, turbo half iterations with per-code-block CRC early
+stop, transport-block CRC (srsran_hip_sch_decode = decode_tb of sch.c) -- at a working-point SNR, against the same blocks
+decoded with a fixed number of half iterations.  Prints one JSON line.  Single GPU; device-resident inputs."""
+import argparse, ctypes as C, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tbs", type=int, default=2048); ap.add_argument("--snr", type=float, default=6.0)
+    ap.add_argument("--iters", type=int, default=8); ap.add_argument("--cpu-sample", type=int, default=2)
+    a = ap.parse_args()
+    import torch
+    import srslte_amd as S, oracle_api as O
+    from srslte_amd import capi
+    lib = S.lib()
+    dev = torch.device("cuda", 0)
+    capi.check(lib.srsran_hip_set_device(0), "set_device")
+    tbs, Qm, G = 75376, 6, 100800
+    seg = O.cbsegm(tbs)
+    ncb = seg["C"]
+    pool_n = 8
+    rng = np.random.default_rng(4)
+    pool = [O.make_tb(tbs, Qm, G, 0, a.snr, rng) for _ in range(pool_n)]
+    e_pool = torch.from_numpy(np.stack([p[0] for p in pool])).to(dev)
+    d_e = e_pool.repeat((a.tbs + pool_n - 1) // pool_n, 1)[:a.tbs].contiguous()
+    dlen = tbs // 8 + 8
+    d_data = torch.zeros((a.tbs, dlen), dtype=torch.uint8, device=dev)
+    d_soft = torch.zeros((a.tbs * ncb, capi.SOFTBUFFER_CB_SIZE), dtype=torch.int16, device=dev)
+    tb_arr = (capi.HipTb * a.tbs)(*[capi.HipTb(tbs, Qm, 0, G, i * G, i * dlen, i * ncb) for i in range(a.tbs)])
+    res = (capi.HipTbResult * a.tbs)()
+    flags = np.zeros(a.tbs * ncb, np.uint8)
+    h = C.c_void_p()
+    capi.check(lib.srsran_hip_sch_create(C.byref(h)), "sch_create")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        flags[:] = 0
+        d_soft.zero_()  # first transmission: srsran_softbuffer_rx_reset
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        capi.check(lib.srsran_hip_sch_decode(h, d_e.data_ptr(), tb_arr, a.tbs, a.iters, d_soft.data_ptr(), flags.ctypes.data, d_data.data_ptr(),
+                                             res, st), "sch_decode")
+        return time.perf_counter() - t0
+
+    for _ in range(a.warmup):
+        step()
+    dt = sum(step() for _ in range(a.steps)) / a.steps
+    ok = sum(1 for r in res if r.crc_ok == 0)
+    avg_it = float(np.mean([r.avg_iterations for r in res]))
+    got = d_data[:pool_n].cpu().numpy()
+    good = all(np.array_equal(got[i][:tbs // 8 + 3], pool[i][1]) for i in range(pool_n) if res[i].crc_ok == 0)
+    # CPU: the oracle's restatement of decode_tb on a few of the same blocks (single thread)
+    t1 = time.perf_counter()
+    par = True
+    for i in range(a.cpu_sample):
+        soft, crc = np.zeros((ncb, capi.SOFTBUFFER_CB_SIZE), np.int16), np.zeros(ncb, np.uint8)
+        ret, data, avg = O.sch_decode_tb(tbs, Qm, 0, pool[i][0], soft, crc, a.iters)
+        par = par and ret == res[i].crc_ok and abs(avg - res[i].avg_iterations) < 1e-6 and np.array_equal(data[:tbs // 8 + 3], got[i][:tbs // 8 + 3])
+    tc = time.perf_counter() - t1
+    # the same code blocks at a fixed number of half iterations (srsran_tdec_run_all through the batch API)
+    K = seg["K1"]
+    nb = lib.srsran_tdec_autoimp_get_subblocks(K)
+    dec = S.TdecBatch(K, a.tbs * ncb, capi.TDEC_AUTO)
+    d_bits = torch.zeros((a.tbs * ncb, K // 8), dtype=torch.uint8, device=dev)
+    def fixed():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); dec.run(d_soft, capi.SOFTBUFFER_CB_SIZE, d_bits, K // 8, a.tbs * ncb, a.iters, 1, st); e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
+    fixed(); t_fixed = fixed()
+    out = {"metric": "transport blocks decoded, Mbit/s of TBS (LTE 64-QAM TBS 75376: rate de-matching + turbo with CRC early stop + TB CRC)",
+           "value": a.tbs * tbs / dt / 1e6, "unit": "Mbit/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
+           "config": {"workload": "%d transport blocks x %d code blocks of %d bits, first transmission, Es/N0 knob %.1f dB, max %d half iterations"
+                                  % (a.tbs, ncb, K, a.snr, a.iters)},
+           "tb_crc_ok": ok, "avg_half_iterations": avg_it, "payload_matches_on_ok_blocks": bool(good),
+           "fixed_iterations_turbo_only_ms": t_fixed * 1e3, "fixed_iterations_mbit_per_s": a.tbs * ncb * K / t_fixed / 1e6,
+           "cpu_baseline": {"value": a.cpu_sample * tbs / tc / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "port",
+                            "sample": "%d transport blocks, oracle restatement of decode_tb (scalar C)" % a.cpu_sample},
+           "parity_vs_oracle": "identical verdicts, iteration counts and bytes" if par else "MISMATCH"}
+    print(json.dumps(out))
+
+
+main()

@@ -176,6 +176,19 @@ int      orc_pss_filter(const float* in, float* out, uint32_t N, uint32_t N_id_2
 float    orc_pss_cfo_compute(const float* pss_recv, uint32_t N, uint32_t N_id_2);
 int      orc_detect_cp(const float* in, uint32_t peak_pos, uint32_t N, float* m);
 
+/* ---------------- soft demodulation + descrambling (orc_modem.c) ---------------- */
+/* demod_soft.c: mod = srsran_mod_t (0 BPSK .. 4 256QAM), x = n complex symbols (re,im floats) */
+int      orc_demod_soft_s(int mod, const float* x, int16_t* llr, int n);
+int      orc_demod_soft_b(int mod, const float* x, int8_t* llr, int n);
+int      orc_demod_soft_f(int mod, const float* x, float* llr, int n);
+/* sequence.c: c(0..len-1) of the length-31 Gold sequence with c_init = seed; scratch: len bytes */
+void     orc_sequence_bits(uint32_t seed, uint8_t* c, uint32_t len);
+void     orc_sequence_apply_s(const int16_t* in, int16_t* out, uint32_t len, uint32_t seed, uint8_t* scratch);
+void     orc_sequence_apply_c(const int8_t* in, int8_t* out, uint32_t len, uint32_t seed, uint8_t* scratch);
+void     orc_sequence_apply_f(const float* in, float* out, uint32_t len, uint32_t seed, uint8_t* scratch);
+uint32_t orc_sequence_pdsch_seed(uint16_t rnti, int q, uint32_t nslot, uint32_t cell_id);
+uint32_t orc_sequence_pusch_seed(uint16_t rnti, uint32_t nslot, uint32_t cell_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,13 @@ class Cbsegm(C.Structure):
 SOFTBUFFER_CB_SIZE = 18600
 
 
+class HipDemodJob(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("mod", "nof_symbols", "symbol_offset", "llr_offset", "seed", "descramble")]
+
+
+LLR_SHORT, LLR_BYTE, LLR_FLOAT, MOD_NONE = 0, 1, 2, 5
+
+
 class HipCell(C.Structure):
     _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
                 ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
@@ -364,6 +371,22 @@ def lib():
             "srsran_hip_sch_free": (None, [vp]),
             "srsran_hip_sch_decode": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
             "srsran_cbsegm": (i32, [C.POINTER(Cbsegm), u32]),
+            "srsran_demod_soft_demodulate": (i32, [i32, vp, vp, i32]),
+            "srsran_demod_soft_demodulate_s": (i32, [i32, vp, vp, i32]),
+            "srsran_demod_soft_demodulate_b": (i32, [i32, vp, vp, i32]),
+            "srsran_sequence_apply_f": (None, [vp, vp, u32, u32]),
+            "srsran_sequence_apply_s": (None, [vp, vp, u32, u32]),
+            "srsran_sequence_apply_c": (None, [vp, vp, u32, u32]),
+            "srsran_sequence_pdsch_apply_f": (None, [vp, vp, C.c_uint16, i32, u32, u32, u32]),
+            "srsran_sequence_pdsch_apply_s": (None, [vp, vp, C.c_uint16, i32, u32, u32, u32]),
+            "srsran_sequence_pdsch_apply_c": (None, [vp, vp, C.c_uint16, i32, u32, u32, u32]),
+            "srsran_sequence_pusch_apply_s": (None, [vp, vp, C.c_uint16, u32, u32, u32]),
+            "srsran_sequence_pusch_apply_c": (None, [vp, vp, C.c_uint16, u32, u32, u32]),
+            "srsran_hip_demod_create": (i32, [C.POINTER(vp)]),
+            "srsran_hip_demod_free": (None, [vp]),
+            "srsran_hip_demod_run": (i32, [vp, vp, vp, i32, C.POINTER(HipDemodJob), u32, vp]),
+            "srsran_hip_sequence_pdsch_seed": (u32, [C.c_uint16, i32, u32, u32]),
+            "srsran_hip_sequence_pusch_seed": (u32, [C.c_uint16, u32, u32]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
             "srsran_hip_cellsearch_free": (None, [vp]),
             "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),

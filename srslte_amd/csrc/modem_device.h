@@ -1,0 +1,54 @@
+// modem_device.h -- parameter blocks and launcher of modem_kernels.hip (soft demodulation + Gold-sequence descrambling)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace phyhip {
+namespace modem {
+
+enum { LLR_I16 = 0, LLR_I8 = 1, LLR_F32 = 2 };
+enum { MOD_PASS = 5 }; // no demodulation: the input already holds LLRs of the output type (srsran_sequence_apply_*)
+
+// Gold sequence jump tables: the generator state at chip 1600 + 512 j.  x1 does not depend on the seed; the x2 state is
+// linear in the 31 seed bits, one column per bit (sequence.c:150-181 keeps the same thing for j = 0 only).
+#define MODEM_SEQ_CHUNK 512u
+#define MODEM_SEQ_NCHUNKS 4096u // 2^21 chips per sequence
+#define MODEM_TILE_BITS 8192u   // soft bits per workgroup = 16 chunks
+
+struct Job {
+  uint32_t mod;     // srsran_mod_t or MOD_PASS
+  uint32_t n;       // symbols (soft bits for MOD_PASS)
+  uint32_t in_off;  // first symbol (cf_t units) / first input soft bit
+  uint32_t out_off; // first output soft bit
+  uint32_t seed;    // c_init
+  uint32_t scramble;
+  uint32_t tile0; // first workgroup of this job
+  uint32_t ntiles;
+};
+
+struct Consts { // thresholds of demod_soft.c, evaluated by the host compiler exactly as the reference's are
+  float t16_tail_s, t16_tail_b; // 2*SCALE/sqrtf(10) (float, 16-QAM scalar tails)
+  float f16, f64a, f64b;        // 2/sqrtf(10), 4/sqrtf(42), 2/sqrtf(42)
+  float c8, c4, c2;             // 8,4,2 / sqrtf(170)
+  float qpsk_s, qpsk_b, qpsk_f; // -SCALE*M_SQRT2 as float
+  int   o16_s, o64a_s, o64b_s, o16_b, o64a_b, o64b_b;
+};
+
+struct Params {
+  const void*     in;
+  void*           out;
+  const Job*      jobs; // device array, or nullptr: `single`
+  Job             single;
+  uint32_t        n_jobs;
+  uint32_t        n_tiles;
+  int             llr_type;
+  const uint32_t* x1_tab;  // MODEM_SEQ_NCHUNKS
+  const uint32_t* x2_cols; // MODEM_SEQ_NCHUNKS x 31
+  Consts          k;
+};
+
+uint32_t   tiles_of(uint32_t mod, uint32_t n);
+hipError_t launch(const Params& p, hipStream_t stream);
+
+} // namespace modem
+} // namespace phyhip

@@ -387,3 +387,75 @@ def sss_detect(symbol, fft_size, N_id_2, M):
     assert orc().orc_sss_m0m1(P(symbol), fft_size, N_id_2, M, C.byref(m0), C.byref(v0), C.byref(m1), C.byref(v1), C.byref(nid),
                               C.byref(sf)) == 0
     return m0.value, m1.value, v0.value, v1.value, nid.value, sf.value
+
+
+# ------------------------------------------------------------------ soft demodulation / descrambling (orc_modem.c)
+LLR_DTYPES = {"s": np.int16, "b": np.int8, "f": np.float32}
+QM = {0: 1, 1: 2, 2: 4, 3: 6, 4: 8}
+
+
+def aligned_empty(n, dtype, align=64):
+    """the reference's SSE loads need 16-byte aligned symbol buffers (demod_soft.c:265 _mm_load_ps)"""
+    isz = np.dtype(dtype).itemsize
+    raw = np.zeros(n * isz + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * isz].view(dtype)
+
+
+def demod_soft(mod, symbols, kind):
+    """orc_demod_soft_{s,b,f}: symbols complex64 [n] -> LLR array of LLR_DTYPES[kind], QM[mod] per symbol"""
+    x = np.ascontiguousarray(symbols, np.complex64)
+    out = np.zeros(x.size * QM[mod], LLR_DTYPES[kind])
+    f = getattr(orc(), "orc_demod_soft_" + kind)
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    assert f(mod, P(x), P(out), x.size) == 0
+    return out
+
+
+def sequence_bits(seed, n):
+    c = np.zeros(n, np.uint8)
+    f = orc().orc_sequence_bits
+    f.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32]
+    f(seed, P(c), n)
+    return c
+
+
+def sequence_apply(x, seed):
+    kind = {np.dtype(np.int16): "s", np.dtype(np.int8): "c", np.dtype(np.float32): "f"}[x.dtype]
+    out = np.zeros_like(x)
+    scratch = np.zeros(max(x.size, 1), np.uint8)
+    f = getattr(orc(), "orc_sequence_apply_" + kind)
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    f(P(x), P(out), x.size, seed, P(scratch))
+    return out
+
+
+def pusch_seed(rnti, nslot, cell_id):
+    f = orc().orc_sequence_pusch_seed
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint16, C.c_uint32, C.c_uint32]
+    return f(rnti, nslot, cell_id)
+
+
+def pdsch_seed(rnti, q, nslot, cell_id):
+    f = orc().orc_sequence_pdsch_seed
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint16, C.c_int, C.c_uint32, C.c_uint32]
+    return f(rnti, q, nslot, cell_id)
+
+
+def qam_symbols(mod, n, seed, snr_db=20.0, scale=1.0):
+    """random points of the LTE constellations (36.211 7.1, unit average power) + noise; returns complex64 [n]"""
+    rng = np.random.default_rng(seed)
+    if mod == 0:
+        b = rng.integers(0, 2, n)
+        s = (1 - 2 * b) * (1 + 1j) / np.sqrt(2)
+    else:
+        m = 1 << mod  # levels per axis: 2, 4, 8, 16
+        lev = 2 * rng.integers(0, m, (2, n)) - (m - 1)
+        s = (lev[0] + 1j * lev[1]) / np.sqrt(2 * (m * m - 1) / 3)
+    sigma = 10 ** (-snr_db / 20) / np.sqrt(2)
+    s = scale * (s + sigma * (rng.normal(size=n) + 1j * rng.normal(size=n)))
+    out = aligned_empty(n, np.complex64)
+    out[:] = s
+    return out

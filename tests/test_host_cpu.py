@@ -74,7 +74,7 @@ REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_of
                     "off_sync_sss_signal": 194096}
 
 
-OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n'
+OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n#include "srsran_amd/phy_modem_abi.h"\n'
 
 
 def _c_sizes(flags, include, extra=""):

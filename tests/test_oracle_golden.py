@@ -60,6 +60,29 @@ def test_rate_dematching_reference_outputs():
         assert zlib.crc32(o.tobytes()) == crc, (K, rv, E, mode)
 
 
+def test_soft_demodulator_and_scrambling_reference_outputs():
+    """srsran_demod_soft_demodulate{,_s,_b} and the Gold sequence of the compiled reference (x86 SIMD body + scalar tails)"""
+    d = np.load(os.path.join(G, "modem_ref.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        mod = int(key[1])
+        for kind in "sbf":
+            got = O.demod_soft(mod, d[key + "_x"], kind)
+            assert np.array_equal(got.view(np.uint8), d[key + "_" + kind].view(np.uint8)), (key, kind)
+    for seed, L in d["seqs"]:
+        c = np.unpackbits(d["seq_%d_%d" % (seed, L)])[:L]
+        assert np.array_equal(O.sequence_bits(int(seed), int(L)), c), (seed, L)
+    for row in d["channel_seeds"]:
+        rnti, nslot, cell, q = [int(v) for v in row[:4]]
+        pusch, pdsch = row[4:16].astype(np.uint8), row[16:28].astype(np.uint8)
+        assert np.array_equal(np.packbits(O.sequence_bits(O.pusch_seed(rnti, nslot, cell), 96)), pusch)
+        assert np.array_equal(np.packbits(O.sequence_bits(O.pdsch_seed(rnti, q, nslot, cell), 96)), pdsch)
+    x = np.array([-32768, 32767, -1, 0, 5] * 20, np.int16)
+    y = O.sequence_apply(x, 77)
+    c = O.sequence_bits(77, x.size)
+    assert np.array_equal(y, np.where(c == 1, -x.astype(np.int32), x).astype(np.int16))
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

@@ -13,6 +13,9 @@ No reference source text is stored.
   tests/golden/ldpc_ref.npz    reference srsran_ldpc_decoder_decode_c (scalar C and AVX2) outputs on seeded LLRs
   tests/golden/ldpc_fs_ref.npz reference float / int16 LDPC decoder outputs on seeded LLRs
   tests/golden/rm_ref.npz      reference srsran_rm_turbo_rx_lut_ / _8bit: seeded inputs, CRC32 of the resulting soft buffers
+  tests/golden/modem_ref.npz   reference srsran_demod_soft_demodulate{,_s,_b} outputs on seeded symbols (all five
+                               modulations, lengths around the SIMD group sizes, in- and out-of-range amplitudes);
+                               scrambling chips recovered from srsran_sequence_apply_s / pusch / pdsch apply
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -265,8 +268,47 @@ def ldpc():
     print("ldpc_examples.npz", os.path.getsize(os.path.join(OUT, "ldpc_examples.npz")))
 
 
+def modem():
+    d = {}
+    cases = []
+    for mod in range(5):
+        for n in (1, 7, 8, 13, 100, 333):
+            for scale in (1.0, 40.0):
+                x = O.qam_symbols(mod, n, seed=mod * 1000 + n, snr_db=12.0, scale=scale)
+                key = "m%d_n%d_s%d" % (mod, n, int(scale))
+                d[key + "_x"] = np.array(x)
+                for kind, fn in (("s", "srsran_demod_soft_demodulate_s"), ("b", "srsran_demod_soft_demodulate_b"),
+                                 ("f", "srsran_demod_soft_demodulate")):
+                    out = O.aligned_empty(n * O.QM[mod], O.LLR_DTYPES[kind])
+                    assert getattr(ref, fn)(mod, P(x), P(out), n) == 0
+                    d[key + "_" + kind] = np.array(out)
+                cases.append(key)
+    d["cases"] = np.array(cases)
+    # scrambling chips: apply to +1 and read the sign
+    seqs = []
+    for seed, L in ((0, 100), (1, 24), (12345, 1000), (0x7FFFFFFF, 47), ((0x1234 << 14) + (7 << 9) + 301, 40000), (987654321, 150000)):
+        one = np.ones(L, np.int16)
+        out = np.zeros(L, np.int16)
+        ref.srsran_sequence_apply_s(P(one), P(out), C.c_uint32(L), C.c_uint32(seed))
+        d["seq_%d_%d" % (seed, L)] = np.packbits(out == -1)
+        seqs.append([seed, L])
+    d["seqs"] = np.array(seqs, dtype=np.int64)
+    ch = []
+    for rnti, nslot, cell, q in ((0x1234, 4, 301, 0), (0xFFFF, 19, 503, 1), (1, 0, 0, 0), (70, 13, 150, 1)):
+        L = 96
+        one = np.ones(L, np.int16)
+        o1 = np.zeros(L, np.int16)
+        o2 = np.zeros(L, np.int16)
+        ref.srsran_sequence_pusch_apply_s(P(one), P(o1), C.c_uint16(rnti), C.c_uint32(nslot), C.c_uint32(cell), C.c_uint32(L))
+        ref.srsran_sequence_pdsch_apply_s(P(one), P(o2), C.c_uint16(rnti), C.c_int(q), C.c_uint32(nslot), C.c_uint32(cell), C.c_uint32(L))
+        ch.append(np.concatenate([[rnti, nslot, cell, q], np.packbits(o1 == -1), np.packbits(o2 == -1)]))
+    d["channel_seeds"] = np.array(ch, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "modem_ref.npz"), **d)
+    print("modem_ref.npz", os.path.getsize(os.path.join(OUT, "modem_ref.npz")))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem}[name]()

@@ -9,11 +9,13 @@ namespace modem {
 enum { LLR_I16 = 0, LLR_I8 = 1, LLR_F32 = 2 };
 enum { MOD_PASS = 5 }; // no demodulation: the input already holds LLRs of the output type (srsran_sequence_apply_*)
 
-// Gold sequence jump tables: the generator state at chip 1600 + 512 j.  x1 does not depend on the seed; the x2 state is
-// linear in the 31 seed bits, one column per bit (sequence.c:150-181 keeps the same thing for j = 0 only).
-#define MODEM_SEQ_CHUNK 512u
-#define MODEM_SEQ_NCHUNKS 4096u // 2^21 chips per sequence
-#define MODEM_TILE_BITS 8192u   // soft bits per workgroup = 16 chunks
+// Gold sequence tables.  x1 does not depend on the seed: its chips (after Nc = 1600) are stored packed.  The x2 register
+// at chip 1600 + 128 j is linear in the 31 seed bits: one column per bit (sequence.c:150-181 keeps the same thing for
+// j = 0 only).  2 MB + 256 KB, resident in L2 / Infinity Cache.
+#define MODEM_SEQ_CHUNK 128u
+#define MODEM_SEQ_NCHUNKS 16384u // 2^21 chips per sequence
+#define MODEM_TILE_SYMS 2048u    // symbols per workgroup
+#define MODEM_TILE_BITS (8u * MODEM_TILE_SYMS) // soft bits per workgroup (256-QAM: 8 per symbol)
 
 struct Job {
   uint32_t mod;     // srsran_mod_t or MOD_PASS
@@ -42,8 +44,9 @@ struct Params {
   uint32_t        n_jobs;
   uint32_t        n_tiles;
   int             llr_type;
-  const uint32_t* x1_tab;  // MODEM_SEQ_NCHUNKS
-  const uint32_t* x2_cols; // MODEM_SEQ_NCHUNKS x 31
+  const uint32_t* tile_job; // job index of every workgroup (device array; unused with `single`)
+  const uint32_t* x1_bits;  // MODEM_SEQ_NCHUNKS x 4 words
+  const uint32_t* x2_cols;  // MODEM_SEQ_NCHUNKS x 31
   Consts          k;
 };
 

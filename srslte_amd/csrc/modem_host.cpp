@@ -33,8 +33,9 @@ bool seq_tables(const uint32_t** x1, const uint32_t** x2)
 {
   std::lock_guard<std::mutex> lk(g_seq.mu);
   if (!g_seq.d_x1 && !g_seq.failed) {
-    // state after Nc = 1600 chips, then every 512 chips; x2 as 31 columns (the map seed -> state is linear over GF(2))
-    std::vector<uint32_t> x1(MODEM_SEQ_NCHUNKS), x2((size_t)MODEM_SEQ_NCHUNKS * 31);
+    // x2: register after Nc = 1600 chips, then every 128 chips, as 31 columns (the map seed -> register is linear over
+    // GF(2)); x1: the chips themselves, 32 per word
+    std::vector<uint32_t> x1((size_t)MODEM_SEQ_NCHUNKS * (MODEM_SEQ_CHUNK / 32)), x2((size_t)MODEM_SEQ_NCHUNKS * 31);
     uint32_t              s1 = 1, col[31];
     for (int i = 0; i < 31; i++) {
       col[i] = 1u << i;
@@ -46,11 +47,11 @@ bool seq_tables(const uint32_t** x1, const uint32_t** x2)
       }
     }
     for (uint32_t j = 0; j < MODEM_SEQ_NCHUNKS; j++) {
-      x1[j] = s1;
       for (int i = 0; i < 31; i++) {
         x2[(size_t)j * 31 + i] = col[i];
       }
       for (uint32_t n = 0; n < MODEM_SEQ_CHUNK / 16; n++) {
+        x1[(size_t)j * (MODEM_SEQ_CHUNK / 32) + n / 2] |= (s1 & 0xffffu) << (16 * (n & 1));
         s1 = adv16_x1(s1);
         for (int i = 0; i < 31; i++) {
           col[i] = adv16_x2(col[i]);
@@ -107,7 +108,7 @@ bool fill_params(modem::Params& p, int llr_type)
   memset(&p, 0, sizeof(p));
   p.llr_type = llr_type;
   p.k        = make_consts();
-  return seq_tables(&p.x1_tab, &p.x2_cols);
+  return seq_tables(&p.x1_bits, &p.x2_cols);
 }
 
 // ---- host-pointer calls: one job, thread-local staging ----------------------------------------------------------------------
@@ -274,6 +275,9 @@ struct srsran_hip_demod {
   modem::Job* d_jobs  = nullptr;
   modem::Job* h_jobs  = nullptr; // pinned
   size_t      cap     = 0;
+  uint32_t*   d_map   = nullptr; // job of every tile
+  uint32_t*   h_map   = nullptr; // pinned
+  size_t      map_cap = 0;
   hipEvent_t  done    = nullptr; // the previous call's kernel has consumed d_jobs / h_jobs
   bool        pending = false;
 };
@@ -306,6 +310,8 @@ extern "C" void srsran_hip_demod_free(srsran_hip_demod_t* h)
   }
   (void)hipFree(h->d_jobs);
   (void)hipHostFree(h->h_jobs);
+  (void)hipFree(h->d_map);
+  (void)hipHostFree(h->h_map);
   (void)hipEventDestroy(h->done);
   delete h;
 }
@@ -354,6 +360,24 @@ extern "C" int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, voi
     h->h_jobs[i] = modem::Job{j.mod, j.nof_symbols, j.symbol_offset, j.llr_offset, j.seed, j.descramble ? 1u : 0u, tiles, nt};
     tiles += nt;
   }
+  if (tiles > h->map_cap) {
+    (void)hipFree(h->d_map);
+    (void)hipHostFree(h->h_map);
+    h->d_map   = nullptr;
+    h->h_map   = nullptr;
+    h->map_cap = 0;
+    const size_t cap = (size_t)tiles + tiles / 2 + 256;
+    PHY_HIP_CHECK(hipMalloc(&h->d_map, cap * sizeof(uint32_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipHostMalloc(&h->h_map, cap * sizeof(uint32_t)), SRSRAN_ERROR);
+    h->map_cap = cap;
+  }
+  for (uint32_t i = 0, t = 0; i < n_jobs; i++) {
+    for (uint32_t k = 0; k < h->h_jobs[i].ntiles; k++) {
+      h->h_map[t++] = i;
+    }
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(h->d_map, h->h_map, tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  p.tile_job = h->d_map;
   p.in      = d_in;
   p.out     = d_llr;
   p.jobs    = h->d_jobs;

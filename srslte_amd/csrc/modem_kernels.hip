@@ -5,10 +5,10 @@
 // The reference writes the LLRs, reads them back and writes them again; here one pass reads 8 B per symbol and writes
 // Qm soft bits: the kernel is a pure HBM stream.
 //
-// One workgroup (256 lanes) = one tile of one job: 1024 symbols (lane l takes symbols l, l+256, l+512, l+768: every load
-// instruction of a wave is one contiguous 512 B) or, without demodulation, 8192 soft bits.  The tile's <= 8192 chips of the
-// scrambling sequence are produced by its first <= 16 lanes, each jumping to a 512-chip boundary with the tables of
-// modem_device.h and running the two shift registers 16 chips at a time, into LDS as packed words.
+// One workgroup (256 lanes) = one tile of one job: 2048 symbols, 512 consecutive ones per wave (lane l takes l, l+64, ...:
+// every load instruction of a wave is one contiguous 512 B, 8 of them in flight) or, without demodulation, 16384 soft bits.
+// Each wave produces its own <= 4096 chips of the scrambling sequence with its first <= 32 lanes, each jumping to a 128-chip boundary
+// with the tables of modem_device.h and running the x2 shift register 16 chips at a time, into LDS as packed words.
 //
 // Arithmetic: the x86 reference mixes a SIMD body (round-to-nearest conversion of symbol * -SCALE, saturating packs,
 // integer thresholds) with scalar tails (truncation, float thresholds); which rule applies depends on the symbol index
@@ -163,38 +163,47 @@ __device__ __forceinline__ void demod_float(float re, float im, const Consts& k,
 
 // ---- scrambling chips of one tile -> LDS --------------------------------------------------------------------------------
 // register = x(n)..x(n+30) in bits 0..30; 16 chips per step (the feedback taps reach back at most 3 chips)
-__device__ __forceinline__ uint32_t step16_x1(uint32_t s)
-{
-  return (s >> 16) | ((((s >> 3) ^ s) & 0xffffu) << 15);
-}
 __device__ __forceinline__ uint32_t step16_x2(uint32_t s)
 {
   return (s >> 16) | ((((s >> 3) ^ (s >> 2) ^ (s >> 1) ^ s) & 0xffffu) << 15);
 }
 
-__device__ __forceinline__ void make_chips(const Params& p, uint32_t seed, uint32_t bit0, uint32_t nbits, uint32_t* cb)
+__device__ __forceinline__ void wave_sync_lds()
 {
-  const uint32_t nch = (nbits + MODEM_SEQ_CHUNK - 1) / MODEM_SEQ_CHUNK;
-  if (threadIdx.x < nch) {
-    const uint32_t j  = bit0 / MODEM_SEQ_CHUNK + threadIdx.x;
-    uint32_t       s1 = p.x1_tab[j];
-    uint32_t       s2 = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// chips bit0 .. bit0 + nbits - 1 (bit0 a multiple of 128, nbits <= MODEM_TILE_BITS / 4) of the sequence -> the wave's LDS strip, packed.
+// One lane per 128 chips: x2 register at the chunk start = XOR of the table columns the seed selects, 8 steps of 16
+// chips; the seed-independent x1 chips come packed from a table.  Waves work independently (no workgroup barrier): while
+// one runs its shift registers the others stream.
+__device__ __forceinline__ void make_chips(const Params& p, uint32_t seed, uint32_t bit0, uint32_t nbits, uint32_t* cbw)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t nch  = (nbits + MODEM_SEQ_CHUNK - 1) / MODEM_SEQ_CHUNK;
+  if (lane < nch) {
+    const uint32_t  j   = bit0 / MODEM_SEQ_CHUNK + lane;
     const uint32_t* col = p.x2_cols + (size_t)j * 31;
+    const uint4     c1  = *(const uint4*)(p.x1_bits + (size_t)j * (MODEM_SEQ_CHUNK / 32));
+    uint32_t        s2  = 0;
 #pragma unroll
     for (int i = 0; i < 31; i++) {
       s2 ^= ((seed >> i) & 1u) ? col[i] : 0u;
     }
+    uint32_t w[4];
 #pragma unroll
-    for (int w = 0; w < 16; w++) {
-      const uint32_t lo = (s1 ^ s2) & 0xffffu;
-      s1                = step16_x1(s1);
+    for (int k = 0; k < 4; k++) {
+      const uint32_t lo = s2 & 0xffffu;
       s2                = step16_x2(s2);
-      const uint32_t hi = (s1 ^ s2) & 0xffffu;
-      s1                = step16_x1(s1);
+      const uint32_t hi = s2 & 0xffffu;
       s2                = step16_x2(s2);
-      cb[threadIdx.x * 16 + w] = lo | (hi << 16);
+      w[k]              = lo | (hi << 16);
     }
+    *(uint4*)(cbw + lane * 4) = make_uint4(w[0] ^ c1.x, w[1] ^ c1.y, w[2] ^ c1.z, w[3] ^ c1.w);
   }
+  wave_sync_lds();
 }
 
 __device__ __forceinline__ uint32_t chips_at(const uint32_t* cb, uint32_t off) // 32 chips starting at tile bit `off`
@@ -276,25 +285,73 @@ __device__ __forceinline__ void store_bits(T* dst, const T* v, bool aligned)
   }
 }
 
-// ---- one tile: 1024 symbols -------------------------------------------------------------------------------------------------
-template <typename T, int MOD>
-__device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint32_t tile, const uint32_t* cb)
+// Soft bits of 64 consecutive symbols whose size per symbol is not a power of two (6, 12, 24 bytes): the lanes' pieces go
+// through a wave-private LDS strip (word stride 3 or 6: conflict-free) and leave as 16-byte stores, contiguous over the wave.
+template <typename T, int QM>
+__device__ __forceinline__ void store_bits_staged(T* wave_dst, const T* v, uint32_t* strip)
 {
-  constexpr int QM   = MOD == 0 ? 1 : 2 * MOD;
-  const float2* sym  = (const float2*)p.in + job.in_off;
-  T*            out  = (T*)p.out + job.out_off;
-  const bool    al   = (((uintptr_t)out) & 15u) == 0;
-  const uint32_t s0  = tile * 1024u;
-  float2        x[4];
+  constexpr int  BYTES = QM * (int)sizeof(T);
+  const uint32_t lane  = threadIdx.x & 63u;
+  if (BYTES == 6) {
+    uint16_t* h = (uint16_t*)strip + lane * 3;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t s = s0 + r * 256u + threadIdx.x;
+    for (int i = 0; i < 3; i++) {
+      h[i] = (uint16_t)((uint32_t)(uint8_t)(int)v[2 * i] | ((uint32_t)(uint8_t)(int)v[2 * i + 1] << 8));
+    }
+  } else {
+    constexpr int W = BYTES / 4;
+    uint32_t*     d = strip + lane * W;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+      if (sizeof(T) == 4) {
+        d[i] = __float_as_uint((float)v[i]);
+      } else {
+        d[i] = (uint32_t)(uint16_t)(int)v[2 * i] | ((uint32_t)(uint16_t)(int)v[2 * i + 1] << 16);
+      }
+    }
+  }
+  wave_sync_lds();
+  constexpr int NQ = 64 * BYTES / 16;
+#pragma unroll
+  for (int k = 0; k < (NQ + 63) / 64; k++) {
+    const uint32_t q = k * 64 + lane;
+    if (q < NQ) {
+      ((uint4*)wave_dst)[q] = ((const uint4*)strip)[q];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- one tile: MODEM_TILE_SYMS symbols, a quarter per wave -------------------------------------------------------------------
+template <typename T, int MOD>
+__device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint32_t tile, uint32_t* cbw, uint32_t* strip)
+{
+  constexpr int  QM    = MOD == 0 ? 1 : 2 * MOD;
+  constexpr int  BYTES = QM * (int)sizeof(T);
+  constexpr bool STAGE = BYTES == 6 || BYTES == 12 || BYTES == 24;
+  const float2*  sym   = (const float2*)p.in + job.in_off;
+  T*             out   = (T*)p.out + job.out_off;
+  const bool     al    = (((uintptr_t)out) & 15u) == 0;
+  const uint32_t lane  = threadIdx.x & 63u;
+  const uint32_t w0    = tile * MODEM_TILE_SYMS + (threadIdx.x >> 6) * (MODEM_TILE_SYMS / 4); // first symbol of this wave
+  if (w0 >= job.n) {
+    return;
+  }
+  constexpr int R = MODEM_TILE_SYMS / 256;
+  float2        x[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const uint32_t s = w0 + r * 64u + lane;
     x[r]             = s < job.n ? sym[s] : make_float2(0.f, 0.f);
   }
+  if (job.scramble) { // the symbol loads are in flight while the first lanes run the shift registers
+    make_chips(p, job.seed, w0 * QM, min((MODEM_TILE_SYMS / 4) * QM, (job.n - w0) * QM), cbw);
+  }
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const uint32_t ls = r * 256u + threadIdx.x;
-    const uint32_t s  = s0 + ls;
+  for (int r = 0; r < R; r++) {
+    const uint32_t sw   = w0 + r * 64u;     // first symbol of this pass
+    const uint32_t s    = sw + lane;
+    const bool     full = sw + 64 <= job.n; // wave-uniform
     if (s >= job.n) {
       continue;
     }
@@ -310,33 +367,44 @@ __device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint
       }
     }
     if (job.scramble) {
-      const uint32_t c = chips_at(cb, ls * QM);
+      const uint32_t c = chips_at(cbw, (r * 64u + lane) * QM);
 #pragma unroll
       for (int i = 0; i < QM; i++) {
         v[i] = flip<T>(v[i], (c >> i) & 1u);
       }
     }
-    store_bits<T, QM>(out + (size_t)s * QM, v, al);
+    if (STAGE && al && full) {
+      store_bits_staged<T, QM>(out + (size_t)sw * QM, v, strip);
+    } else {
+      store_bits<T, QM>(out + (size_t)s * QM, v, al);
+    }
   }
 }
 
-// ---- one tile of srsran_sequence_apply_*: 8192 soft bits ----------------------------------------------------------------------
+// ---- one tile of srsran_sequence_apply_*: MODEM_TILE_BITS soft bits, a quarter per wave ------------------------------------------
 template <typename T>
-__device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint32_t tile, const uint32_t* cb)
+__device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint32_t tile, uint32_t* cbw)
 {
-  constexpr uint32_t V  = 16 / sizeof(T);
-  const T*           in = (const T*)p.in + job.in_off;
-  T*                 out = (T*)p.out + job.out_off;
-  const bool         al  = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0;
-  const uint32_t     e0  = tile * MODEM_TILE_BITS;
+  constexpr uint32_t V    = 16 / sizeof(T);
+  const T*           in   = (const T*)p.in + job.in_off;
+  T*                 out  = (T*)p.out + job.out_off;
+  const bool         al   = ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0;
+  const uint32_t     lane = threadIdx.x & 63u;
+  const uint32_t     w0   = tile * MODEM_TILE_BITS + (threadIdx.x >> 6) * (MODEM_TILE_BITS / 4);
+  if (w0 >= job.n) {
+    return;
+  }
+  if (job.scramble) {
+    make_chips(p, job.seed, w0, min(MODEM_TILE_BITS / 4, job.n - w0), cbw);
+  }
 #pragma unroll
-  for (uint32_t r = 0; r < MODEM_TILE_BITS / (256 * V); r++) {
-    const uint32_t le = (r * 256u + threadIdx.x) * V;
-    const uint32_t e  = e0 + le;
+  for (uint32_t r = 0; r < MODEM_TILE_BITS / 4 / (64 * V); r++) {
+    const uint32_t le = (r * 64u + lane) * V;
+    const uint32_t e  = w0 + le;
     if (e >= job.n) {
       continue;
     }
-    const uint32_t c = job.scramble ? chips_at(cb, le) : 0u;
+    const uint32_t c = job.scramble ? chips_at(cbw, le) : 0u;
     if (al && e + V <= job.n) {
       union {
         uint4 q;
@@ -359,25 +427,17 @@ __device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint3
 template <typename T>
 __global__ __launch_bounds__(256) void modem_kernel(const Params p)
 {
-  __shared__ uint32_t cb[16 * 16 + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t cb[4][MODEM_TILE_BITS / 128 + 4];
+  __shared__ __attribute__((aligned(16))) uint32_t strips[4][384];
   __shared__ Job      sjob;
-  // job of this workgroup: binary search over the first-tile prefix
-  if (threadIdx.x == 0) {
-    if (p.jobs == nullptr) {
-      sjob = p.single;
-    } else {
-      uint32_t lo = 0, hi = p.n_jobs - 1;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (p.jobs[mid].tile0 <= blockIdx.x) {
-          lo = mid;
-        } else {
-          hi = mid - 1;
-        }
-      }
-      sjob = p.jobs[lo];
-    }
-    cb[256] = 0;
+  // job of this workgroup: the host lists the job of every tile
+  const uint32_t lo = p.jobs ? p.tile_job[blockIdx.x] : 0u;
+  if (threadIdx.x < sizeof(Job) / 4) {
+    const uint32_t* src = p.jobs ? (const uint32_t*)(p.jobs + lo) : (const uint32_t*)&p.single;
+    ((uint32_t*)&sjob)[threadIdx.x] = src[threadIdx.x];
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    cb[threadIdx.x >> 6][MODEM_TILE_BITS / 128] = 0; // chips_at reads one word past the last one
   }
   __syncthreads();
   const Job      job  = sjob;
@@ -385,32 +445,26 @@ __global__ __launch_bounds__(256) void modem_kernel(const Params p)
   if (tile >= job.ntiles) {
     return;
   }
-  const uint32_t qm        = job.mod == 0 ? 1u : 2u * job.mod;
-  const uint32_t tile_bits = job.mod == MOD_PASS ? MODEM_TILE_BITS : 1024u * qm;
-  const uint32_t all_bits  = job.mod == MOD_PASS ? job.n : job.n * qm;
-  if (job.scramble) {
-    const uint32_t bit0 = tile * tile_bits;
-    make_chips(p, job.seed, bit0, min(tile_bits, all_bits - bit0), cb);
-    __syncthreads();
-  }
+  uint32_t* cbw   = cb[threadIdx.x >> 6];
+  uint32_t* strip = strips[threadIdx.x >> 6];
   switch (job.mod) {
     case 0:
-      demod_tile<T, 0>(p, job, tile, cb);
+      demod_tile<T, 0>(p, job, tile, cbw, strip);
       break;
     case 1:
-      demod_tile<T, 1>(p, job, tile, cb);
+      demod_tile<T, 1>(p, job, tile, cbw, strip);
       break;
     case 2:
-      demod_tile<T, 2>(p, job, tile, cb);
+      demod_tile<T, 2>(p, job, tile, cbw, strip);
       break;
     case 3:
-      demod_tile<T, 3>(p, job, tile, cb);
+      demod_tile<T, 3>(p, job, tile, cbw, strip);
       break;
     case 4:
-      demod_tile<T, 4>(p, job, tile, cb);
+      demod_tile<T, 4>(p, job, tile, cbw, strip);
       break;
     default:
-      pass_tile<T>(p, job, tile, cb);
+      pass_tile<T>(p, job, tile, cbw);
       break;
   }
 }
@@ -419,7 +473,7 @@ __global__ __launch_bounds__(256) void modem_kernel(const Params p)
 
 uint32_t tiles_of(uint32_t mod, uint32_t n)
 {
-  return mod == MOD_PASS ? ceil_div(n, MODEM_TILE_BITS) : ceil_div(n, 1024u);
+  return mod == MOD_PASS ? ceil_div(n, MODEM_TILE_BITS) : ceil_div(n, MODEM_TILE_SYMS);
 }
 
 hipError_t launch(const Params& p, hipStream_t stream)

@@ -142,10 +142,10 @@ def rm_table(K, rv, nsb=0):
     return t
 
 
-def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0):
+def tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng):
     """transmit side of one transport block (36.212 5.1.1-5.1.5 as sch.c encode_tb does it: CRC24A, segmentation,
-    CRC24B per block, turbo code, rate matching of redundancy version rv, concatenation) + BPSK over AWGN.
-    Returns (int16 soft bits e, payload bytes incl. the CRC24A)"""
+    CRC24B per block, turbo code, rate matching of redundancy version rv, concatenation).
+    Returns (coded bits e, uint8 [<= nof_e_bits]; payload bytes incl. the CRC24A)"""
     s = cbsegm(tbs)
     assert s["F"] == 0
     payload = rng.integers(0, 2, tbs).astype(np.uint8)
@@ -164,11 +164,42 @@ def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0):
         E = n_e if i <= s["C"] - gamma - 1 else n_e + (Qm if gamma else 0)  # transmit-side split (sch.c:296-300)
         t = rm_table(K, rv)
         e.append(d[t[np.arange(E) % t.size]])
-    tx = np.concatenate(e).astype(np.float64)
+    return np.concatenate(e).astype(np.uint8), np.packbits(b)
+
+
+def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0):
+    """tb_coded_bits + BPSK over AWGN.  Returns (int16 soft bits e, payload bytes incl. the CRC24A)"""
+    tx, payload = tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng)
+    tx = tx.astype(np.float64)
     sigma = 10 ** (-esn0_db / 20)
     y = (2.0 * tx - 1.0) + sigma * rng.standard_normal(tx.size)
     pad = np.zeros(nof_e_bits - tx.size)
-    return np.clip(np.round(scale * np.concatenate([y, pad])), -32768, 32767).astype(np.int16), np.packbits(b)
+    return np.clip(np.round(scale * np.concatenate([y, pad])), -32768, 32767).astype(np.int16), payload
+
+
+_AMP = {1: {(): 1}, 2: {(0,): 1, (1,): 3}, 3: {(0, 1): 1, (0, 0): 3, (1, 0): 5, (1, 1): 7},
+        4: {(0, 1, 1): 1, (0, 1, 0): 3, (0, 0, 0): 5, (0, 0, 1): 7, (1, 0, 1): 9, (1, 0, 0): 11, (1, 1, 0): 13, (1, 1, 1): 15}}
+
+
+def modulate(bits, mod):
+    """36.211 7.1 constellations, written from the decision rules of demod_soft.c (bit 0/1 of a symbol = sign of I/Q,
+    the following pairs select the amplitude); returns complex128 [len(bits) / Qm], unit average power"""
+    qm = QM[mod]
+    b = np.asarray(bits, np.uint8).reshape(-1, qm)
+    if mod == 0:
+        return (1 - 2.0 * b[:, 0]) * (1 + 1j) / np.sqrt(2)
+    half = qm // 2
+    tab = np.zeros(1 << (half - 1))
+    for k, v in _AMP[half].items():
+        tab[int("".join(map(str, k)) or "0", 2)] = v
+    axes = []
+    for c in (0, 1):
+        idx = np.zeros(b.shape[0], np.int64)
+        for j in range(1, half):
+            idx = (idx << 1) | b[:, 2 * j + c]
+        axes.append((1 - 2.0 * b[:, c]) * tab[idx])
+    m = 1 << half
+    return (axes[0] + 1j * axes[1]) / np.sqrt(2 * (m * m - 1) / 3)
 
 
 def sch_decode_tb(tbs, Qm, rv, e_bits, softbuf, cb_crc, max_iterations, cb_data=None):

@@ -120,6 +120,12 @@ int orc_ldpc_decode_f(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof
 /* ldpc_enc_c.c / ldpc_encoder.c: systematic encoder, bit per byte, filler bits (value 254) allowed.
  * output: N-2Z bits (cdwd_rm_length = full) */
 int orc_ldpc_encode(const orc_ldpc_graph_t* g, const uint8_t* message, uint8_t* codeword);
+/* srsran_ldpc_encoder_encode_rm (ldpc_encoder.c:55-95,584-591): raw systematic part, parity of the rows cdwd_rm_length needs */
+int orc_ldpc_encode_rm(const orc_ldpc_graph_t* g, const uint8_t* input, uint8_t* output, uint32_t cdwd_rm_length);
+/* srsran_ldpc_rm_tx / srsran_ldpc_rm_rx_{c,s,f} (ldpc_rm.c); type: 0 int8, 1 int16, 2 float; Qm = bits per symbol */
+int orc_ldpc_rm_tx(const uint8_t* input, uint8_t* output, uint32_t E, int bg, uint32_t ls, uint32_t rv, uint32_t Qm, uint32_t Nref);
+int orc_ldpc_rm_rx(int type, const void* input, void* output, uint32_t E, uint32_t F, int bg, uint32_t ls, uint32_t rv, uint32_t Qm,
+                   uint32_t Nref);
 
 /* crc.c:  bit-per-byte CRC as srsran_crc_checksum (no reversal) */
 uint32_t orc_crc_bits(uint32_t poly, int order, const uint8_t* bits, int len);

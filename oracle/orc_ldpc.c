@@ -17,6 +17,7 @@
  */
 #include "oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -352,4 +353,118 @@ int orc_ldpc_encode(const orc_ldpc_graph_t* g, const uint8_t* message, uint8_t* 
   free(x);
   free(lam);
   return 0;
+}
+
+/* ---------------------------------------------------------------- encoder with the reference's output conventions
+ * ldpc_encoder.c:55-95 (encode_c): the systematic part is the raw input (filler flags kept), only the parity blocks of the
+ * first n_layers check rows are written, n_layers follows from cdwd_rm_length after its clamping / rounding; everything
+ * beyond is left untouched. */
+int orc_ldpc_encode_rm(const orc_ldpc_graph_t* g, const uint8_t* input, uint8_t* output, uint32_t cdwd_rm_length)
+{
+  const uint32_t ls = g->ls, full = (uint32_t)(g->bgN - 2) * ls;
+  if (cdwd_rm_length > full) {
+    cdwd_rm_length = full;
+  }
+  if (cdwd_rm_length < (uint32_t)(g->bgK + 2) * ls) {
+    cdwd_rm_length = (uint32_t)(g->bgK + 2) * ls;
+  }
+  if (cdwd_rm_length % ls) {
+    cdwd_rm_length = (cdwd_rm_length / ls + 1) * ls;
+  }
+  uint8_t* cw = malloc(full);
+  if (!cw || orc_ldpc_encode(g, input, cw) != 0) {
+    free(cw);
+    return -1;
+  }
+  memcpy(output, input + 2 * ls, (size_t)(g->bgK - 2) * ls);
+  memcpy(output + (size_t)(g->bgK - 2) * ls, cw + (size_t)(g->bgK - 2) * ls, cdwd_rm_length - (size_t)(g->bgK - 2) * ls);
+  free(cw);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- rate matching, ldpc_rm.c
+ * init_rm (ldpc_rm.c:113-167): N = 66 Z / 50 Z (the codeword without the two punctured blocks), starting positions
+ * k0 = Z * BASEK0[rv] (scaled when the circular buffer is limited to Nref), filler positions [K - 2Z - F, K - 2Z). */
+static int rm_params(int bg, uint32_t ls, uint32_t rv, uint32_t Nref, uint32_t* N, uint32_t* K, uint32_t* Ncb, uint32_t* k0)
+{
+  static const uint32_t basek0[4][2] = {{0, 0}, {17, 13}, {33, 25}, {56, 43}}; /* TS 38.212 table 5.4.2.1-2 */
+  if (bg < 0 || bg > 1 || rv > 3) {
+    return -1;
+  }
+  *N = ls * (bg == 0 ? 66 : 50);
+  *K = ls * (bg == 0 ? 22 : 10);
+  if (*N <= Nref) {
+    *Ncb = *N;
+    *k0  = ls * basek0[rv][bg];
+  } else {
+    *Ncb = Nref;
+    *k0  = ls * ((basek0[rv][bg] * Nref) / *N);
+  }
+  return 0;
+}
+
+/* srsran_ldpc_rm_tx (ldpc_rm.c:173-193,348-362,582-610): select E non-filler bits from k0 on, then interleave */
+int orc_ldpc_rm_tx(const uint8_t* input, uint8_t* output, uint32_t E, int bg, uint32_t ls, uint32_t rv, uint32_t Qm, uint32_t Nref)
+{
+  uint32_t N, K, Ncb, k0;
+  if (rm_params(bg, ls, rv, Nref, &N, &K, &Ncb, &k0) || Qm == 0 || E % Qm) {
+    return -1;
+  }
+  uint8_t* tmp = malloc(E ? E : 1);
+  for (uint32_t k = 0, j = 0; k < E; j++) {
+    uint32_t i = (k0 + j) % Ncb;
+    if (input[i] != 254) {
+      tmp[k++] = input[i];
+    }
+  }
+  const uint32_t cols = E / Qm;
+  for (uint32_t j = 0; j < cols; j++) {
+    for (uint32_t i = 0; i < Qm; i++) {
+      output[i + j * Qm] = tmp[i * cols + j];
+    }
+  }
+  free(tmp);
+  return 0;
+}
+
+/* srsran_ldpc_rm_rx_{c,s,f} (ldpc_rm.c:203-346,365-411,612-706): de-interleave, mark fillers as "infinity", accumulate
+ * the E soft bits in transmission order with saturation at +-63 / +-16383 (none for float).  type: 0 int8, 1 int16,
+ * 2 float.  Returns min(k0 + E, Ncb) like the int8 function (the other two return 0 in the reference). */
+int orc_ldpc_rm_rx(int type, const void* input, void* output, uint32_t E, uint32_t F, int bg, uint32_t ls, uint32_t rv, uint32_t Qm,
+                   uint32_t Nref)
+{
+  uint32_t N, K, Ncb, k0;
+  if (rm_params(bg, ls, rv, Nref, &N, &K, &Ncb, &k0) || Qm == 0 || E % Qm) {
+    return -1;
+  }
+  const uint32_t end_ex = K - 2 * ls, ini_ex = end_ex - F, cols = E / Qm;
+  for (uint32_t i = ini_ex; i < end_ex; i++) {
+    if (type == 0) {
+      ((int8_t*)output)[i] = 127;
+    } else if (type == 1) {
+      ((int16_t*)output)[i] = 32767;
+    } else {
+      ((float*)output)[i] = INFINITY;
+    }
+  }
+  for (uint32_t k = 0, j = 0; k < E; j++) {
+    uint32_t idx = (k0 + j) % Ncb;
+    if (idx >= ini_ex && idx < end_ex) {
+      continue;
+    }
+    const uint32_t src = Qm == 1 ? k : (k % cols) * Qm + k / cols; /* tmp[i*cols + j] = in[j*Qm + i] */
+    if (type == 0) {
+      long t = (long)((int8_t*)output)[idx] + ((const int8_t*)input)[src];
+      t      = t > 63 ? 63 : (t < -63 ? -63 : t);
+      ((int8_t*)output)[idx] = (int8_t)t;
+    } else if (type == 1) {
+      long t = (long)((int16_t*)output)[idx] + ((const int16_t*)input)[src];
+      t      = t > 16383 ? 16383 : (t < -16383 ? -16383 : t);
+      ((int16_t*)output)[idx] = (int16_t)t;
+    } else {
+      ((float*)output)[idx] = ((float*)output)[idx] + ((const float*)input)[src];
+    }
+    k++;
+  }
+  return (int)(k0 + E < Ncb ? k0 + E : Ncb);
 }

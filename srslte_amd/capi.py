@@ -127,6 +127,22 @@ class HipDemodJob(C.Structure):
 LLR_SHORT, LLR_BYTE, LLR_FLOAT, MOD_NONE = 0, 1, 2, 5
 
 
+class LdpcRm(C.Structure):  # srsran_ldpc_rm_t, ldpc_rm.h:37-52
+    _fields_ = [("ptr", C.c_void_p), ("bg", C.c_int), ("ls", C.c_uint16), ("N", C.c_uint32), ("E", C.c_uint32), ("K", C.c_uint32),
+                ("F", C.c_uint32), ("k0", C.c_uint32), ("mod_order", C.c_uint32), ("Ncb", C.c_uint32)]
+
+
+class LdpcEncoder(C.Structure):  # srsran_ldpc_encoder_t, ldpc_encoder.h:53-74
+    _fields_ = [("ptr", C.c_void_p), ("bg", C.c_int), ("ls", C.c_uint16), ("bgN", C.c_uint8), ("liftN", C.c_uint16), ("bgM", C.c_uint8),
+                ("liftM", C.c_uint16), ("bgK", C.c_uint8), ("liftK", C.c_uint16), ("pcm", C.c_void_p), ("free", C.c_void_p),
+                ("encode", C.c_void_p), ("encode_high_rate", C.c_void_p), ("encode_high_rate_avx2", C.c_void_p),
+                ("encode_high_rate_avx512", C.c_void_p)]
+
+
+class HipLdpcCb(C.Structure):
+    _fields_ = [("in_offset", C.c_uint32), ("out_offset", C.c_uint32), ("E", C.c_uint32)]
+
+
 class HipCell(C.Structure):
     _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
                 ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
@@ -371,6 +387,27 @@ def lib():
             "srsran_hip_sch_free": (None, [vp]),
             "srsran_hip_sch_decode": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
             "srsran_cbsegm": (i32, [C.POINTER(Cbsegm), u32]),
+            "srsran_ldpc_rm_tx_init": (i32, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_init_f": (i32, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_init_s": (i32, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_init_c": (i32, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_tx_free": (None, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_free_f": (None, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_free_s": (None, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_rx_free_c": (None, [C.POINTER(LdpcRm)]),
+            "srsran_ldpc_rm_tx": (i32, [C.POINTER(LdpcRm), vp, vp, u32, i32, u32, C.c_uint8, i32, u32]),
+            "srsran_ldpc_rm_rx_f": (i32, [C.POINTER(LdpcRm), vp, vp, u32, u32, i32, u32, C.c_uint8, i32, u32]),
+            "srsran_ldpc_rm_rx_s": (i32, [C.POINTER(LdpcRm), vp, vp, u32, u32, i32, u32, C.c_uint8, i32, u32]),
+            "srsran_ldpc_rm_rx_c": (i32, [C.POINTER(LdpcRm), vp, vp, u32, u32, i32, u32, C.c_uint8, i32, u32]),
+            "srsran_ldpc_encoder_init": (i32, [C.POINTER(LdpcEncoder), i32, i32, C.c_uint16]),
+            "srsran_ldpc_encoder_free": (None, [C.POINTER(LdpcEncoder)]),
+            "srsran_ldpc_encoder_encode": (i32, [C.POINTER(LdpcEncoder), vp, vp, u32]),
+            "srsran_ldpc_encoder_encode_rm": (i32, [C.POINTER(LdpcEncoder), vp, vp, u32, u32]),
+            "srsran_hip_nr_sch_create": (i32, [C.POINTER(vp)]),
+            "srsran_hip_nr_sch_free": (None, [vp]),
+            "srsran_hip_ldpc_rm_rx_batch": (i32, [vp, i32, vp, vp, C.POINTER(HipLdpcCb), u32, u32, i32, u32, u32, i32, u32, vp]),
+            "srsran_hip_ldpc_rm_tx_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, u32, i32, u32, vp]),
+            "srsran_hip_ldpc_encode_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, vp]),
             "srsran_demod_soft_demodulate": (i32, [i32, vp, vp, i32]),
             "srsran_demod_soft_demodulate_s": (i32, [i32, vp, vp, i32]),
             "srsran_demod_soft_demodulate_b": (i32, [i32, vp, vp, i32]),

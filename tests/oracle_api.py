@@ -490,3 +490,33 @@ def qam_symbols(mod, n, seed, snr_db=20.0, scale=1.0):
     out = aligned_empty(n, np.complex64)
     out[:] = s
     return out
+
+
+# ------------------------------------------------------------------ NR LDPC rate matching / encoder (orc_ldpc.c)
+def ldpc_encode_rm(bg, ls, msg, cdwd_rm_length, fill=7):
+    """orc_ldpc_encode_rm: msg uint8 [bgK ls] (254 = filler) -> (bgN - 2) ls bytes; bytes the encoder does not write keep `fill`"""
+    g = ldpc_graph(bg, ls)
+    out = np.full((g.bgN - 2) * ls, fill, np.uint8)
+    f = orc().orc_ldpc_encode_rm
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    assert f(C.byref(g), P(np.ascontiguousarray(msg, np.uint8)), P(out), cdwd_rm_length) == 0
+    return out
+
+
+def ldpc_rm_tx(cw, E, bg, ls, rv, mod, Nref):
+    out = np.zeros(E, np.uint8)
+    f = orc().orc_ldpc_rm_tx
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    assert f(P(np.ascontiguousarray(cw, np.uint8)), P(out), E, bg, ls, rv, QM[mod], Nref) == 0
+    return out
+
+
+def ldpc_rm_rx(x, base, F, bg, ls, rv, mod, Nref):
+    """orc_ldpc_rm_rx: accumulates the soft bits x into a copy of the soft buffer `base` [N]; returns (buffer, n_llr)"""
+    typ = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.float32): 2}[x.dtype]
+    out = np.array(base, dtype=x.dtype)
+    f = orc().orc_ldpc_rm_rx
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    r = f(typ, P(np.ascontiguousarray(x)), P(out), x.size, F, bg, ls, rv, QM[mod], Nref)
+    assert r >= 0
+    return out, r

@@ -62,6 +62,8 @@ def test_struct_layout_matches_ctypes_mirror(L):
     assert sizes["srsran_cp_synch_t"] == C.sizeof(capi.CpSynch)
     assert sizes["off_sync_cfo_corr_frame"] == capi.Sync.cfo_corr_frame.offset
     assert sizes["off_sync_sss_signal"] == capi.Sync.sss_signal.offset
+    assert sizes["srsran_ldpc_rm_t"] == C.sizeof(capi.LdpcRm) and sizes["off_ldpc_rm_Ncb"] == capi.LdpcRm.Ncb.offset
+    assert sizes["srsran_ldpc_encoder_t"] == C.sizeof(capi.LdpcEncoder) and sizes["off_ldpc_encoder_encode"] == capi.LdpcEncoder.encode.offset
 
 
 # sizeof/offsetof recorded from the reference headers (lib/include/srsran/phy/...) with gcc 11, x86-64
@@ -71,10 +73,11 @@ REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_of
                     "srsran_pss_t": 35248, "srsran_sss_t": 38888, "srsran_dft_precoding_t": 5336,
                     "off_pss_conv_output_avg": 1864, "off_pss_tmp_ce": 34744, "off_sss_fc_tables": 3672,
                     "srsran_sync_t": 226864, "srsran_cfo_t": 40, "srsran_cp_synch_t": 16, "off_sync_cfo_corr_frame": 144800,
-                    "off_sync_sss_signal": 194096}
+                    "off_sync_sss_signal": 194096, "srsran_ldpc_rm_t": 48, "srsran_ldpc_encoder_t": 80, "off_ldpc_rm_Ncb": 40,
+                    "off_ldpc_encoder_encode": 48}
 
 
-OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n#include "srsran_amd/phy_modem_abi.h"\n'
+OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n#include "srsran_amd/phy_modem_abi.h"\n#include "srsran_amd/phy_nr_sch_abi.h"\n'
 
 
 def _c_sizes(flags, include, extra=""):
@@ -95,6 +98,10 @@ int main(void) {
   printf("srsran_sync_t %zu\\n", sizeof(srsran_sync_t));
   printf("srsran_cfo_t %zu\\n", sizeof(srsran_cfo_t));
   printf("srsran_cp_synch_t %zu\\n", sizeof(srsran_cp_synch_t));
+  printf("srsran_ldpc_rm_t %zu\\n", sizeof(srsran_ldpc_rm_t));
+  printf("srsran_ldpc_encoder_t %zu\\n", sizeof(srsran_ldpc_encoder_t));
+  printf("off_ldpc_rm_Ncb %zu\\n", offsetof(srsran_ldpc_rm_t, Ncb));
+  printf("off_ldpc_encoder_encode %zu\\n", offsetof(srsran_ldpc_encoder_t, encode));
   printf("off_sync_cfo_corr_frame %zu\\n", offsetof(srsran_sync_t, cfo_corr_frame));
   printf("off_sync_sss_signal %zu\\n", offsetof(srsran_sync_t, sss_signal));
   printf("off_pss_conv_output_avg %zu\\n", offsetof(srsran_pss_t, conv_output_avg));
@@ -123,7 +130,8 @@ def test_struct_layout_matches_recorded_reference(L):
 def test_struct_layout_matches_reference():
     inc = ('#include <complex.h>\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
            '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n#include "srsran/phy/sync/pss.h"\n'
-           '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n#include "srsran/phy/sync/sync.h"\n')
+           '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n#include "srsran/phy/sync/sync.h"\n'
+           '#include "srsran/phy/fec/ldpc/ldpc_rm.h"\n#include "srsran/phy/fec/ldpc/ldpc_encoder.h"\n')
     theirs = _c_sizes(["-I", "/root/reference/lib/include"], inc)
     assert theirs == REFERENCE_LAYOUT
 

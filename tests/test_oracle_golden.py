@@ -83,6 +83,34 @@ def test_soft_demodulator_and_scrambling_reference_outputs():
     assert np.array_equal(y, np.where(c == 1, -x.astype(np.int32), x).astype(np.int16))
 
 
+def _rm_case(key):
+    bg, ls, F, rv, mod, Nref, E = [int(t.lstrip("bgzfrvmne")) for t in key.split("_")[1:]]
+    return bg, ls, F, rv, mod, Nref, E
+
+
+def test_ldpc_encoder_and_rate_matching_reference_outputs():
+    """srsran_ldpc_encoder_encode_rm (C and AVX2 agree), srsran_ldpc_rm_tx and srsran_ldpc_rm_rx_{c,s,f} of the compiled reference"""
+    d = np.load(os.path.join(G, "ldpc_tx_ref.npz"))
+    for key in d["enc_cases"]:
+        key = str(key)
+        bg, ls, F, rmlen = [int(t.lstrip("bgzfr")) for t in key.split("_")[1:]]
+        assert np.array_equal(O.ldpc_encode_rm(bg, ls, d[key + "_msg"], rmlen), d[key + "_cw"]), key
+    for key in d["rm_cases"]:
+        key = str(key)
+        bg, ls, F, rv, mod, Nref, E = _rm_case(key)
+        N = ls * (66 if bg == 0 else 50)
+        cw = d["enc_bg%d_z%d_f%d_r%d_cw" % (bg, ls, F, N)]
+        assert np.array_equal(np.packbits(O.ldpc_rm_tx(cw, E, bg, ls, rv, mod, Nref)), d[key + "_tx"]), key
+        want = d[key + "_rx"]
+        for i, (dt, mul) in enumerate(((np.int8, 1), (np.int16, 200), (np.float32, 0.25))):
+            x = (d[key + "_x"].astype(np.float64) * mul).astype(dt)
+            base = (d[key + "_base"].astype(np.float64) * mul).astype(dt)
+            out, r = O.ldpc_rm_rx(x, base, F, bg, ls, rv, mod, Nref)
+            assert zlib.crc32(out.tobytes()) == want[2 * i], (key, dt)
+            if i == 0:
+                assert r == want[1]
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

@@ -16,6 +16,8 @@ No reference source text is stored.
   tests/golden/modem_ref.npz   reference srsran_demod_soft_demodulate{,_s,_b} outputs on seeded symbols (all five
                                modulations, lengths around the SIMD group sizes, in- and out-of-range amplitudes);
                                scrambling chips recovered from srsran_sequence_apply_s / pusch / pdsch apply
+  tests/golden/ldpc_tx_ref.npz reference LDPC encoder (C and AVX2: equal) code words with and without filler bits, srsran_ldpc_rm_tx
+                               outputs and srsran_ldpc_rm_rx_{c,s,f} soft buffers (as CRC32) on stored inputs
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -268,6 +270,63 @@ def ldpc():
     print("ldpc_examples.npz", os.path.getsize(os.path.join(OUT, "ldpc_examples.npz")))
 
 
+def ldpc_tx():
+    d = {}
+    rng = np.random.default_rng(77)
+    enc_cases, rm_cases = [], []
+    QMS = [1, 2, 4, 6, 8]
+    for bg, ls in ((0, 384), (0, 2), (1, 208), (0, 52), (1, 11), (1, 384), (0, 224), (1, 15)):
+        N, K = ls * (66 if bg == 0 else 50), ls * (22 if bg == 0 else 10)
+        for F in (0, min(ls, 20)):
+            msg = rng.integers(0, 2, K).astype(np.uint8)
+            if F:
+                msg[K - F:] = 254
+            for rmlen in (N, N // 2 + 3):
+                outs = []
+                for typ in (0, 1):
+                    enc = C.create_string_buffer(256)
+                    assert ref.srsran_ldpc_encoder_init(enc, typ, bg, C.c_uint16(ls)) == 0
+                    o = np.full(N, 7, np.uint8)
+                    assert ref.srsran_ldpc_encoder_encode_rm(enc, P(msg), P(o), C.c_uint32(K), C.c_uint32(rmlen)) == 0
+                    ref.srsran_ldpc_encoder_free(enc)
+                    outs.append(o)
+                assert np.array_equal(outs[0], outs[1])
+                key = "enc_bg%d_z%d_f%d_r%d" % (bg, ls, F, rmlen)
+                d[key + "_msg"], d[key + "_cw"] = msg, outs[0]
+                enc_cases.append(key)
+            cw = d["enc_bg%d_z%d_f%d_r%d_cw" % (bg, ls, F, N)]
+            for rv, mod, nref_on, emul in ((0, 1, 0, 0.6), (1, 3, 0, 1.0), (2, 2, 1, 0.4), (3, 4, 0, 2.3), (0, 0, 1, 1.5))[:5 if ls < 200 else (2 if F else 0)]:
+                Qm = QMS[mod]
+                Nref = (N * 2 // 3 // ls * ls + 7) if nref_on else N
+                E = max(Qm, int(N * emul) // Qm * Qm)
+                q = C.create_string_buffer(64)
+                assert ref.srsran_ldpc_rm_tx_init(q) == 0
+                tx = np.zeros(E, np.uint8)
+                ref.srsran_ldpc_rm_tx(q, P(cw), P(tx), C.c_uint32(E), C.c_int(bg), C.c_uint32(ls), C.c_uint8(rv), C.c_int(mod), C.c_uint32(Nref))
+                ref.srsran_ldpc_rm_tx_free(q)
+                key = "rm_bg%d_z%d_f%d_rv%d_m%d_n%d_e%d" % (bg, ls, F, rv, mod, Nref, E)
+                d[key + "_tx"] = np.packbits(tx)
+                x8 = rng.integers(-50, 51, E).astype(np.int8)
+                base = rng.integers(-20, 21, N).astype(np.int8)
+                d[key + "_x"], d[key + "_base"] = x8, base
+                crcs = []
+                for dt, init, fn, free, mul in ((np.int8, ref.srsran_ldpc_rm_rx_init_c, ref.srsran_ldpc_rm_rx_c, ref.srsran_ldpc_rm_rx_free_c, 1),
+                                                (np.int16, ref.srsran_ldpc_rm_rx_init_s, ref.srsran_ldpc_rm_rx_s, ref.srsran_ldpc_rm_rx_free_s, 200),
+                                                (np.float32, ref.srsran_ldpc_rm_rx_init_f, ref.srsran_ldpc_rm_rx_f, ref.srsran_ldpc_rm_rx_free_f, 0.25)):
+                    q = C.create_string_buffer(64)
+                    assert init(q) == 0
+                    x = (x8.astype(np.float64) * mul).astype(dt)
+                    o = (base.astype(np.float64) * mul).astype(dt)
+                    r = fn(q, P(x), P(o), C.c_uint32(E), C.c_uint32(F), C.c_int(bg), C.c_uint32(ls), C.c_uint8(rv), C.c_int(mod), C.c_uint32(Nref))
+                    free(q)
+                    crcs += [zlib.crc32(o.tobytes()), r]
+                d[key + "_rx"] = np.array(crcs, dtype=np.int64)
+                rm_cases.append(key)
+    d["enc_cases"], d["rm_cases"] = np.array(enc_cases), np.array(rm_cases)
+    np.savez_compressed(os.path.join(OUT, "ldpc_tx_ref.npz"), **d)
+    print("ldpc_tx_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_tx_ref.npz")))
+
+
 def modem():
     d = {}
     cases = []
@@ -309,6 +368,6 @@ def modem():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx}[name]()

@@ -60,7 +60,8 @@ typedef struct {
   uint32_t symbol_offset; /* first symbol in d_symbols (cf_t units; soft bits with SRSRAN_HIP_MOD_NONE) */
   uint32_t llr_offset;    /* first soft bit in d_llr; multiples of 16 bytes take the fast store path */
   uint32_t seed;          /* c_init of the scrambling sequence */
-  uint32_t descramble;    /* 0: demodulate only */
+  uint32_t descramble;    /* bit 0: descramble with `seed`; bit 1: change the sign of every soft bit first (the NR chain,
+                           * pdsch_nr.c:467 srsran_vec_neg_bb); 0: demodulate only */
 } srsran_hip_demod_job_t;
 
 typedef struct srsran_hip_demod srsran_hip_demod_t;

@@ -327,7 +327,7 @@ extern "C" int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, voi
   }
   for (uint32_t i = 0; i < n_jobs; i++) {
     const srsran_hip_demod_job_t& j = jobs[i];
-    if (j.mod > SRSRAN_HIP_MOD_NONE || (j.descramble && (uint64_t)j.nof_symbols * bits_per_symbol(j.mod) > SRSRAN_HIP_SEQUENCE_MAX_LEN)) {
+    if (j.mod > SRSRAN_HIP_MOD_NONE || ((j.descramble & 1u) && (uint64_t)j.nof_symbols * bits_per_symbol(j.mod) > SRSRAN_HIP_SEQUENCE_MAX_LEN)) {
       set_error("srsran_hip_demod_run: job %u: modulation %u / %u symbols not supported", i, j.mod, j.nof_symbols);
       fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
       return SRSRAN_ERROR_INVALID_INPUTS;
@@ -357,7 +357,7 @@ extern "C" int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, voi
   for (uint32_t i = 0; i < n_jobs; i++) {
     const srsran_hip_demod_job_t& j = jobs[i];
     const uint32_t                nt = modem::tiles_of(j.mod, j.nof_symbols);
-    h->h_jobs[i] = modem::Job{j.mod, j.nof_symbols, j.symbol_offset, j.llr_offset, j.seed, j.descramble ? 1u : 0u, tiles, nt};
+    h->h_jobs[i] = modem::Job{j.mod, j.nof_symbols, j.symbol_offset, j.llr_offset, j.seed, j.descramble & 3u, tiles, nt};
     tiles += nt;
   }
   if (tiles > h->map_cap) {

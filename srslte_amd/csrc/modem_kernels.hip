@@ -344,7 +344,7 @@ __device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint
     const uint32_t s = w0 + r * 64u + lane;
     x[r]             = s < job.n ? sym[s] : make_float2(0.f, 0.f);
   }
-  if (job.scramble) { // the symbol loads are in flight while the first lanes run the shift registers
+  if (job.scramble & 1u) { // the symbol loads are in flight while the first lanes run the shift registers
     make_chips(p, job.seed, w0 * QM, min((MODEM_TILE_SYMS / 4) * QM, (job.n - w0) * QM), cbw);
   }
 #pragma unroll
@@ -366,8 +366,8 @@ __device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint
         v[i] = (T)iv[i];
       }
     }
-    if (job.scramble) {
-      const uint32_t c = chips_at(cbw, (r * 64u + lane) * QM);
+    if (job.scramble) { // bit 0: descramble, bit 1: negate everything (pdsch_nr.c:467)
+      const uint32_t c = ((job.scramble & 1u) ? chips_at(cbw, (r * 64u + lane) * QM) : 0u) ^ ((job.scramble & 2u) ? ~0u : 0u);
 #pragma unroll
       for (int i = 0; i < QM; i++) {
         v[i] = flip<T>(v[i], (c >> i) & 1u);
@@ -394,7 +394,7 @@ __device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint3
   if (w0 >= job.n) {
     return;
   }
-  if (job.scramble) {
+  if (job.scramble & 1u) {
     make_chips(p, job.seed, w0, min(MODEM_TILE_BITS / 4, job.n - w0), cbw);
   }
 #pragma unroll
@@ -404,7 +404,7 @@ __device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint3
     if (e >= job.n) {
       continue;
     }
-    const uint32_t c = job.scramble ? chips_at(cbw, le) : 0u;
+    const uint32_t c = ((job.scramble & 1u) ? chips_at(cbw, le) : 0u) ^ ((job.scramble & 2u) ? ~0u : 0u);
     if (al && e + V <= job.n) {
       union {
         uint4 q;

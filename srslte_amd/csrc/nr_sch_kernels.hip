@@ -4,10 +4,10 @@
 //   encode_kernel  srsran_ldpc_encoder_encode_rm (ldpc_encoder.c:55-95, ldpc_enc_c.c)
 //
 // The reference's de-matcher is a sequential scatter-accumulate in transmission order (the saturation after every addition
-// makes the order matter when a position is received more than once).  Here every lane owns 16 bytes of the soft buffer,
-// works out which transmitted soft bits land on each of its positions -- rank of the position in the circular,
-// filler-skipping read-out order, then every P-th one after it -- gathers them through the de-interleaving index and
-// does one 16-byte read-modify-write.  No atomics, no temporary buffer.
+// makes the order matter when a position is received more than once).  Here every lane owns positions of the soft buffer,
+// works out which transmitted soft bits land on each of them -- rank of the position in the circular, filler-skipping
+// read-out order, then every P-th one after it -- gathers them through the de-interleaving index and updates the position
+// once.  No atomics, no temporary buffer.
 #include "hip_common.h"
 #include "nr_sch_device.h"
 
@@ -40,21 +40,50 @@ __device__ __forceinline__ uint32_t fcount(const RmParams& p, uint32_t x)
   return min(max(x, p.ini_ex), p.end_ex) - p.ini_ex;
 }
 
-template <typename T>
-__device__ __forceinline__ T rx_position(const RmParams& p, const T* in, uint32_t E, uint32_t cols, uint32_t P, uint32_t fk0, uint32_t fN,
-                                         uint32_t pos, T cur)
+// k / cols and k % cols for k < 2^24 through a float reciprocal (one correction step)
+__device__ __forceinline__ void divmod(uint32_t k, uint32_t cols, float inv, uint32_t* q, uint32_t* r)
+{
+  uint32_t qq = (uint32_t)__float2uint_rz(__uint2float_rn(k) * inv);
+  int      rr = (int)(k - qq * cols);
+  if (rr < 0) {
+    qq--;
+    rr += (int)cols;
+  } else if ((uint32_t)rr >= cols) {
+    qq++;
+    rr -= (int)cols;
+  }
+  *q = qq;
+  *r = (uint32_t)rr;
+}
+
+// rank of a position in the read-out order that starts at k0, wraps at Ncb and skips the fillers; 0xffffffff: the position
+// gets nothing from this transmission; 0xfffffffe: filler
+__device__ __forceinline__ uint32_t rx_rank(const RmParams& p, uint32_t E, uint32_t P, uint32_t fk0, uint32_t fN, uint32_t pos)
 {
   if (pos >= p.ini_ex && pos < p.end_ex) {
-    return Acc<T>::inf();
+    return 0xfffffffeu;
   }
   if (pos >= p.Ncb || P == 0) {
-    return cur;
+    return 0xffffffffu;
   }
-  // rank of this position in the read-out order that starts at k0, wraps at Ncb and skips the fillers
-  uint32_t k = pos >= p.k0 ? (pos - p.k0) - (fcount(p, pos) - fk0) : (pos + p.Ncb - p.k0) - (fN - fk0 + fcount(p, pos));
-  for (; k < E; k += P) {
-    const uint32_t src = p.Qm == 1 ? k : (k % cols) * p.Qm + k / cols; // ldpc_rm.c:365-411: tmp[i * cols + j] = in[j * Qm + i]
-    cur                = Acc<T>::add(cur, in[src]);
+  const uint32_t k = pos >= p.k0 ? (pos - p.k0) - (fcount(p, pos) - fk0) : (pos + p.Ncb - p.k0) - (fN - fk0 + fcount(p, pos));
+  return k < E ? k : 0xffffffffu;
+}
+
+template <typename T>
+__device__ __forceinline__ T rx_accumulate(const RmParams& p, const T* in, uint32_t E, uint32_t cols, float inv, uint32_t P, uint32_t k, T cur)
+{
+  if (k == 0xfffffffeu) {
+    return Acc<T>::inf();
+  }
+  for (; k < E; k += P) { // k = 0xffffffff falls through
+    uint32_t src = k;
+    if (p.Qm != 1) { // ldpc_rm.c:365-411: tmp[i * cols + j] = in[j * Qm + i]
+      uint32_t i, j;
+      divmod(k, cols, inv, &i, &j);
+      src = j * p.Qm + i;
+    }
+    cur = Acc<T>::add(cur, in[src]);
   }
   return cur;
 }
@@ -62,31 +91,31 @@ __device__ __forceinline__ T rx_position(const RmParams& p, const T* in, uint32_
 template <typename T>
 __global__ __launch_bounds__(256) void rm_rx_kernel(const RmParams p)
 {
+  // a workgroup covers 256 V consecutive positions; lane l takes l, l + 256, ...: consecutive lanes hold consecutive ranks, so
+  // the de-interleaving gathers of one instruction fall Qm elements apart (a few cache lines) instead of one line per lane
   constexpr uint32_t V   = 16 / sizeof(T);
   const CbJob        job = p.jobs[blockIdx.y];
   const T*           in  = (const T*)p.in + job.in_off;
   T*                 out = (T*)p.out + job.out_off;
   const uint32_t     E = job.E, cols = E / p.Qm;
+  const float        inv = 1.0f / (float)max(cols, 1u);
   const uint32_t     fk0 = fcount(p, p.k0), fN = fcount(p, p.Ncb), P = p.Ncb - fN;
   const uint32_t     cover = max(p.Ncb, p.end_ex);
-  const uint32_t     p0    = (blockIdx.x * 256u + threadIdx.x) * V;
-  if (p0 >= cover) {
-    return;
-  }
-  if ((((uintptr_t)out) & 15u) == 0 && p0 + V <= cover) {
-    union {
-      uint4 q;
-      T     t[V];
-    } u;
-    u.q = *(const uint4*)(out + p0);
+  const uint32_t     p0    = blockIdx.x * 256u * V + threadIdx.x;
+  uint32_t           k[V];
+  T                  cur[V];
 #pragma unroll
-    for (uint32_t i = 0; i < V; i++) {
-      u.t[i] = rx_position<T>(p, in, E, cols, P, fk0, fN, p0 + i, u.t[i]);
+  for (uint32_t i = 0; i < V; i++) {
+    const uint32_t pos = p0 + i * 256u;
+    k[i]               = pos < cover ? rx_rank(p, E, P, fk0, fN, pos) : 0xffffffffu;
+    if (k[i] != 0xffffffffu) { // positions this transmission does not reach are neither read nor written
+      cur[i] = out[pos];
     }
-    *(uint4*)(out + p0) = u.q;
-  } else {
-    for (uint32_t i = 0; i < V && p0 + i < cover; i++) {
-      out[p0 + i] = rx_position<T>(p, in, E, cols, P, fk0, fN, p0 + i, out[p0 + i]);
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < V; i++) {
+    if (k[i] != 0xffffffffu) {
+      out[p0 + i * 256u] = rx_accumulate<T>(p, in, E, cols, inv, P, k[i], cur[i]);
     }
   }
 }

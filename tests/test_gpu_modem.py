@@ -115,9 +115,11 @@ def test_fused_batch(hiplib, kind):
         n = int(rng.choice([1, 7, 144, 1200, 1024, 3000, 14400]))
         x = O.qam_symbols(mod, n, seed=100 + i, snr_db=15.0)
         seed = int(rng.integers(0, 1 << 31))
-        scr = int(i % 5 != 0)
+        scr = (1, 1, 2, 3, 0)[i % 5]  # bit 0 descramble, bit 1 sign change first (srsran_vec_neg_bb, pdsch_nr.c:467)
         llr = O.demod_soft(mod, x, kind)
-        if scr:
+        if scr & 2:
+            llr = -llr if kind == "f" else (-llr.astype(np.int32)).astype(dt)
+        if scr & 1:
             llr = O.sequence_apply(llr, seed)
         pad = int(rng.choice([0, 0, 1, 3, 8]))  # some jobs start unaligned
         jobs.append((mod, n, s_off, l_off + pad, seed, scr))

@@ -557,9 +557,13 @@ __device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, 
   }
 }
 
-template <int LPC, class AR>
-__global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
+// ES: early-stop / descriptor mode (transport-block decoding, sch_host.cpp).  A separate instantiation: the CRC state and
+// the per-block descriptors must not cost the fixed-iteration kernel registers (it runs at 2 waves per SIMD).
+template <int LPC, class AR, bool ES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdec_win_kernel(const WinParams p)
 {
+  const uint32_t crc_poly = ES ? p.crc_poly : 0u;
+  const CbDesc*  desc     = ES ? p.desc : nullptr;
   constexpr int NB  = 2 * LPC;
   constexpr int CPW = 64 / LPC;
   // re-derived backward metrics of the current 8-step block: 8 steps x 8 states x int16x2 per lane
@@ -594,20 +598,20 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
 
   // ---- phase 0: input extraction
   if (p.n_begin == 0) {
-    const bool fast = !p.desc && !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
+    const bool fast = !desc && !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
     if (fast) {
       const int first = blockIdx.x * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
                                        S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
     } else if (!p.in_is8 && p.sb_layout && (long_sb & 7u) == 0 &&
-               __all(((reinterpret_cast<uintptr_t>(p.input) + 2 * (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride)) & 15u) == 0)) {
-      const short* in = p.input + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
+               __all(((reinterpret_cast<uintptr_t>(p.input) + 2 * (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride)) & 15u) == 0)) {
+      const short* in = p.input + (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input_sb16<LPC, AR>(in, K, nblk, lane, pl, S, P0, P1, TL, Tr);
     } else if (p.in_is8) {
-      const signed char* in = reinterpret_cast<const signed char*>(p.input) + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
+      const signed char* in = reinterpret_cast<const signed char*>(p.input) + (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     } else {
-      const short* in = p.input + (p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride);
+      const short* in = p.input + (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
     }
   }
@@ -622,15 +626,15 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
   // With a CRC generator the checksum of the K hard bits is formed on the way (sch.c:430-447: zero means the code
   // block is good): every lane runs the bit-serial CRC of its two sub-blocks, the 16 partial checksums are shifted
   // to their place by multiplication with x^(W (NB-1-d)) mod g and XOR-ed across the lanes of the code block.
-  uint8_t*       out       = p.output + (p.desc ? (size_t)p.desc[cb].out_off : (size_t)cb * p.out_stride);
-  const uint32_t out_bytes = p.desc ? p.desc[cb].out_bytes : K / 8;
+  uint8_t*       out       = p.output + (desc ? (size_t)desc[cb].out_off : (size_t)cb * p.out_stride);
+  const uint32_t out_bytes = desc ? desc[cb].out_bytes : K / 8;
   auto decide = [&](bool write) -> uint32_t {
     short*         o16   = (p.dec_llr && live && write) ? p.dec_llr + (size_t)cb * K : nullptr;
     const bool     whole = (long_sb & 7) == 0;
     const uint32_t bps   = long_sb >> 3; // bytes per sub-block
-    const uint32_t poly  = p.crc_poly & 0xffffffu;
+    const uint32_t poly  = crc_poly & 0xffffffu;
     uint32_t       c0 = 0, c1 = 0;
-    if (whole || p.crc_poly) {
+    if (whole || crc_poly) {
       const bool wide = whole && ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0) && out_bytes == K / 8;
       uint32_t   w0 = 0, w1 = 0;
       uint32_t   t[8], tn[8];
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
             const uint32_t x0 = v.x > 0 ? 1u : 0u, x1 = v.y > 0 ? 1u : 0u;
             b0 |= (x0 << 7) >> j;
             b1 |= (x1 << 7) >> j;
-            if (p.crc_poly) { // crc.c:92-140, MSB first, zero initial state
+            if (crc_poly) { // crc.c:92-140, MSB first, zero initial state
               c0 = ((c0 << 1) & 0xffffffu) ^ ((((c0 >> 23) ^ x0) & 1u) ? poly : 0u);
               c1 = ((c1 << 1) & 0xffffffu) ^ ((((c1 >> 23) ^ x1) & 1u) ? poly : 0u);
             }
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       }
     }
     uint32_t crc = 0;
-    if (p.crc_poly) {
+    if (crc_poly) {
       auto mulmod = [&](uint32_t a, uint32_t m) { // a(x) m(x) mod g(x), all below x^24
         uint32_t r = 0;
 #pragma unroll 4
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     //              difference is formed before the permutation and no ext1 array is exchanged at all.
     // The raw SISO output is only needed by the hard decision: the LAST half iteration of a launch files it in D.
     const bool fuse = dec1 && n >= 2;
-    const bool last = (n + 1 == p.n_end) || p.crc_poly; // with early stop every half iteration may be the last
+    const bool last = (n + 1 == p.n_end) || crc_poly; // with early stop every half iteration may be the last
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
     load_block(CK, 64 + lane, ck);
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
       }
     }
     __syncthreads();
-    if (p.crc_poly) {
+    if (crc_poly) {
       // decode_tb_cb (sch.c:420-454): hard bits + CRC after every half iteration; a code block stops at its first
       // match (its bits are written then and never again), the wave stops when all its code blocks have
       const bool     fin = n + 1 == p.n_end;
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(const WinParams p)
     }
   }
 
-  if (!p.crc_poly) {
+  if (!crc_poly) {
     decide(true);
   } else if (p.noi && live && pl == 0) {
     p.noi[cb_raw]    = (int)noi;
@@ -1207,22 +1211,28 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
 
 // ------------------------------------------------------------------------------------------------ launchers
 
-hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream)
+template <bool ES>
+static hipError_t launch_win_es(int nb, bool arith8, const WinParams& p, hipStream_t stream)
 {
   const int lpc = nb / 2;
   dim3      grid(ceil_div(p.n_cb, 64 / lpc));
   if (!arith8 && nb == 16) {
-    hipLaunchKernelGGL((tdec_win_kernel<8, Ar16>), grid, dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((tdec_win_kernel<8, Ar16, ES>), grid, dim3(64), 0, stream, p);
   } else if (!arith8 && nb == 8) {
-    hipLaunchKernelGGL((tdec_win_kernel<4, Ar16>), grid, dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((tdec_win_kernel<4, Ar16, ES>), grid, dim3(64), 0, stream, p);
   } else if (arith8 && nb == 16) {
-    hipLaunchKernelGGL((tdec_win_kernel<8, Ar8>), grid, dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((tdec_win_kernel<8, Ar8, ES>), grid, dim3(64), 0, stream, p);
   } else if (arith8 && nb == 32) {
-    hipLaunchKernelGGL((tdec_win_kernel<16, Ar8>), grid, dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((tdec_win_kernel<16, Ar8, ES>), grid, dim3(64), 0, stream, p);
   } else {
     return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream)
+{
+  return (p.crc_poly || p.desc) ? launch_win_es<true>(nb, arith8, p, stream) : launch_win_es<false>(nb, arith8, p, stream);
 }
 
 hipError_t launch_gen(const GenParams& p, hipStream_t stream)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round measurement pass on the GPU box (run through gpurun from the repository root):
+#   full GPU test suite, bench.py, the secondary benches, rocprofv3 kernel trace of bench.py and separate PMC passes.
+# Outputs go to gpurun_out/round/; the summaries to keep are copied into profiles/ by hand afterwards.
+set -o pipefail
+export TMPDIR=/tmp
+OUT=gpurun_out/round
+mkdir -p $OUT
+python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+tail -3 $OUT/pytest_gpu.log
+python bench.py > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json | cut -c1-400 &&
+python tools/bench_nr.py > $OUT/bench_nr.json 2> $OUT/bench_nr.err &&
+python tools/bench_sync.py > $OUT/bench_sync.json 2> $OUT/bench_sync.err &&
+python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
+python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
+python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/trace.err &&
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_fetch.err &&
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_write.err &&
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/pmc_sq -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_sq.err &&
+python tools/rocpd_summary.py $OUT/trace > $OUT/kernel_stats.txt &&
+python tools/rocpd_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > $OUT/pmc.txt &&
+rocprofv3 --kernel-trace -d $OUT/trace_nr -o nr -- python tools/bench_nr.py > /dev/null 2> $OUT/trace_nr.err &&
+rocprofv3 --kernel-trace -d $OUT/trace_sync -o sync -- python tools/bench_sync.py > /dev/null 2> $OUT/trace_sync.err &&
+python tools/rocpd_summary.py $OUT/trace_nr $OUT/trace_sync > $OUT/kernel_stats_nr_sync.txt
+echo "profile pass rc=$?"
+rm -rf $OUT/trace/*/*.db.tmp 2>/dev/null
+du -sh $OUT

@@ -76,6 +76,15 @@ SRSRAN_API int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, voi
 SRSRAN_API uint32_t srsran_hip_sequence_pdsch_seed(uint16_t rnti, int q, uint32_t nslot, uint32_t cell_id);
 SRSRAN_API uint32_t srsran_hip_sequence_pusch_seed(uint16_t rnti, uint32_t nslot, uint32_t cell_id);
 
+/* ---- single-antenna ZF / MMSE equaliser: lib/include/srsran/phy/mimo/precoding.h:70-71 (precoding.c:357-392), the step before
+ * transform de-precoding in pusch.c:413.  x = y conj(h) / ((|h|^2 + noise_estimate) scaling); csi (optional) = |h|^2 + noise.
+ * Returns nof_symbols.  Float arithmetic: equals the reference to 1e-6 relative (3e-4 with csi, where the reference's SIMD body
+ * uses an approximate reciprocal). */
+SRSRAN_API int srsran_predecoding_single(cf_t* y, cf_t* h, cf_t* x, float* csi, int nof_symbols, float scaling, float noise_estimate);
+/* device buffers, 16-byte aligned (d_csi 8-byte); asynchronous on `stream` */
+SRSRAN_API int srsran_hip_predecoding_single(const cf_t* d_y, const cf_t* d_h, cf_t* d_x, float* d_csi, uint32_t nof_symbols, float scaling,
+                                             float noise_estimate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,8 @@ void     orc_sequence_apply_c(const int8_t* in, int8_t* out, uint32_t len, uint3
 void     orc_sequence_apply_f(const float* in, float* out, uint32_t len, uint32_t seed, uint8_t* scratch);
 uint32_t orc_sequence_pdsch_seed(uint16_t rnti, int q, uint32_t nslot, uint32_t cell_id);
 uint32_t orc_sequence_pusch_seed(uint16_t rnti, uint32_t nslot, uint32_t cell_id);
+/* srsran_predecoding_single (mimo/precoding.c:357-392): single-antenna ZF / MMSE equaliser, double arithmetic */
+int      orc_predecoding_single(const float* y, const float* h, float* x, float* csi, int n, float scaling, float noise_estimate);
 
 #ifdef __cplusplus
 }

@@ -326,3 +326,21 @@ uint32_t orc_sequence_pusch_seed(uint16_t rnti, uint32_t nslot, uint32_t cell_id
 {
   return ((uint32_t)rnti << 14) + ((nslot / 2) << 9) + cell_id;
 }
+
+/* srsran_predecoding_single (mimo/precoding.c:196-392), one receive antenna: x = y conj(h) / ((|h|^2 + noise) scaling),
+ * csi (optional) = |h|^2 + noise.  Evaluated in double; the reference's float paths (AVX body, scalar tail, and for the csi
+ * variant an approximate reciprocal, simd.h srsran_simd_f_rcp) scatter around it by 1e-7 / 3e-4 relative. */
+int orc_predecoding_single(const float* y, const float* h, float* x, float* csi, int n, float scaling, float noise_estimate)
+{
+  for (int i = 0; i < n; i++) {
+    const double yr = y[2 * i], yi = y[2 * i + 1], hr = h[2 * i], hi = h[2 * i + 1];
+    const double hh = hr * hr + hi * hi + ((csi || noise_estimate > 0) ? (double)noise_estimate : 0.0);
+    const double d  = hh * (double)scaling;
+    x[2 * i]        = (float)((yr * hr + yi * hi) / d);
+    x[2 * i + 1]    = (float)((yi * hr - yr * hi) / d);
+    if (csi) {
+      csi[i] = (float)hh;
+    }
+  }
+  return n;
+}

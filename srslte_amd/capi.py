@@ -408,6 +408,8 @@ def lib():
             "srsran_hip_ldpc_rm_rx_batch": (i32, [vp, i32, vp, vp, C.POINTER(HipLdpcCb), u32, u32, i32, u32, u32, i32, u32, vp]),
             "srsran_hip_ldpc_rm_tx_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, u32, i32, u32, vp]),
             "srsran_hip_ldpc_encode_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, vp]),
+            "srsran_predecoding_single": (i32, [vp, vp, vp, vp, i32, C.c_float, C.c_float]),
+            "srsran_hip_predecoding_single": (i32, [vp, vp, vp, vp, u32, C.c_float, C.c_float, vp]),
             "srsran_demod_soft_demodulate": (i32, [i32, vp, vp, i32]),
             "srsran_demod_soft_demodulate_s": (i32, [i32, vp, vp, i32]),
             "srsran_demod_soft_demodulate_b": (i32, [i32, vp, vp, i32]),

@@ -52,6 +52,8 @@ struct Params {
 
 uint32_t   tiles_of(uint32_t mod, uint32_t n);
 hipError_t launch(const Params& p, hipStream_t stream);
+// srsran_predecoding_single on device buffers (y, h, x: cf_t, 16-byte aligned; csi optional)
+hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t n, float scaling, float noise, hipStream_t stream);
 
 } // namespace modem
 } // namespace phyhip

@@ -389,3 +389,46 @@ extern "C" int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, voi
   h->pending = true;
   return SRSRAN_SUCCESS;
 }
+
+// ---- single-antenna equaliser ---------------------------------------------------------------------------------------------------
+extern "C" int srsran_hip_predecoding_single(const cf_t* d_y, const cf_t* d_h, cf_t* d_x, float* d_csi, uint32_t nof_symbols, float scaling,
+                                             float noise_estimate, void* stream)
+{
+  if (nof_symbols && (!d_y || !d_h || !d_x || ((((uintptr_t)d_y) | ((uintptr_t)d_h) | ((uintptr_t)d_x)) & 15u) || (((uintptr_t)d_csi) & 7u))) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(modem::launch_eq(d_y, d_h, d_x, d_csi, nof_symbols, scaling, noise_estimate, (hipStream_t)stream), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_predecoding_single(cf_t* y, cf_t* h, cf_t* x, float* csi, int nof_symbols, float scaling, float noise_estimate)
+{
+  if (nof_symbols <= 0) {
+    return nof_symbols;
+  }
+  Stage& s = stage();
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_predecoding_single: no HIP device (there is no CPU fallback)\n");
+    return SRSRAN_ERROR;
+  }
+  const size_t nb   = (size_t)nof_symbols * sizeof(cf_t);
+  const size_t slot = (nb + 255) & ~(size_t)255;
+  if (!Stage::grow(&s.d_in, &s.cap_in, 2 * slot) || !Stage::grow(&s.d_out, &s.cap_out, slot + (size_t)nof_symbols * sizeof(float))) {
+    return SRSRAN_ERROR;
+  }
+  uint8_t* din  = (uint8_t*)s.d_in;
+  uint8_t* dout = (uint8_t*)s.d_out;
+  PHY_HIP_CHECK(hipMemcpyAsync(din, y, nb, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(din + slot, h, nb, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(modem::launch_eq(din, din + slot, dout, csi ? (float*)(dout + slot) : nullptr, (uint32_t)nof_symbols, scaling, noise_estimate, s.st),
+                SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(x, dout, nb, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+  if (csi) {
+    PHY_HIP_CHECK(hipMemcpyAsync(csi, dout + slot, (size_t)nof_symbols * sizeof(float), hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+  }
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  return nof_symbols;
+}

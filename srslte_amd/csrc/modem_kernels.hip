@@ -469,7 +469,59 @@ __global__ __launch_bounds__(256) void modem_kernel(const Params p)
   }
 }
 
+// ---- single-antenna ZF / MMSE equaliser: srsran_predecoding_single (mimo/precoding.c:196-392), the float formulas of its AVX
+// body: x = (y conj(h)) / (|h|^2 + noise) * (1 / scaling); two symbols (one dwordx4 of y and of h) per lane
+__global__ __launch_bounds__(256) void eq_kernel(const float4* y, const float4* h, float4* x, float2* csi, uint32_t n, float inv_scaling,
+                                                 float noise, int add_noise)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x; // pair index
+  if (2 * i >= n) {
+    return;
+  }
+  float4 yy, hh;
+  if (2 * i + 1 < n) {
+    yy = y[i];
+    hh = h[i];
+  } else { // odd tail
+    const float2 a = ((const float2*)y)[2 * i], b = ((const float2*)h)[2 * i];
+    yy             = make_float4(a.x, a.y, 0.f, 0.f);
+    hh             = make_float4(b.x, b.y, 1.f, 0.f);
+  }
+  float c0 = __fadd_rn(__fmul_rn(hh.x, hh.x), __fmul_rn(hh.y, hh.y));
+  float c1 = __fadd_rn(__fmul_rn(hh.z, hh.z), __fmul_rn(hh.w, hh.w));
+  if (add_noise) {
+    c0 = __fadd_rn(c0, noise);
+    c1 = __fadd_rn(c1, noise);
+  }
+  float4 o;
+  o.x = __fmul_rn(__fdiv_rn(__fadd_rn(__fmul_rn(yy.x, hh.x), __fmul_rn(yy.y, hh.y)), c0), inv_scaling);
+  o.y = __fmul_rn(__fdiv_rn(__fsub_rn(__fmul_rn(yy.y, hh.x), __fmul_rn(yy.x, hh.y)), c0), inv_scaling);
+  o.z = __fmul_rn(__fdiv_rn(__fadd_rn(__fmul_rn(yy.z, hh.z), __fmul_rn(yy.w, hh.w)), c1), inv_scaling);
+  o.w = __fmul_rn(__fdiv_rn(__fsub_rn(__fmul_rn(yy.w, hh.z), __fmul_rn(yy.z, hh.w)), c1), inv_scaling);
+  if (2 * i + 1 < n) {
+    x[i] = o;
+    if (csi) {
+      csi[i] = make_float2(c0, c1);
+    }
+  } else {
+    ((float2*)x)[2 * i] = make_float2(o.x, o.y);
+    if (csi) {
+      ((float*)csi)[2 * i] = c0;
+    }
+  }
+}
+
 } // namespace
+
+hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t n, float scaling, float noise, hipStream_t stream)
+{
+  if (n == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(eq_kernel, dim3(ceil_div(ceil_div(n, 2u), 256u)), dim3(256), 0, stream, (const float4*)y, (const float4*)h, (float4*)x,
+                     (float2*)csi, n, 1.0f / scaling, noise, (csi != nullptr || noise > 0.f) ? 1 : 0);
+  return hipGetLastError();
+}
 
 uint32_t tiles_of(uint32_t mod, uint32_t n)
 {

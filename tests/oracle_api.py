@@ -520,3 +520,14 @@ def ldpc_rm_rx(x, base, F, bg, ls, rv, mod, Nref):
     r = f(typ, P(np.ascontiguousarray(x)), P(out), x.size, F, bg, ls, rv, QM[mod], Nref)
     assert r >= 0
     return out, r
+
+
+def predecoding_single(y, h, scaling, noise_estimate, want_csi=False):
+    """orc_predecoding_single (double arithmetic): returns x [, csi]"""
+    y, h = np.ascontiguousarray(y, np.complex64), np.ascontiguousarray(h, np.complex64)
+    x = np.zeros_like(y)
+    csi = np.zeros(y.size, np.float32)
+    f = orc().orc_predecoding_single
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float]
+    f(P(y), P(h), P(x), P(csi) if want_csi else None, y.size, scaling, noise_estimate)
+    return (x, csi) if want_csi else x

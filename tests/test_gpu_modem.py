@@ -155,3 +155,40 @@ def test_fused_batch(hiplib, kind):
     bad = (capi.HipDemodJob * 1)(capi.HipDemodJob(6, 10, 0, 0, 0, 0))
     assert lib.srsran_hip_demod_run(h, d.ptr, d.ptr, llr_type, bad, 1, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
     lib.srsran_hip_demod_free(h)
+
+
+def test_predecoding_single(hiplib):
+    """single-antenna equaliser (mimo/precoding.c:357-392) vs the oracle (double arithmetic) and the recorded reference outputs"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 7, 32, 33, 1200, 14401):
+        y = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
+        h = (0.3 + 0.7 * (rng.normal(size=n) + 1j * rng.normal(size=n))).astype(np.complex64)
+        for noise in (0.0, 0.05):
+            for scaling in (1.0, 0.7):
+                x = np.zeros_like(y)
+                assert lib.srsran_predecoding_single(O.P(y), O.P(h), O.P(x), None, n, scaling, noise) == n
+                want = O.predecoding_single(y, h, scaling, noise)
+                assert np.abs(x - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (n, noise, scaling)
+                csi = np.zeros(n, np.float32)
+                assert lib.srsran_predecoding_single(O.P(y), O.P(h), O.P(x), O.P(csi), n, scaling, noise) == n
+                wx, wc = O.predecoding_single(y, h, scaling, noise, want_csi=True)
+                assert np.abs(x - wx).max() <= 1e-6 * max(1.0, np.abs(wx).max()) and np.abs(csi - wc).max() <= 1e-6 * wc.max()
+    d = np.load(os.path.join(G, "modem_ref.npz"))
+    y, h = d["eq_y"], d["eq_h"]
+    for i, (scaling, noise) in enumerate(d["eq_par"]):
+        x = np.zeros_like(y)
+        lib.srsran_predecoding_single(O.P(y), O.P(h), O.P(x), None, y.size, float(scaling), float(noise))
+        assert np.abs(x - d["eq_x"][i]).max() <= 1e-6 * np.abs(d["eq_x"][i]).max()  # the reference's own float result
+    # batched: device pointers
+    n = 100000
+    y = (rng.normal(size=n) + 1j * rng.normal(size=n)).astype(np.complex64)
+    h = (0.5 + 0.5 * (rng.normal(size=n) + 1j * rng.normal(size=n))).astype(np.complex64)
+    dy, dh, dx = S.DeviceBuffer.from_numpy(y), S.DeviceBuffer.from_numpy(h), S.DeviceBuffer(n * 8)
+    capi.check(lib.srsran_hip_predecoding_single(dy.ptr, dh.ptr, dx.ptr, None, n, 1.0, 0.01, None), "eq")
+    capi.check(lib.srsran_hip_stream_sync(None), "sync")
+    want = O.predecoding_single(y, h, 1.0, 0.01)
+    assert np.abs(dx.to_numpy(np.complex64, (n,)) - want).max() <= 1e-6 * np.abs(want).max()

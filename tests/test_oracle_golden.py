@@ -77,6 +77,9 @@ def test_soft_demodulator_and_scrambling_reference_outputs():
         pusch, pdsch = row[4:16].astype(np.uint8), row[16:28].astype(np.uint8)
         assert np.array_equal(np.packbits(O.sequence_bits(O.pusch_seed(rnti, nslot, cell), 96)), pusch)
         assert np.array_equal(np.packbits(O.sequence_bits(O.pdsch_seed(rnti, q, nslot, cell), 96)), pdsch)
+    for i, (scaling, noise) in enumerate(d["eq_par"]):
+        got = O.predecoding_single(d["eq_y"], d["eq_h"], float(scaling), float(noise))
+        assert np.abs(got - d["eq_x"][i]).max() <= 1e-6 * np.abs(d["eq_x"][i]).max()
     x = np.array([-32768, 32767, -1, 0, 5] * 20, np.int16)
     y = O.sequence_apply(x, 77)
     c = O.sequence_bits(77, x.size)

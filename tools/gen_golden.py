@@ -362,6 +362,20 @@ def modem():
         ref.srsran_sequence_pdsch_apply_s(P(one), P(o2), C.c_uint16(rnti), C.c_int(q), C.c_uint32(nslot), C.c_uint32(cell), C.c_uint32(L))
         ch.append(np.concatenate([[rnti, nslot, cell, q], np.packbits(o1 == -1), np.packbits(o2 == -1)]))
     d["channel_seeds"] = np.array(ch, dtype=np.int64)
+    # srsran_predecoding_single (AVX body + scalar tail), csi = NULL as pusch.c:413 calls it
+    ref.srsran_predecoding_single.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float]
+    rng = np.random.default_rng(8)
+    n = 333
+    y, h = O.aligned_empty(n, np.complex64), O.aligned_empty(n, np.complex64)
+    y[:] = rng.normal(size=n) + 1j * rng.normal(size=n)
+    h[:] = 0.3 + 0.7 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    xs, pars = [], []
+    for scaling, noise in ((1.0, 0.0), (0.7, 0.05), (2.0, 0.3)):
+        x = O.aligned_empty(n, np.complex64)
+        ref.srsran_predecoding_single(P(y), P(h), P(x), None, n, scaling, noise)
+        xs.append(np.array(x))
+        pars.append([scaling, noise])
+    d["eq_y"], d["eq_h"], d["eq_x"], d["eq_par"] = np.array(y), np.array(h), np.stack(xs), np.array(pars, np.float32)
     np.savez_compressed(os.path.join(OUT, "modem_ref.npz"), **d)
     print("modem_ref.npz", os.path.getsize(os.path.join(OUT, "modem_ref.npz")))
 

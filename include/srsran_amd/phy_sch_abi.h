@@ -76,6 +76,32 @@ typedef struct SRSRAN_API {
 } srsran_cbsegm_t;
 SRSRAN_API int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs);
 
+/* ---- transmit side: turbo encoder (lib/include/srsran/phy/fec/turbo/turbocoder.h:46-58, turbocoder.c:40-185) ----
+ * srsran_tcod_encode: input long_cb bits (one per byte; 100 = SRSRAN_TX_NULL filler, encoded as 0 and passed through on the
+ * systematic and first parity outputs), output 3 long_cb + 12 bytes: [d0 d1 d2] per bit, then the 12 tail bits.
+ * Not provided: the byte-packed srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut pair; the batched call below covers what
+ * encode_tb (sch.c:230-330) does with them. */
+typedef struct SRSRAN_API {
+  uint32_t max_long_cb;
+  uint8_t* temp;
+} srsran_tcod_t;
+SRSRAN_API int  srsran_tcod_init(srsran_tcod_t* h, uint32_t max_long_cb);
+SRSRAN_API void srsran_tcod_free(srsran_tcod_t* h);
+SRSRAN_API int  srsran_tcod_encode(srsran_tcod_t* h, uint8_t* input, uint8_t* output, uint32_t long_cb);
+/* device resident: n_cb code blocks of long_cb bits, strides in bytes */
+SRSRAN_API int srsran_hip_tcod_encode_batch(const uint8_t* d_in, uint32_t in_stride, uint8_t* d_out, uint32_t out_stride, uint32_t n_cb,
+                                            uint32_t long_cb, void* stream);
+
+/* encode_tb (sch.c:230-330) for a batch of transport blocks, device resident: CRC24A, segmentation, CRC24B per block, turbo
+ * coding, rate matching of redundancy version rv, concatenation.  srsran_hip_tb_t: data_offset = first payload BYTE in d_data
+ * (tbs / 8 bytes are read), e_offset = first output BIT in d_e_bits (MSB first; nof_e_bits bits are written, the range is
+ * cleared first), first_cb unused.  Asynchronous on `stream`. */
+typedef struct srsran_hip_sch_enc srsran_hip_sch_enc_t;
+SRSRAN_API int  srsran_hip_sch_enc_create(srsran_hip_sch_enc_t** h);
+SRSRAN_API void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h);
+SRSRAN_API int  srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_data, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
+                                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

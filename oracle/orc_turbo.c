@@ -547,15 +547,17 @@ int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t K)
   uint8_t r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
   uint32_t k = 0;
   for (uint32_t i = 0; i < K; i++) {
-    uint8_t bit = input[i] & 1;
-    output[k++] = bit;
+    /* turbocoder.c:109-127: filler bits are marked SRSRAN_TX_NULL (100): encoded as 0, passed through on the systematic
+     * and first parity outputs */
+    uint8_t bit = input[i] == 100 ? 0 : input[i];
+    output[k++] = input[i];
     uint8_t in  = bit ^ (r1[2] ^ r1[1]);
     uint8_t out = r1[2] ^ (r1[0] ^ in);
     r1[2] = r1[1];
     r1[1] = r1[0];
     r1[0] = in;
-    output[k++] = out;
-    bit = input[fw[i]] & 1;
+    output[k++] = input[i] == 100 ? 100 : out;
+    bit = input[fw[i]] == 100 ? 0 : input[fw[i]];
     in  = bit ^ (r2[2] ^ r2[1]);
     out = r2[2] ^ (r2[0] ^ in);
     r2[2] = r2[1];

@@ -120,6 +120,10 @@ class Cbsegm(C.Structure):
 SOFTBUFFER_CB_SIZE = 18600
 
 
+class Tcod(C.Structure):  # srsran_tcod_t, turbocoder.h:46-49
+    _fields_ = [("max_long_cb", C.c_uint32), ("temp", C.c_void_p)]
+
+
 class HipDemodJob(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("mod", "nof_symbols", "symbol_offset", "llr_offset", "seed", "descramble")]
 
@@ -387,6 +391,13 @@ def lib():
             "srsran_hip_sch_free": (None, [vp]),
             "srsran_hip_sch_decode": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
             "srsran_cbsegm": (i32, [C.POINTER(Cbsegm), u32]),
+            "srsran_tcod_init": (i32, [C.POINTER(Tcod), u32]),
+            "srsran_tcod_free": (None, [C.POINTER(Tcod)]),
+            "srsran_tcod_encode": (i32, [C.POINTER(Tcod), vp, vp, u32]),
+            "srsran_hip_tcod_encode_batch": (i32, [vp, u32, vp, u32, u32, u32, vp]),
+            "srsran_hip_sch_enc_create": (i32, [C.POINTER(vp)]),
+            "srsran_hip_sch_enc_free": (None, [vp]),
+            "srsran_hip_sch_encode": (i32, [vp, vp, C.POINTER(HipTb), u32, vp, vp]),
             "srsran_ldpc_rm_tx_init": (i32, [C.POINTER(LdpcRm)]),
             "srsran_ldpc_rm_rx_init_f": (i32, [C.POINTER(LdpcRm)]),
             "srsran_ldpc_rm_rx_init_s": (i32, [C.POINTER(LdpcRm)]),

@@ -99,6 +99,28 @@ const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
   return d;
 }
 
+// forward table of the natural buffer (transmit side): bit k of the rate-matched output = d[table[k mod len]]
+const uint16_t* fwd_table_on_device(uint32_t K, uint32_t rv, uint32_t* len)
+{
+  const uint32_t              key = K | (rv << 16) | (1u << 31);
+  const std::vector<uint16_t> fwd = build_table(K, rv, 0);
+  *len                            = (uint32_t)fwd.size();
+  std::lock_guard<std::mutex> lk(g_pool.mu);
+  auto                        it = g_pool.dev.find(key);
+  if (it != g_pool.dev.end()) {
+    return it->second;
+  }
+  uint16_t* d = nullptr;
+  if (hipMalloc(&d, fwd.size() * sizeof(uint16_t)) != hipSuccess ||
+      hipMemcpy(d, fwd.data(), fwd.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("rm_turbo: cannot place the transmit table of K=%u rv=%u on the device", K, rv);
+    (void)hipFree(d);
+    return nullptr;
+  }
+  g_pool.dev[key] = d;
+  return d;
+}
+
 int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out, uint32_t out_stride, uint32_t n_cb, uint32_t K,
              uint32_t rv, uint32_t nof_sb, bool elem8, hipStream_t st)
 {
@@ -219,6 +241,10 @@ namespace rm {
 const uint16_t* device_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
 {
   return table_on_device(K, rv, nof_sb);
+}
+const uint16_t* device_fwd_table(uint32_t K, uint32_t rv, uint32_t* len)
+{
+  return fwd_table_on_device(K, rv, len);
 }
 std::vector<uint16_t> host_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
 {

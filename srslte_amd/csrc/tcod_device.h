@@ -1,0 +1,45 @@
+// tcod_device.h -- parameter blocks and launchers of tcod_kernels.hip: LTE turbo encoder and the transmit side of a transport
+// block (CRC attachment, segmentation, turbo coding, rate matching, concatenation; sch.c encode_tb / turbocoder.c / rm_turbo.c)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace phyhip {
+namespace tcod {
+
+struct EncParams { // srsran_tcod_encode over a batch of code blocks of one size
+  const uint8_t* in;  // n_cb x K bytes (bit per byte; 100 = SRSRAN_TX_NULL), in_stride apart
+  uint8_t*       out; // n_cb x (3K + 12) bytes, out_stride apart
+  uint32_t       in_stride, out_stride;
+  uint32_t       n_cb, K, f1, f2;
+};
+hipError_t launch_encode(const EncParams& p, hipStream_t stream);
+
+struct TbCbJob { // one code block of a transport block
+  uint32_t src_bit;    // first payload bit of this block in d_data (bit offset; payload bytes are MSB first)
+  uint32_t n_src_bits; // payload bits taken from d_data
+  uint32_t tb_crc;     // index into tb_crc[] when the 24 transport-block CRC bits follow the payload in this block, else 0xffffffff
+  uint32_t crc24b;     // 1: append CRC24B (more than one block in the transport block)
+  uint32_t K, f1, f2;  // block size (= n_src_bits + 24 per CRC) and its QPP parameters
+  uint32_t E;          // rate-matched bits
+  uint32_t out_bit;    // first output bit in d_e (bit offset, MSB first)
+  const uint16_t* table; // forward rate-matching table of (K, rv): position in the natural [d0 d1 d2] x K + 12 buffer of each bit
+  uint32_t table_len;
+  uint32_t pad;
+};
+struct TbCrcJob { // CRC24A of one transport block
+  uint32_t src_byte, n_bytes;
+};
+struct TbParams {
+  const uint8_t*  data;   // packed payload bytes of all transport blocks
+  uint8_t*        e_bits; // packed output, zeroed by the launcher's caller (blocks OR their bits in)
+  const TbCbJob*  cbs;
+  const TbCrcJob* tbs;
+  uint32_t*       tb_crc; // n_tb checksums (device scratch)
+  uint32_t        n_cb, n_tb;
+};
+hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream);
+hipError_t launch_tb_encode(const TbParams& p, hipStream_t stream);
+
+} // namespace tcod
+} // namespace phyhip

@@ -1,0 +1,250 @@
+// tcod_host.cpp -- C ABI of the LTE turbo encoder and of the transmit side of a transport block
+// (include/srsran_amd/phy_sch_abi.h): srsran_tcod_{init,free,encode}, srsran_hip_tcod_encode_batch, srsran_hip_sch_encode.
+#include "hip_common.h"
+#include "srsran_amd/phy_sch_abi.h"
+#include "tables/lte_qpp_table.h"
+#include "tcod_device.h"
+
+#include <vector>
+
+using namespace phyhip;
+
+namespace phyhip {
+namespace rm {
+const uint16_t* device_fwd_table(uint32_t K, uint32_t rv, uint32_t* len); // rm_host.cpp
+}
+} // namespace phyhip
+
+namespace {
+
+bool qpp_params(uint32_t K, uint32_t* f1, uint32_t* f2)
+{
+  const int idx = srsran_cbsegm_cbindex(K);
+  if (idx < 0 || (uint32_t)srsran_cbsegm_cbsize((uint32_t)idx) != K) {
+    return false;
+  }
+  *f1 = lte_qpp_table[idx][1];
+  *f2 = lte_qpp_table[idx][2];
+  return true;
+}
+
+struct Ctx { // behind srsran_tcod_t.temp
+  hipStream_t st    = nullptr;
+  uint8_t*    d_in  = nullptr;
+  uint8_t*    d_out = nullptr;
+};
+
+} // namespace
+
+extern "C" int srsran_hip_tcod_encode_batch(const uint8_t* d_in, uint32_t in_stride, uint8_t* d_out, uint32_t out_stride, uint32_t n_cb,
+                                            uint32_t long_cb, void* stream)
+{
+  tcod::EncParams p{};
+  if (!d_in || !d_out || !qpp_params(long_cb, &p.f1, &p.f2) || in_stride < long_cb || out_stride < 3 * long_cb + 12) {
+    set_error("tcod batch: invalid arguments (K=%u)", long_cb);
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  p.in         = d_in;
+  p.out        = d_out;
+  p.in_stride  = in_stride;
+  p.out_stride = out_stride;
+  p.n_cb       = n_cb;
+  p.K          = long_cb;
+  PHY_HIP_CHECK(tcod::launch_encode(p, (hipStream_t)stream), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
+}
+
+// turbocoder.c:40-75
+extern "C" int srsran_tcod_init(srsran_tcod_t* h, uint32_t max_long_cb)
+{
+  if (!h) {
+    return -1;
+  }
+  h->max_long_cb = max_long_cb;
+  h->temp        = nullptr;
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tcod_init: %s (there is no CPU fallback)\n", get_error());
+    return -1;
+  }
+  Ctx* c = new Ctx;
+  if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->d_in, 6144 + 64) != hipSuccess ||
+      hipMalloc(&c->d_out, 3 * 6144 + 64) != hipSuccess) {
+    (void)hipFree(c->d_in);
+    (void)hipFree(c->d_out);
+    delete c;
+    return -1;
+  }
+  h->temp = reinterpret_cast<uint8_t*>(c);
+  return 0;
+}
+
+extern "C" void srsran_tcod_free(srsran_tcod_t* h)
+{
+  if (!h) {
+    return;
+  }
+  h->max_long_cb = 0;
+  if (h->temp) {
+    Ctx* c = reinterpret_cast<Ctx*>(h->temp);
+    (void)hipFree(c->d_in);
+    (void)hipFree(c->d_out);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+    h->temp = nullptr;
+  }
+}
+
+extern "C" int srsran_tcod_encode(srsran_tcod_t* h, uint8_t* input, uint8_t* output, uint32_t long_cb)
+{
+  if (long_cb > h->max_long_cb) {
+    fprintf(stderr, "Turbo coder initiated for max_long_cb=%d\n", h->max_long_cb); // turbocoder.c:85-88
+    return -1;
+  }
+  uint32_t f1, f2;
+  if (!qpp_params(long_cb, &f1, &f2)) {
+    fprintf(stderr, "Invalid CB size %d\n", long_cb); // turbocoder.c:90-94
+    return -1;
+  }
+  Ctx* c = reinterpret_cast<Ctx*>(h->temp);
+  if (!c) {
+    return -1;
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, input, long_cb, hipMemcpyHostToDevice, c->st), -1);
+  if (srsran_hip_tcod_encode_batch(c->d_in, long_cb, c->d_out, 3 * long_cb + 12, 1, long_cb, c->st) != SRSRAN_SUCCESS) {
+    return -1;
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(output, c->d_out, 3 * long_cb + 12, hipMemcpyDeviceToHost, c->st), -1);
+  PHY_HIP_CHECK(hipStreamSynchronize(c->st), -1);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ transport blocks, transmit side
+struct srsran_hip_sch_enc {
+  void*  d_scratch = nullptr;
+  void*  h_scratch = nullptr; // pinned
+  size_t cap       = 0;
+  hipEvent_t done  = nullptr;
+  bool   pending   = false;
+};
+
+extern "C" int srsran_hip_sch_enc_create(srsran_hip_sch_enc_t** hh)
+{
+  if (!hh) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *hh = nullptr;
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  srsran_hip_sch_enc* h = new srsran_hip_sch_enc;
+  if (hipEventCreateWithFlags(&h->done, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return SRSRAN_ERROR;
+  }
+  *hh = h;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
+{
+  if (!h) {
+    return;
+  }
+  if (h->pending) {
+    (void)hipEventSynchronize(h->done);
+  }
+  (void)hipFree(h->d_scratch);
+  (void)hipHostFree(h->h_scratch);
+  (void)hipEventDestroy(h->done);
+  delete h;
+}
+
+extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_data, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
+                                     void* stream)
+{
+  if (!h || !d_data || !tbs || !d_e_bits || n_tb == 0) {
+    set_error("sch encode: invalid arguments");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  hipStream_t                 st = (hipStream_t)stream;
+  std::vector<tcod::TbCbJob>  cbs;
+  std::vector<tcod::TbCrcJob> crcs(n_tb);
+  for (uint32_t t = 0; t < n_tb; t++) {
+    const srsran_hip_tb_t& tb = tbs[t];
+    srsran_cbsegm_t        cs;
+    if (srsran_cbsegm(&cs, tb.tbs) || tb.Qm == 0 || tb.rv > 3 || (tb.tbs & 7) || tb.tbs == 0 || tb.nof_e_bits % tb.Qm) {
+      set_error("sch encode: transport block %u: invalid tbs / Qm / rv / nof_e_bits", t);
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    if (cs.F) {
+      fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // sch.c:249-252
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    crcs[t] = {tb.data_offset, tb.tbs / 8};
+    // sch.c:254-330: bits per block and rate-matched lengths
+    const uint32_t Gp = tb.nof_e_bits / tb.Qm, gamma = Gp % cs.C;
+    uint32_t       src = 8 * tb.data_offset, wp = tb.e_offset;
+    for (uint32_t i = 0; i < cs.C; i++) {
+      tcod::TbCbJob j{};
+      j.K             = i < cs.C2 ? cs.K2 : cs.K1; // sch.c:284-290: the transmit side puts the C2 smaller blocks first (the receive side, sch.c:392, the C1 larger ones; valid LTE block sizes never mix the two)
+      const uint32_t rlen = cs.C == 1 ? j.K : j.K - 24; // bits of the block without its own CRC
+      const bool     last = i + 1 == cs.C;
+      j.src_bit       = src;
+      j.n_src_bits    = last ? rlen - 24 : rlen; // the last block ends with the 24 transport-block CRC bits
+      j.tb_crc        = last ? t : 0xffffffffu;
+      j.crc24b        = cs.C > 1 ? 1u : 0u;
+      j.E             = tb.Qm * (Gp / cs.C) + ((i <= cs.C - gamma - 1) ? 0u : tb.Qm); // sch.c:296-300
+      j.out_bit       = wp;
+      if (!qpp_params(j.K, &j.f1, &j.f2)) {
+        return SRSRAN_ERROR_INVALID_INPUTS;
+      }
+      j.table = rm::device_fwd_table(j.K, tb.rv, &j.table_len);
+      if (!j.table) {
+        return SRSRAN_ERROR;
+      }
+      src += j.n_src_bits;
+      wp += j.E;
+      cbs.push_back(j);
+    }
+  }
+  const size_t bytes = cbs.size() * sizeof(tcod::TbCbJob) + n_tb * (sizeof(tcod::TbCrcJob) + 4) + 64;
+  if (h->pending) {
+    PHY_HIP_CHECK(hipEventSynchronize(h->done), SRSRAN_ERROR);
+    h->pending = false;
+  }
+  if (bytes > h->cap) {
+    (void)hipFree(h->d_scratch);
+    (void)hipHostFree(h->h_scratch);
+    h->d_scratch = h->h_scratch = nullptr;
+    h->cap                      = 0;
+    PHY_HIP_CHECK(hipMalloc(&h->d_scratch, bytes * 2), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipHostMalloc(&h->h_scratch, bytes * 2), SRSRAN_ERROR);
+    h->cap = bytes * 2;
+  }
+  uint8_t* hb = static_cast<uint8_t*>(h->h_scratch);
+  memcpy(hb, cbs.data(), cbs.size() * sizeof(tcod::TbCbJob));
+  memcpy(hb + cbs.size() * sizeof(tcod::TbCbJob), crcs.data(), n_tb * sizeof(tcod::TbCrcJob));
+  uint8_t* db = static_cast<uint8_t*>(h->d_scratch);
+  PHY_HIP_CHECK(hipMemcpyAsync(db, hb, cbs.size() * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  tcod::TbParams p{};
+  p.data   = d_data;
+  p.e_bits = d_e_bits;
+  p.cbs    = reinterpret_cast<const tcod::TbCbJob*>(db);
+  p.tbs    = reinterpret_cast<const tcod::TbCrcJob*>(db + cbs.size() * sizeof(tcod::TbCbJob));
+  p.tb_crc = reinterpret_cast<uint32_t*>(db + cbs.size() * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob));
+  p.n_cb   = (uint32_t)cbs.size();
+  p.n_tb   = n_tb;
+  // the code blocks OR their partial bytes into the output: clear every transport block's range first
+  for (uint32_t t = 0; t < n_tb; t++) {
+    const uint32_t b0 = tbs[t].e_offset / 8, b1 = (tbs[t].e_offset + tbs[t].nof_e_bits + 7) / 8;
+    PHY_HIP_CHECK(hipMemsetAsync(d_e_bits + b0, 0, b1 - b0, st), SRSRAN_ERROR);
+  }
+  PHY_HIP_CHECK(tcod::launch_tb_crc24a(p, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(tcod::launch_tb_encode(p, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipEventRecord(h->done, st), SRSRAN_ERROR);
+  h->pending = true;
+  return SRSRAN_SUCCESS;
+}

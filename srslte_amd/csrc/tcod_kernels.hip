@@ -1,0 +1,277 @@
+// tcod_kernels.hip -- LTE turbo encoder (TS 36.212 5.1.3.2; lib/src/phy/fec/turbo/turbocoder.c:76-185) and the transmit side of a
+// transport block (sch.c:230-330 encode_tb: CRC24A, segmentation, CRC24B, turbo coding, rate matching, concatenation) for gfx950.
+//
+// One wave = one code block.  The two recursive convolutional encoders are linear over GF(2): every lane runs its stretch of
+// the block from the zero state, the true entry states follow from a scan over the 64 lanes (state' = A^len state + v; A has
+// period 7), and a second run from the true entry state emits the parity bits.  The CRCs use the same splitting: a bit-serial
+// checksum per stretch, shifted into place by x^(bits behind it) mod g and XOR-ed over the wave.
+#include "hip_common.h"
+#include "tcod_device.h"
+
+namespace phyhip {
+namespace tcod {
+
+namespace {
+
+#define TX_NULL 100u // turbocoder.h:41 SRSRAN_TX_NULL
+
+// registers r0 (newest), r1, r2 in bits 0..2; turbocoder.c:118-124
+__device__ __forceinline__ uint32_t rsc_step(uint32_t s, uint32_t bit, uint32_t* out)
+{
+  const uint32_t r0 = s & 1u, r1 = (s >> 1) & 1u, r2 = (s >> 2) & 1u;
+  const uint32_t in = bit ^ r2 ^ r1;
+  *out              = r2 ^ r0 ^ in;
+  return in | (r0 << 1) | (r1 << 2);
+}
+
+__device__ __forceinline__ uint32_t rsc_idle(uint32_t s, uint32_t n) // n zero-input steps (period 7)
+{
+  n %= 7u;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t o;
+    s = rsc_step(s, 0u, &o);
+  }
+  return s;
+}
+
+struct Qpp { // PI(i) = (f1 i + f2 i^2) mod K, walked incrementally
+  uint32_t pi, g, K, step2;
+  __device__ __forceinline__ void start(uint32_t i, uint32_t K_, uint32_t f1, uint32_t f2)
+  {
+    K     = K_;
+    pi    = (uint32_t)(((uint64_t)f1 * i + (uint64_t)f2 * i % K * i) % K);
+    g     = (uint32_t)((f1 + (uint64_t)f2 * (2ull * i + 1ull)) % K); // PI(i+1) - PI(i)
+    step2 = (2u * f2) % K;
+  }
+  __device__ __forceinline__ void next()
+  {
+    pi += g;
+    pi -= pi >= K ? K : 0u;
+    g += step2;
+    g -= g >= K ? K : 0u;
+  }
+};
+
+// d: the natural code word in LDS, 3 K + 12 bytes: d[3 i] = input bit i (0 / 1 / TX_NULL) on entry; d[3 i + 1], d[3 i + 2] receive
+// the two parity bits, d[3 K ..] the 12 tail bits.  All 64 lanes of the wave call this.
+__device__ __forceinline__ void encode_block(uint8_t* d, uint32_t K, uint32_t f1, uint32_t f2)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t L    = (K + 63u) / 64u;
+  const uint32_t i0 = min(lane * L, K), i1 = min(i0 + L, K);
+  uint32_t       fin[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    // run from the zero state
+    uint32_t s = 0, o;
+    Qpp      q;
+    q.start(i0, K, f1, f2);
+    for (uint32_t i = i0; i < i1; i++) {
+      uint32_t b = d[3u * (e == 0 ? i : q.pi)];
+      s          = rsc_step(s, b == TX_NULL ? 0u : b, &o);
+      q.next();
+    }
+    // true entry states: lane l+1 enters where lane l leaves
+    uint32_t s_in = 0, s_out = s; // lane 0 enters at zero: its zero-state run is already the truth
+    for (uint32_t l = 0; l < 63u; l++) {
+      const uint32_t v = __shfl(s_out, l);
+      if (lane == l + 1) {
+        s_in  = v;
+        s_out = rsc_idle(v, i1 - i0) ^ s;
+      }
+    }
+    fin[e] = __shfl(s_out, 63);
+    // second run, from the true entry state
+    s = s_in;
+    q.start(i0, K, f1, f2);
+    for (uint32_t i = i0; i < i1; i++) {
+      uint32_t b       = d[3u * (e == 0 ? i : q.pi)];
+      s                = rsc_step(s, b == TX_NULL ? 0u : b, &o);
+      d[3u * i + 1 + e] = (uint8_t)o;
+      q.next();
+    }
+  }
+  if (lane < 2) { // turbocoder.c:150-185: three (systematic, parity) pairs per constituent encoder
+    uint32_t s = fin[lane];
+    for (int j = 0; j < 3; j++) {
+      const uint32_t bit = ((s >> 2) ^ (s >> 1)) & 1u;
+      uint32_t       o;
+      s                        = rsc_step(s, bit, &o);
+      d[3u * K + lane * 6 + 2 * j]     = (uint8_t)bit;
+      d[3u * K + lane * 6 + 2 * j + 1] = (uint8_t)o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void encode_kernel(const EncParams p)
+{
+  extern __shared__ uint8_t sm[]; // the natural code word d
+  const uint32_t K   = p.K;
+  const uint8_t* in  = p.in + (size_t)blockIdx.x * p.in_stride;
+  uint8_t*       out = p.out + (size_t)blockIdx.x * p.out_stride;
+  for (uint32_t i = threadIdx.x; i < K; i += 64) {
+    sm[3u * i] = in[i];
+  }
+  __syncthreads();
+  encode_block(sm, K, p.f1, p.f2);
+  __syncthreads();
+  // turbocoder.c:109-147: systematic raw, first parity TX_NULL where the input is, second parity always a bit
+  for (uint32_t t = threadIdx.x; t < 3 * K + 12; t += 64) {
+    uint8_t v = sm[t];
+    if (t < 3 * K && t % 3u == 1 && sm[t - 1] == TX_NULL) {
+      v = (uint8_t)TX_NULL;
+    }
+    out[t] = v;
+  }
+}
+
+// ---- CRC helpers (crc.c:92-140: MSB first, zero initial state, 24-bit generators) ----------------------------------------------
+__device__ __forceinline__ uint32_t crc24_bit(uint32_t c, uint32_t bit, uint32_t poly)
+{
+  return ((c << 1) & 0xffffffu) ^ ((((c >> 23) ^ bit) & 1u) ? poly : 0u);
+}
+__device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t m, uint32_t poly) // a(x) m(x) mod g(x)
+{
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+    r ^= ((m >> i) & 1u) ? a : 0u;
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t xpow24(uint32_t n, uint32_t poly) // x^n mod g(x)
+{
+  uint32_t r = 1, b = 2; // b = x
+  while (n) {
+    if (n & 1u) {
+      r = mulmod24(r, b, poly);
+    }
+    b = mulmod24(b, b, poly);
+    n >>= 1;
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v ^= __shfl_xor(v, off);
+  }
+  return v;
+}
+
+#define CRC24A_POLY 0x864CFBu // crc.h:41-42 without the x^24 term
+#define CRC24B_POLY 0x800063u
+
+// CRC24A of the payload bytes of one transport block: one wave per block
+__global__ __launch_bounds__(64) void tb_crc24a_kernel(const TbParams p)
+{
+  const TbCrcJob  job = p.tbs[blockIdx.x];
+  const uint8_t*  d   = p.data + job.src_byte;
+  const uint32_t  L   = (job.n_bytes + 63u) / 64u;
+  const uint32_t  i0 = min((threadIdx.x & 63u) * L, job.n_bytes), i1 = min(i0 + L, job.n_bytes);
+  uint32_t        c = 0;
+  for (uint32_t i = i0; i < i1; i++) {
+    const uint32_t b = d[i];
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+      c = crc24_bit(c, (b >> k) & 1u, CRC24A_POLY);
+    }
+  }
+  c = mulmod24(c, xpow24(8u * (job.n_bytes - i1), CRC24A_POLY), CRC24A_POLY);
+  c = wave_xor(c);
+  if (threadIdx.x == 0) {
+    p.tb_crc[blockIdx.x] = c;
+  }
+}
+
+// one code block of a transport block: gather its bits, append the CRCs, encode, rate-match into the packed output
+__global__ __launch_bounds__(64) void tb_encode_kernel(const TbParams p)
+{
+  extern __shared__ uint8_t sm[]; // the natural code word d, as in the encoder kernel
+  const TbCbJob  job  = p.cbs[blockIdx.x];
+  const uint32_t K    = job.K;
+  const uint32_t lane = threadIdx.x;
+  // payload bits of this block (sch.c:262-286: bytes of the transport block, MSB first)
+  for (uint32_t i = lane; i < job.n_src_bits; i += 64) {
+    const uint32_t b = job.src_bit + i;
+    sm[3u * i]       = (p.data[b >> 3] >> (7u - (b & 7u))) & 1u;
+  }
+  uint32_t n = job.n_src_bits;
+  if (job.tb_crc != 0xffffffffu) { // the transport-block CRC closes the last block (sch.c:268-273)
+    const uint32_t crc = p.tb_crc[job.tb_crc];
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (crc >> (23u - lane)) & 1u;
+    }
+    n += 24;
+  }
+  __syncthreads();
+  if (job.crc24b) { // sch.c:276-284 / turbocoder.c:230-255
+    const uint32_t L  = (n + 63u) / 64u;
+    const uint32_t i0 = min(lane * L, n), i1 = min(i0 + L, n);
+    uint32_t       v  = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+      v = crc24_bit(v, sm[3u * i], CRC24B_POLY);
+    }
+    v = wave_xor(mulmod24(v, xpow24(n - i1, CRC24B_POLY), CRC24B_POLY));
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (v >> (23u - lane)) & 1u;
+    }
+    __syncthreads();
+  }
+  encode_block(sm, K, job.f1, job.f2);
+  __syncthreads();
+  // rate matching (rm_turbo.c:340-378, TS 36.212 5.1.4.1.2): output bit k = d[table[k mod Ncb]], d natural = 3 i + stream;
+  // the code blocks are concatenated bit-wise (E need not be a multiple of 8): whole bytes are stored, the two partial bytes
+  // at the ends are OR-ed in atomically (the output is zeroed beforehand)
+  const uint32_t first = job.out_bit, last = job.out_bit + job.E; // [first, last)
+  for (uint32_t byte = (first >> 3) + lane; byte <= ((last - 1) >> 3) && job.E; byte += 64) {
+    uint32_t v = 0, mask = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t ob = byte * 8u + k;
+      if (ob >= first && ob < last) {
+        const uint32_t bit = sm[job.table[(ob - first) % job.table_len]];
+        v |= bit << (7u - k);
+        mask |= 1u << (7u - k);
+      }
+    }
+    if (mask == 0xffu) {
+      p.e_bits[byte] = (uint8_t)v;
+    } else {
+      atomicOr((unsigned int*)(p.e_bits + (byte & ~3u)), v << (8u * (byte & 3u)));
+    }
+  }
+}
+
+} // namespace
+
+hipError_t launch_encode(const EncParams& p, hipStream_t stream)
+{
+  if (p.n_cb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(encode_kernel, dim3(p.n_cb), dim3(64), 3 * p.K + 16, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream)
+{
+  if (p.n_tb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(tb_crc24a_kernel, dim3(p.n_tb), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tb_encode(const TbParams& p, hipStream_t stream)
+{
+  if (p.n_cb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(tb_encode_kernel, dim3(p.n_cb), dim3(64), 3 * 6144 + 16, stream, p);
+  return hipGetLastError();
+}
+
+} // namespace tcod
+} // namespace phyhip

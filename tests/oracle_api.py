@@ -142,19 +142,21 @@ def rm_table(K, rv, nsb=0):
     return t
 
 
-def tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng):
+def tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng, payload=None, tx_order=False):
     """transmit side of one transport block (36.212 5.1.1-5.1.5 as sch.c encode_tb does it: CRC24A, segmentation,
     CRC24B per block, turbo code, rate matching of redundancy version rv, concatenation).
     Returns (coded bits e, uint8 [<= nof_e_bits]; payload bytes incl. the CRC24A)"""
     s = cbsegm(tbs)
     assert s["F"] == 0
-    payload = rng.integers(0, 2, tbs).astype(np.uint8)
+    payload = rng.integers(0, 2, tbs).astype(np.uint8) if payload is None else np.asarray(payload, np.uint8)
     b = crc_attach(payload, CRC24A)
     e, pos = [], 0
     Gp = nof_e_bits // Qm
     gamma, n_e = Gp % s["C"], Qm * (Gp // s["C"])
     for i in range(s["C"]):
-        K = s["K1"] if i < s["C1"] else s["K2"]
+        # sch.c:392 (receive) takes the C1 blocks of K1 bits first, sch.c:284 (transmit) the C2 blocks of K2 bits; standard
+        # transport block sizes have C2 = 0
+        K = (s["K2"] if i < s["C2"] else s["K1"]) if tx_order else (s["K1"] if i < s["C1"] else s["K2"])
         rlen = K if s["C"] == 1 else K - 24
         cb = b[pos:pos + rlen]
         pos += rlen

@@ -121,3 +121,103 @@ def test_harq_retransmission_and_errors(hiplib):
         flags[:] = 0
         assert lib.srsran_hip_sch_decode(h, d.ptr, (capi.HipTb * 1)(bad), 1, 8, d.ptr, O.P(flags), d.ptr, r, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
     lib.srsran_hip_sch_free(h)
+
+
+def test_turbo_encoder(hiplib):
+    """srsran_tcod_encode (turbocoder.c:76-185) drop-in and batched, every block size, filler marks"""
+    import ctypes as C
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(12)
+    q = capi.Tcod()
+    assert lib.srsran_tcod_init(C.byref(q), 6144) == 0
+    orc = O.orc()
+    for K in (40, 48, 512, 1008, 2112, 6144):
+        x = rng.integers(0, 2, K).astype(np.uint8)
+        x[:min(K // 4, 28)] = 100  # SRSRAN_TX_NULL
+        out, want = np.zeros(3 * K + 12, np.uint8), np.zeros(3 * K + 12, np.uint8)
+        assert lib.srsran_tcod_encode(C.byref(q), O.P(x), O.P(out), K) == 0
+        assert orc.orc_tcod_encode(O.P(x), O.P(want), K) == 0
+        assert np.array_equal(out, want), K
+    x = np.zeros(41, np.uint8)
+    assert lib.srsran_tcod_encode(C.byref(q), O.P(x), O.P(out), 41) == -1  # "Invalid CB size"
+    small = capi.Tcod()
+    assert lib.srsran_tcod_init(C.byref(small), 512) == 0
+    assert lib.srsran_tcod_encode(C.byref(small), O.P(x), O.P(out), 1024) == -1  # initiated for max_long_cb=512
+    lib.srsran_tcod_free(C.byref(small))
+    lib.srsran_tcod_free(C.byref(q))
+    for K in O.tc_sizes():
+        n_cb = 3
+        x = rng.integers(0, 2, (n_cb, K)).astype(np.uint8)
+        d_in, d_out = S.DeviceBuffer.from_numpy(x), S.DeviceBuffer(n_cb * (3 * K + 12))
+        capi.check(lib.srsran_hip_tcod_encode_batch(d_in.ptr, K, d_out.ptr, 3 * K + 12, n_cb, K, None), "tcod batch")
+        capi.check(lib.srsran_hip_stream_sync(None), "sync")
+        got = d_out.to_numpy(np.uint8, (n_cb, 3 * K + 12))
+        for i in range(n_cb):
+            assert np.array_equal(got[i], O.turbo_encode(x[i])), (K, i)
+
+
+def test_transport_block_encode(hiplib):
+    """srsran_hip_sch_encode == encode_tb_off of the reference (fixture built from its CRC / tcod_encode_lut / rm_turbo_tx_lut),
+    several transport blocks per call at unaligned bit offsets, and a device loop-back through srsran_hip_sch_decode"""
+    import ctypes as C
+    import os
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sch_tx_ref.npz"))
+    h = C.c_void_p()
+    capi.check(lib.srsran_hip_sch_enc_create(C.byref(h)), "enc_create")
+    keys = [str(k) for k in d["cases"]]
+    datas, tb, want, off_b, off_e = [], [], [], 0, 5
+    for key in keys:
+        tbs, Qm, rv, nof_e = [int(t.lstrip("tbqrvg")) for t in key.split("_")]
+        datas.append(d[key + "_data"])
+        tb.append(capi.HipTb(tbs, Qm, rv, nof_e, off_e, off_b, 0))
+        want.append((off_e, nof_e, np.unpackbits(d[key + "_e"])[:nof_e // Qm * Qm]))
+        off_b += tbs // 8
+        off_e += nof_e + 3
+    d_data = S.DeviceBuffer.from_numpy(np.concatenate(datas))
+    d_e = S.DeviceBuffer.from_numpy(np.full(off_e // 8 + 16, 0xFF, np.uint8))
+    arr = (capi.HipTb * len(tb))(*tb)
+    for _ in range(2):
+        capi.check(lib.srsran_hip_sch_encode(h, d_data.ptr, arr, len(tb), d_e.ptr, None), "sch_encode")
+    capi.check(lib.srsran_hip_stream_sync(None), "sync")
+    got = np.unpackbits(d_e.to_numpy(np.uint8, (off_e // 8 + 16,)))
+    for key, (o, n, e) in zip(keys, want):
+        assert np.array_equal(got[o:o + e.size], e), key
+    bad = (capi.HipTb * 1)(capi.HipTb(6208, 2, 0, 9000, 0, 0, 0))  # filler bits
+    assert lib.srsran_hip_sch_encode(h, d_data.ptr, bad, 1, d_e.ptr, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
+    # loop-back: 24 transport blocks encoded on the device, BPSK soft bits, decoded on the device
+    rng = np.random.default_rng(3)
+    tbs, Qm, G, n_tb = 75376, 6, 100800, 24
+    ncb = O.cbsegm(tbs)["C"]
+    payload = rng.integers(0, 256, (n_tb, tbs // 8)).astype(np.uint8)
+    d_data = S.DeviceBuffer.from_numpy(payload)
+    d_e = S.DeviceBuffer(n_tb * G // 8)
+    tbv = (capi.HipTb * n_tb)(*[capi.HipTb(tbs, Qm, 0, G, i * G, i * (tbs // 8), i * ncb) for i in range(n_tb)])
+    capi.check(lib.srsran_hip_sch_encode(h, d_data.ptr, tbv, n_tb, d_e.ptr, None), "sch_encode")
+    capi.check(lib.srsran_hip_stream_sync(None), "sync")
+    e = np.unpackbits(d_e.to_numpy(np.uint8, (n_tb * G // 8,))).reshape(n_tb, G)
+    assert np.array_equal(e[0], O.tb_coded_bits(tbs, Qm, G, 0, None, payload=np.unpackbits(payload[0]), tx_order=True)[0])
+    llr = np.clip(np.round(40.0 * ((2.0 * e - 1.0) + 0.45 * rng.standard_normal(e.shape))), -32768, 32767).astype(np.int16)
+    d_llr = S.DeviceBuffer.from_numpy(llr)
+    dlen = tbs // 8 + 8
+    d_out = S.DeviceBuffer.from_numpy(np.zeros((n_tb, dlen), np.uint8))
+    d_soft = S.DeviceBuffer.from_numpy(np.zeros((n_tb * ncb, capi.SOFTBUFFER_CB_SIZE), np.int16))
+    flags = np.zeros(n_tb * ncb, np.uint8)
+    res = (capi.HipTbResult * n_tb)()
+    rx = (capi.HipTb * n_tb)(*[capi.HipTb(tbs, Qm, 0, G, i * G, i * dlen, i * ncb) for i in range(n_tb)])
+    hd = C.c_void_p()
+    capi.check(lib.srsran_hip_sch_create(C.byref(hd)), "sch_create")
+    capi.check(lib.srsran_hip_sch_decode(hd, d_llr.ptr, rx, n_tb, 8, d_soft.ptr, flags.ctypes.data, d_out.ptr, res, None), "sch_decode")
+    out = d_out.to_numpy(np.uint8, (n_tb, dlen))
+    assert all(r.crc_ok == 0 for r in res)
+    assert np.array_equal(out[:, :tbs // 8], payload)
+    lib.srsran_hip_sch_free(hd)
+    lib.srsran_hip_sch_enc_free(h)

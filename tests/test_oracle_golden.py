@@ -114,6 +114,17 @@ def test_ldpc_encoder_and_rate_matching_reference_outputs():
                 assert r == want[1]
 
 
+def test_transport_block_transmit_chain_reference_outputs():
+    """encode_tb_off (sch.c:238-345) built from the compiled reference's CRC, srsran_tcod_encode_lut and srsran_rm_turbo_tx_lut"""
+    d = np.load(os.path.join(G, "sch_tx_ref.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        tbs, Qm, rv, nof_e = [int(t.lstrip("tbqrvg")) for t in key.split("_")]
+        e, _ = O.tb_coded_bits(tbs, Qm, nof_e, rv, None, payload=np.unpackbits(d[key + "_data"]), tx_order=True)
+        n = e.size // 8
+        assert np.array_equal(np.packbits(e)[:n], d[key + "_e"][:n]), key
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

@@ -18,6 +18,8 @@ No reference source text is stored.
                                scrambling chips recovered from srsran_sequence_apply_s / pusch / pdsch apply
   tests/golden/ldpc_tx_ref.npz reference LDPC encoder (C and AVX2: equal) code words with and without filler bits, srsran_ldpc_rm_tx
                                outputs and srsran_ldpc_rm_rx_{c,s,f} soft buffers (as CRC32) on stored inputs
+  tests/golden/sch_tx_ref.npz  transmit side of transport blocks as encode_tb_off (sch.c:238-345) chains the reference's
+                               srsran_crc_*, srsran_tcod_encode_lut and srsran_rm_turbo_tx_lut: payload bytes -> packed e bits
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -327,6 +329,59 @@ def ldpc_tx():
     print("ldpc_tx_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_tx_ref.npz")))
 
 
+def sch_tx():
+    class Tcod(C.Structure):
+        _fields_ = [("max_long_cb", C.c_uint32), ("temp", C.c_void_p)]
+
+    class Seg(C.Structure):
+        _fields_ = [(n, C.c_uint32) for n in ("F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs", "L_tb", "L_cb", "Z")]
+
+    crc_tb, crc_cb = C.create_string_buffer(4096), C.create_string_buffer(4096)
+    assert ref.srsran_crc_init(crc_tb, C.c_uint32(0x1864CFB), 24) == 0 and ref.srsran_crc_init(crc_cb, C.c_uint32(0x1800063), 24) == 0
+    tc = Tcod()
+    assert ref.srsran_tcod_init(C.byref(tc), 6144) == 0
+    ref.srsran_rm_turbo_gentables()
+    rng = np.random.default_rng(31)
+    d, cases = {}, []
+    for tbs, Qm, rv, G in ((40, 2, 0, 120), (6200, 6, 0, 9000), (75376, 6, 0, 100800), (75376, 6, 2, 100800), (12960, 4, 1, 21004),
+                           (6264, 2, 3, 7000), (31704, 8, 0, 40000), (2216, 2, 2, 9000)):
+        seg = Seg()
+        assert ref.srsran_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0
+        data = rng.integers(0, 256, tbs // 8 + 3).astype(np.uint8)
+        data[tbs // 8:] = 0
+        e_bits = np.zeros(G // 8 + 8, np.uint8)
+        cb_in, parity = np.zeros(6144 // 8 + 64, np.uint8), np.zeros(3 * 6144 // 8 + 64, np.uint8)
+        Gp = G // Qm
+        gamma = Gp % seg.C
+        ref.srsran_crc_set_init(crc_tb, C.c_uint64(0))
+        rp = wp = 0
+        for i in range(seg.C):  # sch.c:280-340
+            cb_len, idx = (seg.K2, seg.K2_idx) if i < seg.C2 else (seg.K1, seg.K1_idx)
+            rlen = cb_len - 24 if seg.C > 1 else cb_len
+            n_e = Qm * (Gp // seg.C) if i <= seg.C - gamma - 1 else Qm * -(-Gp // seg.C)
+            last = i == seg.C - 1
+            nb = (rlen - 24) // 8 if last else rlen // 8
+            cb_in[:] = 0
+            cb_in[:nb] = data[rp // 8:rp // 8 + nb]
+            ref.srsran_tcod_encode_lut(C.byref(tc), crc_tb, crc_cb if seg.C > 1 else None, P(cb_in), P(parity), C.c_uint32(idx), C.c_bool(last))
+            w_buff = np.zeros(3 * 6176, np.uint8)
+            if rv:  # a retransmission reads the circular buffer the first transmission (rv 0) filled: rm_turbo.c:352-361
+                scratch = np.zeros(n_e // 8 + 8, np.uint8)
+                assert ref.srsran_rm_turbo_tx_lut(P(w_buff), P(cb_in), P(parity), P(scratch), C.c_uint32(idx), C.c_uint32(n_e), C.c_uint32(0), C.c_uint32(0)) == 0
+            assert ref.srsran_rm_turbo_tx_lut(P(w_buff), P(cb_in), P(parity), C.c_void_p(e_bits.ctypes.data + wp // 8), C.c_uint32(idx), C.c_uint32(n_e),
+                                              C.c_uint32(wp % 8), C.c_uint32(rv)) == 0
+            rp += rlen
+            wp += n_e
+        key = "tb%d_q%d_rv%d_g%d" % (tbs, Qm, rv, G)
+        d[key + "_data"], d[key + "_e"] = data[:tbs // 8], e_bits[:(G + 7) // 8]
+        cases.append(key)
+        want = np.packbits(O.tb_coded_bits(tbs, Qm, G, rv, None, payload=np.unpackbits(data[:tbs // 8]), tx_order=True)[0])
+        assert np.array_equal(want[:wp // 8], e_bits[:wp // 8]), key
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "sch_tx_ref.npz"), **d)
+    print("sch_tx_ref.npz", os.path.getsize(os.path.join(OUT, "sch_tx_ref.npz")))
+
+
 def modem():
     d = {}
     cases = []
@@ -382,6 +437,6 @@ def modem():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx}[name]()

@@ -63,7 +63,8 @@ std::vector<uint16_t> build_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
 // device pool of tables, built on first use
 struct TablePool {
   std::mutex                       mu;
-  std::map<uint32_t, uint16_t*>    dev;  // key = K | rv << 16 | nof_sb << 20
+  std::map<uint32_t, uint16_t*>    dev;  // key = K | rv << 16 | nof_sb << 20 (bit 31: forward table of the transmit side)
+  std::map<uint32_t, uint32_t>     fwd_len;
   ~TablePool()
   {
     for (auto& kv : dev) {
@@ -103,21 +104,23 @@ const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
 const uint16_t* fwd_table_on_device(uint32_t K, uint32_t rv, uint32_t* len)
 {
   const uint32_t              key = K | (rv << 16) | (1u << 31);
-  const std::vector<uint16_t> fwd = build_table(K, rv, 0);
-  *len                            = (uint32_t)fwd.size();
   std::lock_guard<std::mutex> lk(g_pool.mu);
   auto                        it = g_pool.dev.find(key);
   if (it != g_pool.dev.end()) {
+    *len = g_pool.fwd_len[key];
     return it->second;
   }
-  uint16_t* d = nullptr;
+  const std::vector<uint16_t> fwd = build_table(K, rv, 0);
+  uint16_t*                   d   = nullptr;
   if (hipMalloc(&d, fwd.size() * sizeof(uint16_t)) != hipSuccess ||
       hipMemcpy(d, fwd.data(), fwd.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("rm_turbo: cannot place the transmit table of K=%u rv=%u on the device", K, rv);
     (void)hipFree(d);
     return nullptr;
   }
-  g_pool.dev[key] = d;
+  g_pool.dev[key]     = d;
+  g_pool.fwd_len[key] = (uint32_t)fwd.size();
+  *len                = (uint32_t)fwd.size();
   return d;
 }
 

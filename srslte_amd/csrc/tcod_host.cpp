@@ -5,6 +5,7 @@
 #include "tables/lte_qpp_table.h"
 #include "tcod_device.h"
 
+#include <algorithm>
 #include <vector>
 
 using namespace phyhip;
@@ -237,9 +238,17 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   p.tb_crc = reinterpret_cast<uint32_t*>(db + cbs.size() * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob));
   p.n_cb   = (uint32_t)cbs.size();
   p.n_tb   = n_tb;
-  // the code blocks OR their partial bytes into the output: clear every transport block's range first
+  // the code blocks OR their partial bytes into the output: clear every transport block's range first (adjacent ranges merged)
+  std::vector<std::pair<uint32_t, uint32_t>> rng;
   for (uint32_t t = 0; t < n_tb; t++) {
-    const uint32_t b0 = tbs[t].e_offset / 8, b1 = (tbs[t].e_offset + tbs[t].nof_e_bits + 7) / 8;
+    rng.emplace_back(tbs[t].e_offset / 8, (tbs[t].e_offset + tbs[t].nof_e_bits + 7) / 8);
+  }
+  std::sort(rng.begin(), rng.end());
+  for (size_t i = 0; i < rng.size();) {
+    uint32_t b0 = rng[i].first, b1 = rng[i].second;
+    for (i++; i < rng.size() && rng[i].first <= b1; i++) {
+      b1 = std::max(b1, rng[i].second);
+    }
     PHY_HIP_CHECK(hipMemsetAsync(d_e_bits + b0, 0, b1 - b0, st), SRSRAN_ERROR);
   }
   PHY_HIP_CHECK(tcod::launch_tb_crc24a(p, st), SRSRAN_ERROR);

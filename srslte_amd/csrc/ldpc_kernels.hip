@@ -34,6 +34,7 @@ struct Pol8 {
   typedef int     A;
   static constexpr bool kC2vInLds = false; // see the kernel: the HBM/L2 slab wins over LDS residency through occupancy
   static constexpr bool kIntegerFast = true;
+  static constexpr int  kMinWaves    = 1; // 120 VGPRs as it is
   static __device__ __forceinline__ A min_init() { return 127; }
   static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_c.c:338-363
   {
@@ -47,8 +48,10 @@ struct Pol8 {
   static __device__ __forceinline__ A negate(A m) { return -m; }
   static __device__ __forceinline__ A soft(A cn, A v) // :308-315
   {
-    const A t = cn + v;
-    return t > 63 ? 127 : (t < -63 ? -127 : t);
+    // t > 63 -> 127, t < -63 -> -127, written without compares (no VCC round trips): clamp, then push what was clipped out to
+    // the "infinity" value 63 + 64
+    const A t = cn + v, k = min(max(t, -63), 63);
+    return k + (min(max(t - k, -1), 1) << 6);
   }
 };
 
@@ -58,6 +61,9 @@ struct Pol16 {
   typedef int     A;
   static constexpr bool kC2vInLds = false;
   static constexpr bool kIntegerFast = true;
+  // two 6-wave workgroups share a CU (3 waves per SIMD after balancing, 4 on a SIMD while they overlap): above 128 VGPRs
+  // the second workgroup does not fit and the decoder runs at half occupancy (75 ms instead of 55 ms)
+  static constexpr int  kMinWaves    = 4;
   static __device__ __forceinline__ A min_init() { return 32767; }
   static __device__ __forceinline__ A v2c(A s, A c) // ldpc_dec_s.c:338-363
   {
@@ -76,8 +82,8 @@ struct Pol16 {
   static __device__ __forceinline__ A negate(A m) { return -m; }
   static __device__ __forceinline__ A soft(A cn, A v) // :303-311
   {
-    const A t = cn + v;
-    return t > 16383 ? 32767 : (t < -16383 ? -32767 : t);
+    const A t = cn + v, k = min(max(t, -16383), 16383);
+    return k + (min(max(t - k, -1), 1) << 14); // 16383 + 16384 = 32767
   }
 };
 
@@ -87,6 +93,7 @@ struct PolF {
   typedef float A;
   static constexpr bool kC2vInLds = false;
   static constexpr bool kIntegerFast = false;
+  static constexpr int  kMinWaves    = 1;
   static __device__ __forceinline__ A min_init() { return INFINITY; }
   static __device__ __forceinline__ A v2c(A s, A c) { return __fsub_rn(s, c); } // ldpc_dec_f.c:172-181
   static __device__ __forceinline__ A mag(A x) { return fabsf(x); }
@@ -98,8 +105,10 @@ struct PolF {
 
 // One layer (base-graph row) for one lifted check node: all operand loads are issued before the first use
 // so that a layer costs two memory round trips, not two per edge.
+// c2v: the slab of this workgroup (wave-uniform pointer, so that the accesses take the scalar-base form with a 32-bit
+// vector offset); coff: this lane's offset inside one edge row of the slab.
 template <int DEG, class POL>
-__device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c2v, int my_edge, int e0, int c, int Z, int sf,
+__device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c2v, uint32_t coff, int my_edge, int e0, int c, int Z, int sf,
                                       float sf_f, bool active)
 {
   typedef typename POL::A  A;
@@ -114,37 +123,45 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
   if (!active) {
     return;
   }
+  const uint32_t row0 = (uint32_t)e0 * (uint32_t)Z;
+  const uint32_t cb   = (uint32_t)c * (uint32_t)sizeof(TS), Zb = (uint32_t)Z * (uint32_t)sizeof(TS);
+  char*          sbase = reinterpret_cast<char*>(soft);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    int j  = c + (ed[i] >> 16);
-    j      = j >= Z ? j - Z : j;
-    idx[i] = (ed[i] & 0xffff) + j;
-    sb[i]  = soft[idx[i]];
-    co[i]  = c2v[(e0 + i) * Z + c];
+    // byte offset of soft[col * Z + (c + shift) mod Z]: the wrapped difference is huge when c + shift < Z
+    const uint32_t j = cb + (uint32_t)(ed[i] >> 16) * (uint32_t)sizeof(TS);
+    idx[i]           = (int)((uint32_t)(ed[i] & 0xffff) * (uint32_t)sizeof(TS) + min(j, j - Zb));
+    sb[i]            = *reinterpret_cast<TS*>(sbase + idx[i]);
+    co[i]            = c2v[row0 + (uint32_t)i * (uint32_t)Z + coff];
   }
   if constexpr (POL::kIntegerFast) {
     // integer decoders: the same update written for the VALU -- second minimum as a median (v_med3_i32), sign
     // product as the XOR of the messages' sign bits, conditional negation as (m ^ s) - s
-    int min0 = POL::min_init(), min1 = POL::min_init(), pos = -1, sgn = 0;
+    // The reference gives the edge of the FIRST minimum the second minimum.  Comparing magnitudes instead of tracking that
+    // position is the same thing: with two equal smallest magnitudes the second minimum equals the minimum.
+    int min0 = POL::min_init(), min1 = POL::min_init(), sgn = 0;
+    int a[DEG];
 #pragma unroll
     for (int i = 0; i < DEG; i++) {
       const int x = POL::v2c(sb[i], co[i]);
       v[i]        = x;
-      const int a = x < 0 ? -x : x;
-      pos         = a < min0 ? i : pos;                 // strict: the first minimum keeps the position
-      min1        = max(min(a, min1), min(max(a, min1), min0)); // second smallest of {a, min0, min1}
-      min0        = min(a, min0);
+      a[i]        = x < 0 ? -x : x;
+      min1        = max(min(a[i], min1), min(max(a[i], min1), min0)); // second smallest of {a, min0, min1}
+      min0        = min(a[i], min0);
       sgn ^= x;
     }
-    const int s0 = POL::scale(min0, sf, sf_f);
-    const int s1 = POL::scale(min1, sf, sf_f);
+    int s0 = POL::scale(min0, sf, sf_f);
+    int s1 = POL::scale(min1, sf, sf_f);
+    // keep the two scalings (two quarter-rate multiplications each) here: left alone, the compiler sinks them behind the
+    // per-edge select and pays them once per edge
+    asm volatile("" : "+v"(s0), "+v"(s1));
 #pragma unroll
     for (int i = 0; i < DEG; i++) {
-      const int mag = (i == pos) ? s1 : s0;
+      const int mag = (a[i] == min0) ? s1 : s0;
       const int m   = (sgn ^ v[i]) >> 31; // all ones when the product of the OTHER signs is negative
       const int cn  = (mag ^ m) - m;
-      c2v[(e0 + i) * Z + c] = (T)cn;
-      soft[idx[i]]          = (TS)POL::soft(cn, v[i]);
+      c2v[row0 + (uint32_t)i * (uint32_t)Z + coff] = (T)cn;
+      *reinterpret_cast<TS*>(sbase + idx[i])       = (TS)POL::soft(cn, v[i]);
     }
     return;
   }
@@ -174,13 +191,13 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
     const A    mag  = (i == pos) ? s1 : s0;
     const bool sneg = neg ^ POL::neg(v[i]); // sign = product of all signs * own sign (v >= 0 counts as +)
     const A    cn   = sneg ? POL::negate(mag) : mag;
-    c2v[(e0 + i) * Z + c] = (T)cn;
-    soft[idx[i]]          = (TS)POL::soft(cn, v[i]);
+    c2v[row0 + (uint32_t)i * (uint32_t)Z + coff] = (T)cn;
+    *reinterpret_cast<TS*>(sbase + idx[i])       = (TS)POL::soft(cn, v[i]);
   }
 }
 
 template <class POL>
-__global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
 {
   typedef typename POL::T  T;
   typedef typename POL::TS TS;
@@ -198,7 +215,8 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
   // decoder that cannot do it.  With only the soft bits in LDS two workgroups share a CU, 3 waves per SIMD.
   const size_t per_cw = (size_t)liftN; // soft bits (elements of TS) in LDS per code word
   TS*          soft   = reinterpret_cast<TS*>(lds) + (size_t)cwl * per_cw;
-  T*   c2v   = reinterpret_cast<T*>(p.c2v_ws) + ((size_t)blockIdx.x * p.cpb + (cwl < p.cpb ? cwl : 0)) * p.n_edges * Z;
+  T*             c2v  = reinterpret_cast<T*>(p.c2v_ws) + (size_t)blockIdx.x * p.cpb * p.n_edges * Z; // wave-uniform slab base
+  const uint32_t coff = (uint32_t)(cwl < p.cpb ? cwl : 0) * (uint32_t)p.n_edges * (uint32_t)Z + (uint32_t)c;
   int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw * sizeof(TS) + 15) & ~(size_t)15));
   for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
     graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
       soft[n * Z + c] = llr[(n - 2) * Z + c];
     }
     for (int e = 0; e < p.n_edges; e++) {
-      c2v[e * Z + c] = 0;
+      c2v[(uint32_t)e * (uint32_t)Z + coff] = 0;
     }
   }
   __syncthreads();
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(384) void ldpc_layered_kernel(const Params p)
       switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer<D, POL>(soft, c2v, my_edge, e0, c, Z, sf, sf_f, active);                                                     \
+    layer<D, POL>(soft, c2v, coff, my_edge, e0, c, Z, sf, sf_f, active);                                                     \
     break;
         LDPC_CASE(1)
         LDPC_CASE(2)

@@ -110,6 +110,11 @@ int orc_ldpc_decode_c(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof
                       uint8_t* message, uint32_t cdwd_rm_length, uint32_t crc_poly, int crc_order,
                       int8_t* soft_out);
 
+/* the flooded schedule (SRSRAN_LDPC_DECODER_C_FLOOD and its SIMD siblings; ldpc_decoder.c:105-160, ldpc_dec_c_flood.c): same
+ * arguments and return convention; runs 2 * max_nof_iter iterations */
+int orc_ldpc_decode_c_flood(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const int8_t* llrs,
+                            uint8_t* message, uint32_t cdwd_rm_length, uint32_t crc_poly, int crc_order, int8_t* soft_out);
+
 /* srsran_ldpc_decoder_decode_s / _decode_f (ldpc_dec_s.c, ldpc_dec_f.c), fixed number of iterations (no CRC entry
  * point exists for these types, ldpc_decoder.h:111-180).  soft_out: optional liftN a-posteriori values */
 int orc_ldpc_decode_s(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const int16_t* llrs,

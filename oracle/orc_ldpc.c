@@ -468,3 +468,142 @@ int orc_ldpc_rm_rx(int type, const void* input, void* output, uint32_t E, uint32
   }
   return (int)(k0 + E < Ncb ? k0 + E : Ncb);
 }
+
+/* ---------------------------------------------------------------- flooded schedule, int8
+ * ldpc_decoder.c:105-160 (LDPC_DECODER_TEMPLATE_FLOOD) with ldpc_dec_c_flood.c: per iteration all variable-to-check
+ * messages (from the soft bits of the previous iteration), then all check-to-variable messages, then the soft bits are
+ * rebuilt from the channel LLRs by adding the messages of ALL bgM rows in row order with the +-63 -> +-127 saturation
+ * after every addition (rows beyond n_layers add zero, the saturation still applies).  2 * max_nof_iter iterations. */
+int orc_ldpc_decode_c_flood(const orc_ldpc_graph_t* g, float scaling_fctr, int max_nof_iter, const int8_t* llrs,
+                            uint8_t* message, uint32_t cdwd_rm_length, uint32_t crc_poly, int crc_order, int8_t* soft_out)
+{
+  const int ls = g->ls, bgN = g->bgN, bgM = g->bgM, bgK = g->bgK;
+  const int liftN = bgN * ls, liftK = bgK * ls, hrrN = (bgK + 4) * ls, W = hrrN + ls;
+  if (max_nof_iter == 0) {
+    max_nof_iter = 10;
+  }
+  const int sf = (int)(scaling_fctr * 100); /* ldpc_dec_c_flood.c: scaling_fctr * F2I */
+  if (cdwd_rm_length > (uint32_t)(liftN - 2 * ls)) {
+    cdwd_rm_length = liftN - 2 * ls;
+  }
+  if (cdwd_rm_length < (uint32_t)((bgK + 2) * ls)) {
+    cdwd_rm_length = (bgK + 2) * ls;
+  }
+  if (cdwd_rm_length % ls) {
+    cdwd_rm_length = (cdwd_rm_length / ls + 1) * ls;
+  }
+  const int n_layers = (uint8_t)(cdwd_rm_length / ls - bgK + 2);
+
+  int8_t* llr  = malloc(liftN);
+  int8_t* soft = malloc(liftN);
+  int8_t* c2v  = calloc((size_t)W * bgM, 1);
+  int8_t* v2c  = calloc((size_t)W * bgM, 1);
+  int8_t (*minv)[2] = malloc(ls * sizeof(int8_t[2]));
+  int*    min_idx = calloc(ls, sizeof(int)); /* uninitialised in the reference; only read when it was just written */
+  int*    prod    = malloc(ls * sizeof(int));
+  memset(llr, 0, 2 * ls);
+  memcpy(llr + 2 * ls, llrs, liftN - 2 * ls);
+  memcpy(soft, llr, liftN);
+
+  int ret = -2;
+  for (int it = 0; it < 2 * max_nof_iter && ret == -2; it++) {
+    for (int l = 0; l < n_layers; l++) { /* ldpc_dec_c_flood.c:205-229 + :366-391 */
+      int8_t* tc = c2v + (size_t)l * W;
+      int8_t* tv = v2c + (size_t)l * W;
+      for (int i = 0; i < hrrN + (l >= 4 ? ls : 0); i++) {
+        int8_t x = (i < hrrN) ? soft[i] : soft[hrrN + (l - 4) * ls + (i - hrrN)];
+        if (x >= 127) {
+          tv[i] = 127;
+        } else if (x <= -127) {
+          tv[i] = -127;
+        } else {
+          long t = (long)x - tc[i];
+          tv[i]  = (int8_t)(t > 63 ? 63 : (t < -63 ? -63 : t));
+        }
+      }
+    }
+    for (int l = 0; l < n_layers; l++) { /* :231-302 */
+      int8_t* tc = c2v + (size_t)l * W;
+      int8_t* tv = v2c + (size_t)l * W;
+      for (int i = 0; i < ls; i++) {
+        prod[i]    = 1;
+        minv[i][0] = minv[i][1] = INT8_MAX;
+      }
+      for (int e = g->row_start[l]; e < g->row_start[l + 1]; e++) {
+        int base = g->col[e] * ls;
+        base     = base <= hrrN ? base : hrrN;
+        for (int j = 0; j < ls; j++) {
+          int    index  = (j + ls - g->shift[e]) % ls;
+          int    iv     = base + j;
+          int8_t a      = (int8_t)abs(tv[iv]);
+          int    is_min = a < minv[index][0];
+          minv[index][1] = (a >= minv[index][1]) ? minv[index][1] : (is_min ? minv[index][0] : a);
+          minv[index][0] = is_min ? a : minv[index][0];
+          min_idx[index] = is_min ? iv : min_idx[index];
+          prod[index] *= (tv[iv] >= 0) ? 1 : -1;
+        }
+      }
+      for (int e = g->row_start[l]; e < g->row_start[l + 1]; e++) {
+        int base = g->col[e] * ls;
+        base     = base <= hrrN ? base : hrrN;
+        for (int j = 0; j < ls; j++) {
+          int index = (j + ls - g->shift[e]) % ls;
+          int iv    = base + j;
+          tc[iv]    = (iv != min_idx[index]) ? minv[index][0] : minv[index][1];
+          tc[iv]    = (int8_t)(tc[iv] * sf / 100);
+          tc[iv]    = (int8_t)(tc[iv] * (prod[index] * ((tv[iv] >= 0) ? 1 : -1)));
+        }
+      }
+    }
+    memcpy(soft, llr, liftN); /* :304-349 */
+    for (int l = 0; l < bgM; l++) {
+      const int8_t* tc = c2v + (size_t)l * W;
+      for (int e = g->row_start[l]; e < g->row_start[l + 1]; e++) {
+        int ext = g->col[e] * ls;
+        for (int j = 0; j < ls; j++) {
+          int  ib = ext + j;
+          int  ic = (ext <= hrrN) ? ib : hrrN + j;
+          long t  = (long)tc[ic] + soft[ib];
+          if (t > 63) {
+            t = INT8_MAX;
+          }
+          if (t < -63) {
+            t = -INT8_MAX;
+          }
+          soft[ib] = (int8_t)t;
+        }
+      }
+    }
+    if (crc_order > 0) {
+      for (int i = 0; i < liftK; i++) {
+        message[i] = (soft[i] < 0);
+      }
+      uint32_t c1 = orc_crc_bits(crc_poly, crc_order, message, liftK - crc_order);
+      uint32_t c2 = pack_bits(&message[liftK - crc_order], crc_order);
+      if (c1 == c2) {
+        ret = it + 1;
+      }
+    }
+  }
+  if (ret == -2) {
+    if (crc_order > 0) {
+      ret = 0;
+    } else {
+      for (int i = 0; i < liftK; i++) {
+        message[i] = (soft[i] < 0);
+      }
+      ret = max_nof_iter;
+    }
+  }
+  if (soft_out) {
+    memcpy(soft_out, soft, liftN);
+  }
+  free(llr);
+  free(soft);
+  free(c2v);
+  free(v2c);
+  free(minv);
+  free(min_idx);
+  free(prod);
+  return ret;
+}

@@ -118,6 +118,8 @@ class LdpcBatch:
         self.bg, self.Z = int(bg), int(ls)
         self.bgN, self.bgK = (68, 22) if bg == capi.BG1 else (52, 10)
         self.max_iter = int(max_nof_iter) if max_nof_iter else 10
+        if dec_type in (capi.LDPC_C_FLOOD, capi.LDPC_C_AVX2_FLOOD, capi.LDPC_C_AVX512_FLOOD):
+            self.max_iter *= 2  # the flooded schedule runs twice the iterations (ldpc_decoder.c:136)
         self.dtype = {capi.LDPC_F: np.float32, capi.LDPC_S: np.int16}.get(dec_type, np.int8)
         self._h = C.c_void_p()
         capi.check(lib().srsran_hip_ldpc_batch_create_typed(C.byref(self._h), self.bg, self.Z, scaling_fctr, max_nof_iter,

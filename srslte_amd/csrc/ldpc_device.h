@@ -29,6 +29,11 @@ struct Params {
   float           sf_f;     // scaling factor of the float decoder
   void*           c2v_ws;   // LDPC_MAX_SLOTS x cpb x n_edges x Z check-to-variable messages (HBM, L2 / Infinity Cache resident)
   void*           soft_out; // optional: n_cw x bgN*Z a-posteriori soft bits (parity aid)
+  // flooded schedule (int8 only): edges of every variable node in row order over ALL rows; word = edge index | shift << 16
+  int             flood;
+  int             n_col_edges;
+  const int*      col_start; // bgN + 1
+  const int*      col_edges;
 };
 
 #define LDPC_MAX_SLOTS 4096 // resident workgroup slots (256 CUs x up to 4); each owns one c2v slab per code word it holds

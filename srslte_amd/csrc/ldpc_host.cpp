@@ -88,6 +88,9 @@ struct srsran_hip_ldpc_batch {
   int      sf       = 0;
   float    sf_f     = 0.f;
   int      dtype    = ldpc::DT_I8; // message type: int8 (ldpc_dec_c.c), int16 (ldpc_dec_s.c) or float (ldpc_dec_f.c)
+  bool     flood    = false;       // flooded schedule (ldpc_dec_c_flood.c), int8 only
+  int*     d_col_start = nullptr;
+  int*     d_col_edges = nullptr;
   void*    d_c2v    = nullptr;     // int16 / float: check-to-variable messages, max_cw x E x Z
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
@@ -108,7 +111,8 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   if (!hh) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  int dtype;
+  int  dtype;
+  bool flood = false;
   switch (type) {
     case SRSRAN_LDPC_DECODER_F:
       dtype = ldpc::DT_F32;
@@ -121,8 +125,16 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
     case SRSRAN_LDPC_DECODER_C_AVX512:
       dtype = ldpc::DT_I8; // one family: identical results in the reference
       break;
+    case SRSRAN_LDPC_DECODER_C_FLOOD:
+    case SRSRAN_LDPC_DECODER_C_AVX2_FLOOD:
+    case SRSRAN_LDPC_DECODER_C_AVX512_FLOOD:
+      // the flooded schedule, as the scalar ldpc_dec_c_flood.c computes it (the reference's AVX2 "long" flooded decoder
+      // differs from its own scalar one on shortened code words; the scalar one is followed)
+      dtype = ldpc::DT_I8;
+      flood = true;
+      break;
     default:
-      set_error("LDPC decoder type %d (flooded schedule) is not implemented in the HIP engine", (int)type);
+      set_error("LDPC decoder type %d does not exist", (int)type);
       return SRSRAN_ERROR_INVALID_INPUTS;
   }
   *hh = nullptr;
@@ -150,6 +162,7 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   h->sf       = (int)(scaling_fctr * 100);             // ldpc_dec_c.c:150 (float * int, truncated)
   h->sf_f     = scaling_fctr;
   h->dtype    = dtype;
+  h->flood    = flood;
   h->max_cw   = max_nof_cw;
   std::vector<uint8_t>  col(d.E);
   std::vector<uint16_t> shift(d.E);
@@ -173,6 +186,23 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   PHY_HIP_CHECK(hipMalloc(&h->d_edges, d.E * sizeof(int)), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpy(h->d_edges, ed.data(), d.E * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  if (flood) {
+    // edges of every variable node in row order (update_ldpc_soft_bits_c_flood walks the rows, ldpc_dec_c_flood.c:322-346)
+    std::vector<int> cs(d.N + 1, 0), ce;
+    for (int v = 0; v < d.N; v++) {
+      cs[v] = (int)ce.size();
+      for (int e = 0; e < d.E; e++) {
+        if (col[e] == v) {
+          ce.push_back(e | ((int)shift[e] << 16));
+        }
+      }
+    }
+    cs[d.N] = (int)ce.size();
+    PHY_HIP_CHECK(hipMalloc(&h->d_col_start, cs.size() * sizeof(int)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_col_edges, ce.size() * sizeof(int)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_col_start, cs.data(), cs.size() * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpy(h->d_col_edges, ce.data(), ce.size() * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  }
   {
     // one slab of check-to-variable messages per resident workgroup slot and code word it holds (<= 256 / Z words)
     const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
@@ -192,6 +222,8 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
   }
   hipFree(h->d_row_start);
   hipFree(h->d_edges);
+  hipFree(h->d_col_start);
+  hipFree(h->d_col_edges);
   hipFree(h->d_c2v);
   delete h;
 }
@@ -270,6 +302,10 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.sf_f       = h->sf_f;
   p.c2v_ws     = h->d_c2v;
   p.soft_out   = d_soft;
+  p.flood      = h->flood ? 1 : 0;
+  p.n_col_edges = h->E;
+  p.col_start  = h->d_col_start;
+  p.col_edges  = h->d_col_edges;
   p.cpb        = Z <= 128 ? (int)(256 / Z) : 1;
   // keep the workgroup's LDS slab under 64 KB when several words share it
   while (p.cpb > 1 && ldpc::lds_bytes(p) > 64 * 1024) {
@@ -286,6 +322,7 @@ struct LdpcCtx {
   srsran_hip_ldpc_batch_t* b      = nullptr;
   hipStream_t              stream = nullptr;
   size_t                   esz    = 1;       // bytes per LLR (1 / 2 / 4)
+  uint32_t                 n_iter = 0;       // iterations the device runs: max_nof_iter, twice that for the flooded schedule
   int8_t*                  d_llr  = nullptr;
   uint8_t*                 d_msg  = nullptr;
   uint8_t*                 d_iter = nullptr;
@@ -376,9 +413,9 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   }
   // CRC early stop (ldpc_decoder.c:87-99): the device ran every iteration and kept each iteration's
   // hard decisions; the first one whose CRC matches is what the reference would have returned.
-  PHY_HIP_CHECK(hipMemcpyAsync(c->h_iter, c->d_iter, (size_t)msg_bytes * q->max_nof_iter, hipMemcpyDeviceToHost, c->stream), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_iter, c->d_iter, (size_t)msg_bytes * c->n_iter, hipMemcpyDeviceToHost, c->stream), -1);
   PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
-  for (uint32_t it = 0; it < q->max_nof_iter; it++) {
+  for (uint32_t it = 0; it < c->n_iter; it++) {
     const uint8_t* pk = c->h_iter + (size_t)it * msg_bytes;
     for (uint32_t i = 0; i < liftK; i++) {
       message[i] = (pk[i >> 3] >> (7 - (i & 7))) & 1;
@@ -410,7 +447,8 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
     fprintf(stderr, "Base Graph BG%d does not exist\n", args->bg + 1);
     return -1;
   }
-  size_t esz = 1;
+  size_t esz   = 1;
+  bool   flood = false;
   switch (args->type) {
     case SRSRAN_LDPC_DECODER_F:
       esz = 4;
@@ -422,9 +460,13 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
     case SRSRAN_LDPC_DECODER_C_AVX2:
     case SRSRAN_LDPC_DECODER_C_AVX512:
       break; // one family: int8 layered min-sum, identical results in the reference
+    case SRSRAN_LDPC_DECODER_C_FLOOD:
+    case SRSRAN_LDPC_DECODER_C_AVX2_FLOOD:
+    case SRSRAN_LDPC_DECODER_C_AVX512_FLOOD:
+      flood = true; // runs 2 * max_nof_iter iterations (ldpc_decoder.c:136)
+      break;
     default:
-      fprintf(stderr, "[srsran_phy_hip] LDPC decoder type %d (flooded schedule) is not implemented in the HIP engine\n", args->type);
-      return -1;
+      return -1; // ldpc_decoder.c:644-646
   }
   memset(q, 0, sizeof(*q));
   q->bg           = args->bg;
@@ -457,6 +499,7 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
   q->ptr  = c;
   q->free = ldpc_ctx_free;
   c->esz  = esz;
+  c->n_iter = (flood ? 2u : 1u) * q->max_nof_iter;
   // one decode entry point per object, as init_f / init_s / init_c register them (ldpc_decoder.c:170-260)
   if (esz == 4) {
     q->decode_f = ldpc_decode_f;
@@ -469,9 +512,9 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
   bool ok = srsran_hip_ldpc_batch_create_typed(&c->b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, 1, args->type) == SRSRAN_SUCCESS &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipMalloc(&c->d_llr, n_llr * esz) == hipSuccess && hipMalloc(&c->d_msg, q->liftK) == hipSuccess &&
-            hipMalloc(&c->d_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess &&
+            hipMalloc(&c->d_iter, (size_t)msg_bytes * c->n_iter) == hipSuccess &&
             hipHostMalloc(&c->h_llr, n_llr * esz) == hipSuccess && hipHostMalloc(&c->h_msg, q->liftK) == hipSuccess &&
-            hipHostMalloc(&c->h_iter, (size_t)msg_bytes * q->max_nof_iter) == hipSuccess;
+            hipHostMalloc(&c->h_iter, (size_t)msg_bytes * c->n_iter) == hipSuccess;
   if (!ok) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder_init: %s\n", get_error());
     srsran_ldpc_decoder_free(q);

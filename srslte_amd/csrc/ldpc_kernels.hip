@@ -107,7 +107,9 @@ struct PolF {
 // so that a layer costs two memory round trips, not two per edge.
 // c2v: the slab of this workgroup (wave-uniform pointer, so that the accesses take the scalar-base form with a 32-bit
 // vector offset); coff: this lane's offset inside one edge row of the slab.
-template <int DEG, class POL>
+// FLOOD: flooded schedule (ldpc_dec_c_flood.c): the messages are updated, the soft bits are left alone (they are rebuilt from the
+// channel LLRs once per iteration, see the kernel).
+template <int DEG, class POL, bool FLOOD>
 __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c2v, uint32_t coff, int my_edge, int e0, int c, int Z, int sf,
                                       float sf_f, bool active)
 {
@@ -161,7 +163,9 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
       const int m   = (sgn ^ v[i]) >> 31; // all ones when the product of the OTHER signs is negative
       const int cn  = (mag ^ m) - m;
       c2v[row0 + (uint32_t)i * (uint32_t)Z + coff] = (T)cn;
-      *reinterpret_cast<TS*>(sbase + idx[i])       = (TS)POL::soft(cn, v[i]);
+      if (!FLOOD) {
+        *reinterpret_cast<TS*>(sbase + idx[i]) = (TS)POL::soft(cn, v[i]);
+      }
     }
     return;
   }
@@ -192,11 +196,13 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
     const bool sneg = neg ^ POL::neg(v[i]); // sign = product of all signs * own sign (v >= 0 counts as +)
     const A    cn   = sneg ? POL::negate(mag) : mag;
     c2v[row0 + (uint32_t)i * (uint32_t)Z + coff] = (T)cn;
-    *reinterpret_cast<TS*>(sbase + idx[i])       = (TS)POL::soft(cn, v[i]);
+    if (!FLOOD) {
+      *reinterpret_cast<TS*>(sbase + idx[i]) = (TS)POL::soft(cn, v[i]);
+    }
   }
 }
 
-template <class POL>
+template <class POL, bool FLOOD>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
 {
   typedef typename POL::T  T;
@@ -220,6 +226,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
   int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw * sizeof(TS) + 15) & ~(size_t)15));
   for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
     graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
+  }
+  // flooded schedule: the edges of every variable node in row order (all bgM rows), behind the row description
+  int* col_start = graph + 48 + p.n_edges;
+  int* col_edges = col_start + 72;
+  if (FLOOD) {
+    for (int i = t; i < 72 + p.n_col_edges; i += blockDim.x) {
+      col_start[i] = i < 72 ? (i <= p.bgN ? p.col_start[i] : 0) : p.col_edges[i - 72];
+    }
   }
   const int      sf        = p.sf;
   const float    sf_f      = p.sf_f;
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
   int       e0n  = __builtin_amdgcn_readfirstlane(row_start[0]);
   int       degn = __builtin_amdgcn_readfirstlane(row_start[1]) - e0n;
   int       edgn = edges[e0n + (lane < degn ? lane : 0)];
-  for (int it = 0; it < p.max_iter; it++) {
+  const int n_iter = FLOOD ? 2 * p.max_iter : p.max_iter; // ldpc_decoder.c:136
+  for (int it = 0; it < n_iter; it++) {
     for (int l = 0; l < p.n_layers; l++) {
       // wave-uniform by construction; readfirstlane tells the compiler so (scalar switch, scalar addressing)
       const int e0 = e0n, deg = degn, my_edge = edgn;
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
       switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer<D, POL>(soft, c2v, coff, my_edge, e0, c, Z, sf, sf_f, active);                                                     \
+    layer<D, POL, FLOOD>(soft, c2v, coff, my_edge, e0, c, Z, sf, sf_f, active);                                                     \
     break;
         LDPC_CASE(1)
         LDPC_CASE(2)
@@ -284,12 +299,38 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
         default:
           break; // no such row degree in BG1/BG2 (host checks)
       }
+      if (!FLOOD) {
+        __syncthreads(); // the next row reads the soft bits this one wrote
+      }
+    }
+    if (FLOOD) {
+      // update_ldpc_soft_bits_c_flood (ldpc_dec_c_flood.c:304-349): soft = channel LLR, then the messages of ALL rows are added in
+      // row order with the saturation after every addition (rows that were not decoded contribute zero; the saturation
+      // still applies).  Lane = position inside the lifted variable node.
+      __syncthreads(); // all messages of this iteration are written
+      if (active) {
+        const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cw * p.llr_stride;
+        for (int v = 0; v < p.bgN; v++) {
+          typename POL::A acc = v < 2 ? 0 : (typename POL::A)llr[(v - 2) * Z + c];
+          for (int ce = col_start[v]; ce < col_start[v + 1]; ce++) {
+            const int w = col_edges[ce], e = w & 0xffff;
+            typename POL::A m = 0;
+            if (e < p.n_edges) {
+              int ci = c - (w >> 16);
+              ci += ci < 0 ? Z : 0;
+              m = (typename POL::A)c2v[(uint32_t)e * (uint32_t)Z + (coff - (uint32_t)c) + (uint32_t)ci];
+            }
+            acc = POL::soft(m, acc);
+          }
+          soft[v * Z + c] = (TS)acc;
+        }
+      }
       __syncthreads();
     }
     if (p.iter_msgs) {
       // hard decisions of this iteration, packed MSB first (for the host-side CRC early stop)
       if (active) {
-        uint8_t* dst = p.iter_msgs + ((size_t)cw * p.max_iter + it) * msg_bytes;
+        uint8_t* dst = p.iter_msgs + ((size_t)cw * n_iter + it) * msg_bytes;
         for (int b = c; b < msg_bytes; b += Z) {
           uint32_t byte = 0;
           for (int k = 0; k < 8; k++) {
@@ -357,16 +398,16 @@ int grid_slots(const Params& p)
 size_t lds_bytes(const Params& p)
 {
   const size_t per_cw = (size_t)p.bgN * p.Z * (p.dtype == DT_F32 ? 4 : 2); // soft bits: int16 (int8 and int16 decoders) or float
-  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges) * sizeof(int);
+  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges + (p.flood ? 72 + (size_t)p.n_col_edges : 0)) * sizeof(int);
 }
 
-template <class POL>
+template <class POL, bool FLOOD>
 static hipError_t launch_pol(const Params& p, hipStream_t stream)
 {
   const size_t lds = lds_bytes(p);
   static bool  attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel<POL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel<POL, FLOOD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       return e;
@@ -376,7 +417,7 @@ static hipError_t launch_pol(const Params& p, hipStream_t stream)
   int threads = p.cpb * p.Z;
   threads     = ((threads + 63) / 64) * 64;
   dim3 grid(grid_slots(p));
-  hipLaunchKernelGGL(ldpc_layered_kernel<POL>, grid, dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL((ldpc_layered_kernel<POL, FLOOD>), grid, dim3(threads), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -384,11 +425,11 @@ hipError_t launch(const Params& p, hipStream_t stream)
 {
   switch (p.dtype) {
     case DT_I8:
-      return launch_pol<Pol8>(p, stream);
+      return p.flood ? launch_pol<Pol8, true>(p, stream) : launch_pol<Pol8, false>(p, stream);
     case DT_I16:
-      return launch_pol<Pol16>(p, stream);
+      return p.flood ? hipErrorInvalidValue : launch_pol<Pol16, false>(p, stream);
     case DT_F32:
-      return launch_pol<PolF>(p, stream);
+      return p.flood ? hipErrorInvalidValue : launch_pol<PolF, false>(p, stream);
     default:
       return hipErrorInvalidValue;
   }

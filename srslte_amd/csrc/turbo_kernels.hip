@@ -522,28 +522,30 @@ __device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, 
 {
   constexpr int  NB  = 2 * LPC;
   const int      cbw = lane / LPC;
-  uint32_t*      dst[3] = {S, P0, P1};
   uint4*         st4 = reinterpret_cast<uint4*>(stage);
+  // one stream (systematic / parity 0 / parity 1) of one 8-step block: two 16-byte pieces per lane through the staging image
+  auto put = [&](uint32_t* dst, uint32_t b, const uint4& lo, const uint4& hi) {
+    st4[cbw * 2 * LPC + pl]       = lo;
+    st4[cbw * 2 * LPC + LPC + pl] = hi;
+    uint32_t r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t w = stage[cbw * 8 * LPC + j * LPC + pl];
+      r[j] = (uint32_t)(uint16_t)AR::conv_in((short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((short)(w >> 16)) << 16);
+    }
+    store_block(dst, b * 64 + lane, r);
+  };
   for (uint32_t b = 0; b < nblk; b++) {
-    uint4 v[3][2];
-#pragma unroll
-    for (int a3 = 0; a3 < 3; a3++) {
-      const uint4* q = reinterpret_cast<const uint4*>(in + (size_t)a3 * (K + 32) + (size_t)b * 8 * NB);
-      v[a3][0]       = q[pl];
-      v[a3][1]       = q[LPC + pl];
-    }
-#pragma unroll
-    for (int a3 = 0; a3 < 3; a3++) {
-      st4[cbw * 2 * LPC + pl]       = v[a3][0];
-      st4[cbw * 2 * LPC + LPC + pl] = v[a3][1];
-      uint32_t r[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const uint32_t w = stage[cbw * 8 * LPC + j * LPC + pl];
-        r[j] = (uint32_t)(uint16_t)AR::conv_in((short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((short)(w >> 16)) << 16);
-      }
-      store_block(dst[a3], b * 64 + lane, r);
-    }
+    // all six loads of the block are issued before the first use (named registers: an indexed local array ends up in scratch)
+    const uint4* q0 = reinterpret_cast<const uint4*>(in + (size_t)b * 8 * NB);
+    const uint4* q1 = reinterpret_cast<const uint4*>(in + (size_t)(K + 32) + (size_t)b * 8 * NB);
+    const uint4* q2 = reinterpret_cast<const uint4*>(in + (size_t)2 * (K + 32) + (size_t)b * 8 * NB);
+    const uint4  s_lo = q0[pl], s_hi = q0[LPC + pl];
+    const uint4  y_lo = q1[pl], y_hi = q1[LPC + pl];
+    const uint4  z_lo = q2[pl], z_hi = q2[LPC + pl];
+    put(S, b, s_lo, s_hi);
+    put(P0, b, y_lo, y_hi);
+    put(P1, b, z_lo, z_hi);
   }
   if (pl == 0) {
     const uint32_t tb = 3 * (K + 32);

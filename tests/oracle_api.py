@@ -533,3 +533,16 @@ def predecoding_single(y, h, scaling, noise_estimate, want_csi=False):
     f.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_float, C.c_float]
     f(P(y), P(h), P(x), P(csi) if want_csi else None, y.size, scaling, noise_estimate)
     return (x, csi) if want_csi else x
+
+
+def ldpc_decode_flood(bg, ls, llr, scaling_fctr, max_iter, cdwd_rm_length, crc=None):
+    """orc_ldpc_decode_c_flood on one code word: returns (message bits, a-posteriori soft bits [N], return value)"""
+    g = ldpc_graph(bg, ls)
+    K, N = g.bgK * ls, g.bgN * ls
+    llr = np.ascontiguousarray(llr, np.int8)
+    out, soft = np.zeros(K, np.uint8), np.zeros(N, np.int8)
+    f = orc().orc_ldpc_decode_c_flood
+    f.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    poly, order = crc if crc else (0, 0)
+    ret = f(C.byref(g), scaling_fctr, max_iter, P(llr), P(out), cdwd_rm_length, poly, order, P(soft))
+    return out, soft, ret

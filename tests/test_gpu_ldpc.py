@@ -93,9 +93,9 @@ def test_handle_api_and_crc_early_stop(hiplib):
             assert np.array_equal(out2, ref2[0])
         lib.srsran_ldpc_decoder_free(C.byref(q))
         assert not q.ptr
-    # decoder families the HIP engine does not reproduce must be refused loudly
+    # a decoder type that does not exist (ldpc_decoder.c:644-646)
     q = capi.LdpcDecoder()
-    args = capi.LdpcDecoderArgs(capi.LDPC_C_FLOOD, 0, 16, 0.8, 10)
+    args = capi.LdpcDecoderArgs(8, 0, 16, 0.8, 10)
     assert lib.srsran_ldpc_decoder_init(C.byref(q), C.byref(args)) == -1
 
 
@@ -190,4 +190,54 @@ def test_float_and_int16_rate_matched_and_handle(hiplib, kind):
     d = S.DeviceBuffer(N * 4)
     assert lib.srsran_hip_ldpc_batch_run(b._h, d.ptr, N, d.ptr, N, 1, N, None, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
     h = C.c_void_p()
-    assert lib.srsran_hip_ldpc_batch_create_typed(C.byref(h), 0, 16, 0.8, 10, 1, capi.LDPC_C_FLOOD) == capi.SRSRAN_ERROR_INVALID_INPUTS
+    assert lib.srsran_hip_ldpc_batch_create_typed(C.byref(h), 0, 16, 0.8, 10, 1, 8) == capi.SRSRAN_ERROR_INVALID_INPUTS
+
+
+@pytest.mark.parametrize("bg,Z", [(0, 384), (1, 208), (0, 36), (1, 7), (0, 2), (1, 128), (0, 104)])
+def test_flooded_schedule(hiplib, bg, Z):
+    """SRSRAN_LDPC_DECODER_C_FLOOD (ldpc_dec_c_flood.c, ldpc_decoder.c:105-160): messages AND a-posteriori soft bits bit-exact,
+    full and shortened code words, CRC early stop through the handle"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    g = O.ldpc_graph(bg, Z)
+    K, N = g.bgK * Z, g.bgN * Z
+    n_cw = 5
+    for snr, clip, nit in ((2.0, 63, 4), (0.5, 127, 7)):
+        _, llrs = O.ldpc_llrs(bg, Z, n_cw, snr, seed=Z * 3 + bg, clip=clip)
+        for typ in (capi.LDPC_C_FLOOD, capi.LDPC_C_AVX2_FLOOD):
+            dec = S.LdpcBatch(bg, Z, 0.8, nit, n_cw, typ)
+            for rm in (N - 2 * Z, (g.bgK + 9) * Z + 3, (g.bgK + 2) * Z):
+                out, soft = dec.decode(llrs, cdwd_rm_length=rm, want_soft=True)
+                for i in range(n_cw):
+                    want, ws, ret = O.ldpc_decode_flood(bg, Z, llrs[i], 0.8, nit, rm)
+                    assert ret == nit
+                    assert np.array_equal(out[i], want), (typ, rm, i)
+                    assert np.array_equal(soft[i], ws), (typ, rm, i)
+    # handle: decode_c and decode_crc_c (iteration count of the first CRC match, out of 2 * max_nof_iter)
+    q = capi.LdpcDecoder()
+    args = capi.LdpcDecoderArgs(capi.LDPC_C_FLOOD, bg, Z, 0.8, 6)
+    assert lib.srsran_ldpc_decoder_init(C.byref(q), C.byref(args)) == 0
+    msg = np.zeros(K, np.uint8)
+    assert lib.srsran_ldpc_decoder_decode_c(C.byref(q), O.P(llrs[0]), O.P(msg), N - 2 * Z) == 6
+    assert np.array_equal(msg, O.ldpc_decode_flood(bg, Z, llrs[0], 0.8, 6, N - 2 * Z)[0])
+    if K >= 40:
+        poly, order = 0x1800063, 24
+        crc = capi.Crc()
+        crc.polynom, crc.order = poly, order
+        rng = np.random.default_rng(Z)
+        for snr in (3.0, 0.0):
+            m = rng.integers(0, 2, K).astype(np.uint8)
+            cs = O.orc().orc_crc_bits(poly, order, O.P(m), K - order)
+            m[K - order:] = [(cs >> (order - 1 - i)) & 1 for i in range(order)]
+            cw = np.zeros(N - 2 * Z, np.uint8)
+            assert O.orc().orc_ldpc_encode(C.byref(g), O.P(m), O.P(cw)) == 0
+            sigma = 10 ** (-snr / 20)
+            llr = np.clip(np.round(((1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.size)) * 8 / sigma ** 2), -63, 63).astype(np.int8)
+            want, _, ret = O.ldpc_decode_flood(bg, Z, llr, 0.8, 6, N - 2 * Z, crc=(poly, order))
+            got = lib.srsran_ldpc_decoder_decode_crc_c(C.byref(q), O.P(llr), O.P(msg), N - 2 * Z, C.byref(crc))
+            assert got == ret, (bg, Z, snr, got, ret)
+            if ret:
+                assert np.array_equal(msg, want)
+    lib.srsran_ldpc_decoder_free(C.byref(q))

@@ -125,6 +125,17 @@ def test_transport_block_transmit_chain_reference_outputs():
         assert np.array_equal(np.packbits(e)[:n], d[key + "_e"][:n]), key
 
 
+def test_ldpc_flooded_reference_outputs():
+    """SRSRAN_LDPC_DECODER_C_FLOOD of the compiled reference (scalar flooded schedule, 2 x max_nof_iter iterations)"""
+    d = np.load(os.path.join(G, "ldpc_flood_ref.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        bg, Z, nit, rm, sf100 = [int(v) for v in d[key + "_par"]]
+        for i in range(2):
+            out, _, ret = O.ldpc_decode_flood(bg, Z, d[key + "_llr"][i], sf100 / 100.0, nit, rm)
+            assert ret == nit and np.array_equal(np.packbits(out), d[key + "_out"][i]), key
+
+
 def test_sync_glue_reference_outputs():
     """srsran_cfo_correct (table look-up with a float phase accumulator) and srsran_cp_synch of the compiled reference"""
     d = np.load(os.path.join(G, "syncglue_ref.npz"))

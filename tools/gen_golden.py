@@ -20,6 +20,7 @@ No reference source text is stored.
                                outputs and srsran_ldpc_rm_rx_{c,s,f} soft buffers (as CRC32) on stored inputs
   tests/golden/sch_tx_ref.npz  transmit side of transport blocks as encode_tb_off (sch.c:238-345) chains the reference's
                                srsran_crc_*, srsran_tcod_encode_lut and srsran_rm_turbo_tx_lut: payload bytes -> packed e bits
+  tests/golden/ldpc_flood_ref.npz reference SRSRAN_LDPC_DECODER_C_FLOOD (scalar flooded schedule) outputs on seeded LLRs
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -272,6 +273,34 @@ def ldpc():
     print("ldpc_examples.npz", os.path.getsize(os.path.join(OUT, "ldpc_examples.npz")))
 
 
+def ldpc_flood():
+    class Args(C.Structure):
+        _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_int)]
+
+    d, cases = {}, []
+    for bg, Z, snr, nit, sf in ((0, 384, 2.0, 5, 0.8), (0, 384, 0.5, 10, 0.75), (1, 208, 1.0, 6, 0.8), (0, 36, 3.0, 4, 1.0), (1, 7, 2.0, 8, 0.6),
+                                (0, 2, 4.0, 10, 0.8), (1, 128, 0.0, 6, 0.8)):
+        g = O.ldpc_graph(bg, Z)
+        K, N = g.bgK * Z, g.bgN * Z
+        for clip in (63, 127):
+            _, llrs = O.ldpc_llrs(bg, Z, 2, snr, seed=Z + bg, clip=clip)
+            for rm in (N - 2 * Z, (g.bgK + 9) * Z + 3):
+                dec = C.create_string_buffer(4096)
+                a = Args(3, bg, Z, sf, nit)  # SRSRAN_LDPC_DECODER_C_FLOOD
+                assert ref.srsran_ldpc_decoder_init(dec, C.byref(a)) == 0
+                o = np.zeros((2, K), np.uint8)
+                for i in range(2):
+                    assert ref.srsran_ldpc_decoder_decode_c(dec, P(llrs[i]), P(o[i]), rm) == nit
+                ref.srsran_ldpc_decoder_free(dec)
+                key = "bg%d_z%d_it%d_c%d_rm%d" % (bg, Z, nit, clip, rm)
+                d[key + "_llr"], d[key + "_out"] = llrs, np.packbits(o, axis=1)
+                d[key + "_par"] = np.array([bg, Z, nit, rm, int(round(sf * 100))], dtype=np.int32)
+                cases.append(key)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "ldpc_flood_ref.npz"), **d)
+    print("ldpc_flood_ref.npz", os.path.getsize(os.path.join(OUT, "ldpc_flood_ref.npz")))
+
+
 def ldpc_tx():
     d = {}
     rng = np.random.default_rng(77)
@@ -437,6 +466,6 @@ def modem():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood}[name]()

@@ -146,7 +146,48 @@ int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out,
   return SRSRAN_SUCCESS;
 }
 
-// host-pointer form: one code block
+// host-pointer form: one code block.  Staging buffers and the stream are kept per calling thread (the reference's function
+// is stateless; allocating per call would dominate it).
+struct HostStage {
+  hipStream_t st   = nullptr;
+  void*       d_in = nullptr;
+  void*       d_out = nullptr;
+  size_t      cap_in = 0, cap_out = 0;
+  bool        tried = false;
+  ~HostStage()
+  {
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (st) {
+      (void)hipStreamDestroy(st);
+    }
+  }
+  bool ready()
+  {
+    if (!tried) {
+      tried = true;
+      if (device_available() && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        st = nullptr;
+      }
+    }
+    return st != nullptr;
+  }
+  static bool grow(void** p, size_t* cap, size_t need)
+  {
+    if (need <= *cap) {
+      return true;
+    }
+    (void)hipFree(*p);
+    *p   = nullptr;
+    *cap = 0;
+    if (hipMalloc(p, need + 256) != hipSuccess) {
+      return false;
+    }
+    *cap = need + 256;
+    return true;
+  }
+};
+
 template <typename T>
 int rx_host(const T* input, T* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv, uint32_t nof_sb)
 {
@@ -154,28 +195,29 @@ int rx_host(const T* input, T* output, uint32_t in_len, uint32_t cb_idx, uint32_
     printf("Invalid inputs rv_idx=%d, cb_idx=%d\n", rv, cb_idx);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  if (!device_available()) {
+  static thread_local HostStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_rx_lut: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;
+  }
+  if (in_len == 0) {
+    return SRSRAN_SUCCESS;
   }
   const uint32_t K = (uint32_t)srsran_cbsegm_cbsize(cb_idx);
   const size_t   n_out = nof_sb ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
-  T *            d_in = nullptr, *d_out = nullptr;
-  int            rc   = SRSRAN_ERROR;
-  if (hipMalloc(&d_in, (in_len ? in_len : 1) * sizeof(T)) == hipSuccess && hipMalloc(&d_out, n_out * sizeof(T)) == hipSuccess &&
-      hipMemcpy(d_in, input, in_len * sizeof(T), hipMemcpyHostToDevice) == hipSuccess &&
-      hipMemcpy(d_out, output, n_out * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) {
-    rc = in_len ? rx_batch(d_in, in_len, in_len, d_out, (uint32_t)n_out, 1, K, rv, nof_sb, sizeof(T) == 1, nullptr) : SRSRAN_SUCCESS;
-    if (rc == SRSRAN_SUCCESS && (hipDeviceSynchronize() != hipSuccess ||
-                                 hipMemcpy(output, d_out, n_out * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess)) {
-      rc = SRSRAN_ERROR;
-    }
+  if (!HostStage::grow(&s.d_in, &s.cap_in, in_len * sizeof(T)) || !HostStage::grow(&s.d_out, &s.cap_out, n_out * sizeof(T))) {
+    return SRSRAN_ERROR;
   }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
+  PHY_HIP_CHECK(hipMemcpyAsync(s.d_in, input, in_len * sizeof(T), hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(s.d_out, output, n_out * sizeof(T), hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  const int rc = rx_batch(s.d_in, in_len, in_len, s.d_out, (uint32_t)n_out, 1, K, rv, nof_sb, sizeof(T) == 1, s.st);
   if (rc != SRSRAN_SUCCESS) {
     fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_rx_lut: %s\n", get_error());
+    return rc;
   }
-  return rc;
+  PHY_HIP_CHECK(hipMemcpyAsync(output, s.d_out, n_out * sizeof(T), hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  return SRSRAN_SUCCESS;
 }
 
 } // namespace

@@ -68,6 +68,13 @@ SRSRAN_API int  srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** h, 
 SRSRAN_API int  srsran_hip_ldpc_batch_run_typed(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride,
                                                 uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
                                                 uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* stream);
+/* srsran_ldpc_decoder_decode_crc_c (ldpc_decoder.c:87-99,682-685) for a batch: int8 decoders only (layered or flooded).  Every
+ * code word leaves the iteration loop at the first iteration whose hard decisions pass the CRC (generator crc_polynom of
+ * crc_order bits over the first liftK - crc_order bits, compared with the last crc_order); d_nof_iterations[i] receives that
+ * iteration count, 0 when it never matched (the reference's return value). */
+SRSRAN_API int  srsran_hip_ldpc_batch_run_crc(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                                              uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint32_t crc_polynom,
+                                              uint32_t crc_order, int32_t* d_nof_iterations, void* stream);
 SRSRAN_API void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h);
 /* d_llrs   : n_cw x (N-2Z) int8 (only the first cdwd_rm_length... all N-2Z are read, as the reference does),
  *            `llr_stride` bytes apart;  d_message: n_cw x K bytes, one bit per byte, `msg_stride` apart.

@@ -233,6 +233,7 @@ def lib():
             "srsran_hip_ldpc_batch_create": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32]),
             "srsran_hip_ldpc_batch_create_typed": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32, i32]),
             "srsran_hip_ldpc_batch_run_typed": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
+            "srsran_hip_ldpc_batch_run_crc": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_free": (None, [vp]),
             "srsran_hip_ldpc_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),

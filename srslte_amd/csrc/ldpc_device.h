@@ -34,6 +34,12 @@ struct Params {
   int             n_col_edges;
   const int*      col_start; // bgN + 1
   const int*      col_edges;
+  // CRC early stop (decode_crc_c): generator without / with its top bit, order (0: off), x^((Z-1-c) bgK) mod g per lane,
+  // iterations per code word out (0 = no match)
+  uint32_t        crc_poly;
+  int             crc_order;
+  const uint32_t* crc_mult;
+  int*            n_iter_out;
 };
 
 #define LDPC_MAX_SLOTS 4096 // resident workgroup slots (256 CUs x up to 4); each owns one c2v slab per code word it holds

@@ -91,6 +91,9 @@ struct srsran_hip_ldpc_batch {
   bool     flood    = false;       // flooded schedule (ldpc_dec_c_flood.c), int8 only
   int*     d_col_start = nullptr;
   int*     d_col_edges = nullptr;
+  uint32_t* d_crc_mult = nullptr; // x^((Z-1-c) bgK) mod g for the generator below (CRC early stop)
+  uint32_t crc_poly = 0;
+  int      crc_order = 0;
   void*    d_c2v    = nullptr;     // int16 / float: check-to-variable messages, max_cw x E x Z
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
@@ -224,13 +227,14 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
   hipFree(h->d_edges);
   hipFree(h->d_col_start);
   hipFree(h->d_col_edges);
+  hipFree(h->d_crc_mult);
   hipFree(h->d_c2v);
   delete h;
 }
 
 static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
-                          void* stream);
+                          void* stream, uint32_t crc_poly = 0, int crc_order = 0, int* d_n_iter = nullptr);
 
 extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride,
                                          uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
@@ -260,7 +264,7 @@ extern "C" SRSRAN_API int srsran_hip_ldpc_batch_run_dbg(srsran_hip_ldpc_batch_t*
 
 static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
-                          void* stream)
+                          void* stream, uint32_t crc_poly, int crc_order, int* d_n_iter)
 {
   if (!h || !d_llrs || !d_message || n_cw == 0 || n_cw > (h->max_cw ? h->max_cw : 1)) {
     set_error("ldpc batch: invalid arguments");
@@ -302,6 +306,39 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.sf_f       = h->sf_f;
   p.c2v_ws     = h->d_c2v;
   p.soft_out   = d_soft;
+  p.crc_poly   = 0;
+  p.crc_order  = 0;
+  p.crc_mult   = nullptr;
+  p.n_iter_out = nullptr;
+  if (crc_order) {
+    if (crc_order < 8 || crc_order > 24 || h->dtype != ldpc::DT_I8 || !d_n_iter) {
+      set_error("ldpc batch: CRC early stop needs the int8 decoder, a generator of order 8..24 and an iteration array");
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    if (!h->d_crc_mult || h->crc_poly != crc_poly || h->crc_order != crc_order) {
+      // x^n mod g by repeated multiplication with x; lane c needs n = (Z - 1 - c) * bgK
+      const uint32_t mask = (1u << crc_order) - 1u, g = crc_poly & mask;
+      std::vector<uint32_t> m(Z);
+      uint32_t              r = 1;
+      for (int c = (int)Z - 1; c >= 0; c--) {
+        m[c] = r;
+        for (int k = 0; k < h->K; k++) {
+          r = ((r << 1) & mask) ^ (((r >> (crc_order - 1)) & 1u) ? g : 0u);
+        }
+      }
+      if (!h->d_crc_mult) {
+        PHY_HIP_CHECK(hipMalloc(&h->d_crc_mult, 384 * sizeof(uint32_t)), SRSRAN_ERROR);
+      }
+      PHY_HIP_CHECK(hipMemcpyAsync(h->d_crc_mult, m.data(), Z * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t)stream), SRSRAN_ERROR);
+      PHY_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream), SRSRAN_ERROR); // m goes out of scope
+      h->crc_poly  = crc_poly;
+      h->crc_order = crc_order;
+    }
+    p.crc_poly   = crc_poly;
+    p.crc_order  = crc_order;
+    p.crc_mult   = h->d_crc_mult;
+    p.n_iter_out = d_n_iter;
+  }
   p.flood      = h->flood ? 1 : 0;
   p.n_col_edges = h->E;
   p.col_start  = h->d_col_start;
@@ -313,6 +350,17 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   }
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_ldpc_batch_run_crc(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                                             uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint32_t crc_polynom, uint32_t crc_order,
+                                             int32_t* d_nof_iterations, void* stream)
+{
+  if (!crc_order || !d_nof_iterations) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, nullptr, nullptr, stream, crc_polynom, (int)crc_order,
+                        (int*)d_nof_iterations);
 }
 
 // ------------------------------------------------------------------------------------------------ handle ABI
@@ -401,35 +449,31 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   const uint32_t msg_bytes = (liftK + 7) / 8;
   memcpy(c->h_llr, llrs, n_llr * c->esz);
   PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr * c->esz, hipMemcpyHostToDevice, c->stream), -1);
-  if (srsran_hip_ldpc_batch_run_typed(c->b, c->d_llr, n_llr, c->d_msg, liftK, 1, cdwd_rm_length, crc ? c->d_iter : nullptr, c->stream)) {
+  if (crc) {
+    // CRC early stop on the device (ldpc_decoder.c:87-99): the kernel leaves the iteration loop at the first match and
+    // reports the iteration count (0: no match within the budget, the reference's return value as well)
+    int* d_nit = reinterpret_cast<int*>(c->d_iter);
+    if (srsran_hip_ldpc_batch_run_crc(c->b, reinterpret_cast<const int8_t*>(c->d_llr), n_llr, c->d_msg, liftK, 1, cdwd_rm_length,
+                                      (uint32_t)crc->polynom, (uint32_t)crc->order, d_nit, c->stream)) {
+      fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
+      return -1;
+    }
+    PHY_HIP_CHECK(hipMemcpyAsync(c->h_msg, c->d_msg, liftK, hipMemcpyDeviceToHost, c->stream), -1);
+    PHY_HIP_CHECK(hipMemcpyAsync(c->h_iter, d_nit, sizeof(int), hipMemcpyDeviceToHost, c->stream), -1);
+    PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
+    const int nit = *reinterpret_cast<const int*>(c->h_iter);
+    // the reference extracts the message at every iteration it checks: after a failed run `message` holds the last one
+    memcpy(message, c->h_msg, liftK);
+    return nit;
+  }
+  if (srsran_hip_ldpc_batch_run_typed(c->b, c->d_llr, n_llr, c->d_msg, liftK, 1, cdwd_rm_length, nullptr, c->stream)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
     return -1;
   }
-  if (!crc) {
-    PHY_HIP_CHECK(hipMemcpyAsync(c->h_msg, c->d_msg, liftK, hipMemcpyDeviceToHost, c->stream), -1);
-    PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
-    memcpy(message, c->h_msg, liftK);
-    return (int)q->max_nof_iter;
-  }
-  // CRC early stop (ldpc_decoder.c:87-99): the device ran every iteration and kept each iteration's
-  // hard decisions; the first one whose CRC matches is what the reference would have returned.
-  PHY_HIP_CHECK(hipMemcpyAsync(c->h_iter, c->d_iter, (size_t)msg_bytes * c->n_iter, hipMemcpyDeviceToHost, c->stream), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(c->h_msg, c->d_msg, liftK, hipMemcpyDeviceToHost, c->stream), -1);
   PHY_HIP_CHECK(hipStreamSynchronize(c->stream), -1);
-  for (uint32_t it = 0; it < c->n_iter; it++) {
-    const uint8_t* pk = c->h_iter + (size_t)it * msg_bytes;
-    for (uint32_t i = 0; i < liftK; i++) {
-      message[i] = (pk[i >> 3] >> (7 - (i & 7))) & 1;
-    }
-    uint32_t c1 = crc_bits((uint32_t)crc->polynom, crc->order, message, (int)liftK - crc->order);
-    uint32_t c2 = 0;
-    for (int i = 0; i < crc->order; i++) {
-      c2 = (c2 << 1) | (message[liftK - crc->order + i] & 1);
-    }
-    if (c1 == c2) {
-      return (int)it + 1;
-    }
-  }
-  return 0;
+  memcpy(message, c->h_msg, liftK);
+  return (int)q->max_nof_iter;
 }
 } // namespace
 

@@ -202,8 +202,9 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
   }
 }
 
-template <class POL, bool FLOOD>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
+// ES: CRC early stop (decode_crc_c), its own instantiation so that its state costs the plain decoders no registers
+template <class POL, bool FLOOD, bool ES>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(ES ? 4 : POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
 {
   typedef typename POL::T  T;
   typedef typename POL::TS TS;
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
 
   for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
   const int  cw     = cw0 + cwl;
-  const bool active = (cwl < p.cpb) && (cw < p.n_cw);
+  const bool present = (cwl < p.cpb) && (cw < p.n_cw);
+  bool       active  = present; // cleared once this code word's CRC matches (early stop): its state is then frozen
+  int        it_done = 0;
   __syncthreads(); // the previous code word's message extraction has finished reading soft[]
 
   // init_ldpc_dec_c (ldpc_dec_c.c:170-188): punctured nodes 0,1 start at 0, all c2v at 0
@@ -327,9 +330,67 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
       }
       __syncthreads();
     }
+    if (ES && p.crc_order) {
+      // CRC early stop (ldpc_decoder.c:87-99, crc.c:187-193): the check "checksum of the first liftK - order bits equals the
+      // last order bits" is the remainder of ALL liftK hard decisions being zero.  Every lane takes bgK consecutive bits,
+      // shifts its partial remainder into place with x^(bits behind it) mod g, one lane per code word folds them.
+      uint32_t* red = reinterpret_cast<uint32_t*>(col_edges + (FLOOD ? p.n_col_edges : 0));
+      const uint32_t order = (uint32_t)p.crc_order, mask = order == 32 ? 0xffffffffu : ((1u << order) - 1u), poly = p.crc_poly & mask;
+      uint32_t r = 0;
+      if (active) {
+        for (int k = 0; k < p.bgK; k++) {
+          const uint32_t bit = soft[c * p.bgK + k] < 0 ? 1u : 0u;
+          r = ((r << 1) & mask) ^ ((((r >> (order - 1)) ^ bit) & 1u) ? poly : 0u);
+        }
+        const uint32_t m = p.crc_mult[c];
+        uint32_t       q = 0;
+        for (int i = (int)order - 1; i >= 0; i--) {
+          q = ((q << 1) & mask) ^ (((q >> (order - 1)) & 1u) ? poly : 0u);
+          q ^= ((m >> i) & 1u) ? r : 0u;
+        }
+        r = q;
+      }
+      // fold the partial remainders of a code word.  One code word per workgroup (Z > 128): XOR inside each wave first, one
+      // word per wave in LDS (the workgroup's LDS budget at two workgroups per CU has no room for more); several code words
+      // per workgroup (small Z): one word per lane, folded by the first lane of each code word.
+      uint32_t total;
+      if (p.cpb == 1) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          r ^= __shfl_xor(r, off);
+        }
+        if ((t & 63) == 0) {
+          red[t >> 6] = r;
+        }
+        __syncthreads();
+        total = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
+          total ^= red[w];
+        }
+      } else {
+        red[t] = r;
+        __syncthreads();
+        if (active && c == 0) {
+          uint32_t x = 0;
+          for (int i = 0; i < Z; i++) {
+            x ^= red[t + i];
+          }
+          red[t] = x;
+        }
+        __syncthreads();
+        total = active ? red[t - c] : 1u;
+      }
+      if (active && total == 0) {
+        active  = false;
+        it_done = it + 1;
+      }
+      if (__syncthreads_and(!active)) {
+        break; // every code word of this workgroup has stopped (or was never there)
+      }
+    }
     if (p.iter_msgs) {
       // hard decisions of this iteration, packed MSB first (for the host-side CRC early stop)
-      if (active) {
+      if (present) {
         uint8_t* dst = p.iter_msgs + ((size_t)cw * n_iter + it) * msg_bytes;
         for (int b = c; b < msg_bytes; b += Z) {
           uint32_t byte = 0;
@@ -348,7 +409,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(POL::kMinWa
     }
   }
   // extract_ldpc_message_c (:323-336)
-  if (active) {
+  if (ES && present && p.n_iter_out) {
+    if (c == 0) {
+      p.n_iter_out[cw] = it_done; // iterations until the CRC matched; 0: it never did (what decode_crc_c returns)
+    }
+  }
+  if (present) {
     uint8_t* m = p.msg + (size_t)cw * p.msg_stride;
     for (int i = c; i < liftK; i += Z) {
       m[i] = soft[i] < 0;
@@ -398,17 +464,17 @@ int grid_slots(const Params& p)
 size_t lds_bytes(const Params& p)
 {
   const size_t per_cw = (size_t)p.bgN * p.Z * (p.dtype == DT_F32 ? 4 : 2); // soft bits: int16 (int8 and int16 decoders) or float
-  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges + (p.flood ? 72 + (size_t)p.n_col_edges : 0)) * sizeof(int);
+  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges + 72 + (p.flood ? (size_t)p.n_col_edges : 0) + (p.crc_order ? (p.cpb == 1 ? (size_t)16 : (size_t)((p.cpb * p.Z + 63) / 64) * 64 + 8) : 0)) * sizeof(int);
 }
 
-template <class POL, bool FLOOD>
+template <class POL, bool FLOOD, bool ES>
 static hipError_t launch_pol(const Params& p, hipStream_t stream)
 {
   const size_t lds = lds_bytes(p);
   static bool  attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel<POL, FLOOD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_layered_kernel<POL, FLOOD, ES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); // a few static words (block-wide vote) come on top
     if (e != hipSuccess) {
       return e;
     }
@@ -417,7 +483,7 @@ static hipError_t launch_pol(const Params& p, hipStream_t stream)
   int threads = p.cpb * p.Z;
   threads     = ((threads + 63) / 64) * 64;
   dim3 grid(grid_slots(p));
-  hipLaunchKernelGGL((ldpc_layered_kernel<POL, FLOOD>), grid, dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL((ldpc_layered_kernel<POL, FLOOD, ES>), grid, dim3(threads), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -425,11 +491,14 @@ hipError_t launch(const Params& p, hipStream_t stream)
 {
   switch (p.dtype) {
     case DT_I8:
-      return p.flood ? launch_pol<Pol8, true>(p, stream) : launch_pol<Pol8, false>(p, stream);
+      if (p.crc_order) {
+        return p.flood ? launch_pol<Pol8, true, true>(p, stream) : launch_pol<Pol8, false, true>(p, stream);
+      }
+      return p.flood ? launch_pol<Pol8, true, false>(p, stream) : launch_pol<Pol8, false, false>(p, stream);
     case DT_I16:
-      return p.flood ? hipErrorInvalidValue : launch_pol<Pol16, false>(p, stream);
+      return (p.flood || p.crc_order) ? hipErrorInvalidValue : launch_pol<Pol16, false, false>(p, stream);
     case DT_F32:
-      return p.flood ? hipErrorInvalidValue : launch_pol<PolF, false>(p, stream);
+      return (p.flood || p.crc_order) ? hipErrorInvalidValue : launch_pol<PolF, false, false>(p, stream);
     default:
       return hipErrorInvalidValue;
   }

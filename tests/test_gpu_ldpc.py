@@ -241,3 +241,52 @@ def test_flooded_schedule(hiplib, bg, Z):
             if ret:
                 assert np.array_equal(msg, want)
     lib.srsran_ldpc_decoder_free(C.byref(q))
+
+
+@pytest.mark.parametrize("bg,Z,typ", [(0, 384, "C"), (1, 208, "C"), (0, 36, "C"), (1, 16, "C"), (0, 7, "C"), (0, 96, "FLOOD"), (1, 30, "FLOOD")])
+def test_batch_crc_early_stop(hiplib, bg, Z, typ):
+    """srsran_hip_ldpc_batch_run_crc: per code word the iteration count of the first CRC match (0 = none) and the message the
+    reference returns, code words of very different SNR in one launch (several per workgroup for small Z)"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    g = O.ldpc_graph(bg, Z)
+    K, N = g.bgK * Z, g.bgN * Z
+    rng = np.random.default_rng(Z + bg)
+    for poly, order in ((0x1800063, 24), (0x11021, 16)):
+        if K <= order + 8:
+            continue
+        n_cw, nit = 24, 8
+        llrs = np.zeros((n_cw, N - 2 * Z), np.int8)
+        for i in range(n_cw):
+            m = rng.integers(0, 2, K).astype(np.uint8)
+            cs = O.orc().orc_crc_bits(poly, order, O.P(m), K - order)
+            m[K - order:] = [(cs >> (order - 1 - j)) & 1 for j in range(order)]
+            cw = np.zeros(N - 2 * Z, np.uint8)
+            assert O.orc().orc_ldpc_encode(C.byref(g), O.P(m), O.P(cw)) == 0
+            snr = (4.0, 1.5, 0.0, -4.0)[i % 4]
+            sigma = 10 ** (-snr / 20)
+            llrs[i] = np.clip(np.round(((1.0 - 2.0 * cw) + sigma * rng.standard_normal(cw.size)) * 8 / sigma ** 2), -63, 63).astype(np.int8)
+        flood = typ == "FLOOD"
+        dec = S.LdpcBatch(bg, Z, 0.8, nit, n_cw, capi.LDPC_C_FLOOD if flood else capi.LDPC_C_AVX2)
+        d_llr, d_msg = S.DeviceBuffer.from_numpy(llrs), S.DeviceBuffer(n_cw * K)
+        d_it = S.DeviceBuffer.from_numpy(np.full(n_cw, -1, np.int32))
+        for rm in (N - 2 * Z, (g.bgK + 12) * Z):
+            capi.check(lib.srsran_hip_ldpc_batch_run_crc(dec._h, d_llr.ptr, N - 2 * Z, d_msg.ptr, K, n_cw, rm, poly, order, d_it.ptr, None), "run_crc")
+            capi.check(lib.srsran_hip_stream_sync(None), "sync")
+            its, msg = d_it.to_numpy(np.int32, (n_cw,)), d_msg.to_numpy(np.uint8, (n_cw, K))
+            seen = set()
+            for i in range(n_cw):
+                if flood:
+                    want, _, ret = O.ldpc_decode_flood(bg, Z, llrs[i], 0.8, nit, rm, crc=(poly, order))
+                else:
+                    w, r = O.ldpc_decode(bg, Z, llrs[i][None], 0.8, nit, rm, crc=(poly, order))
+                    want, ret = w[0], r[0]
+                assert its[i] == ret, (typ, rm, i, its[i], ret)
+                if ret:
+                    assert np.array_equal(msg[i], want), (typ, rm, i)
+                seen.add(ret)
+            assert len(seen) >= 2  # the batch really mixes early and late / failed code words
+    bad = S.LdpcBatch(bg, Z, 0.8, 4, 1, capi.LDPC_S)
+    assert lib.srsran_hip_ldpc_batch_run_crc(bad._h, d_llr.ptr, N, d_msg.ptr, K, 1, N, 0x1800063, 24, d_it.ptr, None) == capi.SRSRAN_ERROR_INVALID_INPUTS

@@ -26,7 +26,7 @@ struct RmParams { // init_rm, ldpc_rm.c:113-167
   int          type;
 };
 
-hipError_t launch_rm_rx(const RmParams& p, hipStream_t stream);
+hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream); // max_E: the largest job.E of the batch
 hipError_t launch_rm_tx(const RmParams& p, hipStream_t stream); // uint8 code words -> uint8 rate-matched bits
 
 #define NRSCH_MAX_CORE_TERMS 4

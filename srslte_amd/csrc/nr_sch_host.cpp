@@ -266,11 +266,13 @@ static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d
   if (n_cb == 0) {
     return SRSRAN_SUCCESS;
   }
-  RmCfg c;
+  RmCfg    c;
+  uint32_t max_E = 0;
   for (uint32_t i = 0; i < n_cb; i++) {
     if (!rm_cfg(cbs[i].E, bg, ls, rv, mod, Nref, &c)) {
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
+    max_E = std::max(max_E, cbs[i].E);
   }
   if (F > c.K - 2 * ls || c.Ncb == 0 || c.Ncb > 65535) {
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -289,7 +291,7 @@ static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d
   p.ini_ex = p.end_ex - F;
   p.Qm     = c.Qm;
   p.type   = llr_type == SRSRAN_HIP_LLR_BYTE ? nrsch::T_I8 : (llr_type == SRSRAN_HIP_LLR_SHORT ? nrsch::T_I16 : nrsch::T_F32);
-  PHY_HIP_CHECK(tx ? nrsch::launch_rm_tx(p, st) : nrsch::launch_rm_rx(p, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(tx ? nrsch::launch_rm_tx(p, st) : nrsch::launch_rm_rx(p, max_E, st), SRSRAN_ERROR);
   return h->finish(st);
 }
 

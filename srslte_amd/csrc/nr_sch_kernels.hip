@@ -4,10 +4,9 @@
 //   encode_kernel  srsran_ldpc_encoder_encode_rm (ldpc_encoder.c:55-95, ldpc_enc_c.c)
 //
 // The reference's de-matcher is a sequential scatter-accumulate in transmission order (the saturation after every addition
-// makes the order matter when a position is received more than once).  Here every lane owns positions of the soft buffer,
-// works out which transmitted soft bits land on each of them -- rank of the position in the circular, filler-skipping
-// read-out order, then every P-th one after it -- gathers them through the de-interleaving index and updates the position
-// once.  No atomics, no temporary buffer.
+// makes the order matter when a position is received more than once).  Here the rank -> position map of the circular,
+// filler-skipping read-out order is closed-form, one lap of the buffer touches every position at most once, and laps are
+// separate launches: no atomics, no temporary buffer, no index table.
 #include "hip_common.h"
 #include "nr_sch_device.h"
 
@@ -56,66 +55,64 @@ __device__ __forceinline__ void divmod(uint32_t k, uint32_t cols, float inv, uin
   *r = (uint32_t)rr;
 }
 
-// rank of a position in the read-out order that starts at k0, wraps at Ncb and skips the fillers; 0xffffffff: the position
-// gets nothing from this transmission; 0xfffffffe: filler
-__device__ __forceinline__ uint32_t rx_rank(const RmParams& p, uint32_t E, uint32_t P, uint32_t fk0, uint32_t fN, uint32_t pos)
+// Position of rank k (k < P) in the read-out order that starts at k0, wraps at Ncb and skips the filler range [fi, fe).
+__device__ __forceinline__ uint32_t rx_position(const RmParams& p, uint32_t fi, uint32_t fe, uint32_t A, uint32_t k)
 {
-  if (pos >= p.ini_ex && pos < p.end_ex) {
-    return 0xfffffffeu;
+  uint32_t s = p.k0, q = k;
+  if (k >= A) { // second stretch: from the start of the buffer
+    s = 0;
+    q = k - A;
+  } else if (s >= fi && s < fe) { // k0 inside the fillers: the read-out really starts behind them
+    s = fe;
   }
-  if (pos >= p.Ncb || P == 0) {
-    return 0xffffffffu;
+  uint32_t pos = s + q;
+  if (s <= fi && pos >= fi) {
+    pos += fe - fi;
   }
-  const uint32_t k = pos >= p.k0 ? (pos - p.k0) - (fcount(p, pos) - fk0) : (pos + p.Ncb - p.k0) - (fN - fk0 + fcount(p, pos));
-  return k < E ? k : 0xffffffffu;
+  return pos;
 }
 
 template <typename T>
-__device__ __forceinline__ T rx_accumulate(const RmParams& p, const T* in, uint32_t E, uint32_t cols, float inv, uint32_t P, uint32_t k, T cur)
+__global__ __launch_bounds__(256) void rm_rx_kernel(const RmParams p, uint32_t lap)
 {
-  if (k == 0xfffffffeu) {
-    return Acc<T>::inf();
-  }
-  for (; k < E; k += P) { // k = 0xffffffff falls through
-    uint32_t src = k;
-    if (p.Qm != 1) { // ldpc_rm.c:365-411: tmp[i * cols + j] = in[j * Qm + i]
-      uint32_t i, j;
-      divmod(k, cols, inv, &i, &j);
-      src = j * p.Qm + i;
+  // Driven by the INPUT: a lane takes one modulation symbol j, i.e. the Qm consecutive soft bits in[j Qm .. j Qm + Qm - 1], which
+  // the de-interleaver sends to the ranks i * cols + j of the read-out order (ldpc_rm.c:365-411).  For a fixed i consecutive
+  // lanes hold consecutive ranks, hence consecutive soft-buffer positions: loads and read-modify-writes are coalesced without
+  // any index arithmetic beyond the closed-form rank -> position map.  Within one lap of the circular buffer (P ranks) every
+  // position receives at most one soft bit, so the lanes never collide; further laps (repetition, E > P) are separate
+  // launches in stream order, which also keeps the reference's saturation order.  The workgroups behind the symbol tiles
+  // write the filler "infinities" (first lap only).
+  const CbJob    job = p.jobs[blockIdx.y];
+  const T*       in  = (const T*)p.in + job.in_off;
+  T*             out = (T*)p.out + job.out_off;
+  const uint32_t E = job.E, cols = E / p.Qm;
+  const uint32_t fi = min(p.ini_ex, p.Ncb), fe = min(p.end_ex, p.Ncb);
+  const uint32_t P = p.Ncb - (fe - fi);
+  const uint32_t A = (p.Ncb - p.k0) - (fe - min(max(p.k0, fi), fe)); // non-filler positions in [k0, Ncb)
+  const uint32_t spl = p.Qm >= 8 ? 1u : 8u / p.Qm; // symbols per lane: about 8 soft bits whatever the modulation
+  const uint32_t sym_tiles = (cols + 256u * spl - 1) / (256u * spl);
+  if (blockIdx.x >= sym_tiles) {
+    const uint32_t i = p.ini_ex + (blockIdx.x - sym_tiles) * 256u + threadIdx.x;
+    if (lap == 0 && i < p.end_ex) {
+      out[i] = Acc<T>::inf(); // ldpc_rm.c:226-229,266-269,318-321
     }
-    cur = Acc<T>::add(cur, in[src]);
+    return;
   }
-  return cur;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void rm_rx_kernel(const RmParams p)
-{
-  // a workgroup covers 256 V consecutive positions; lane l takes l, l + 256, ...: consecutive lanes hold consecutive ranks, so
-  // the de-interleaving gathers of one instruction fall Qm elements apart (a few cache lines) instead of one line per lane
-  constexpr uint32_t V   = 16 / sizeof(T);
-  const CbJob        job = p.jobs[blockIdx.y];
-  const T*           in  = (const T*)p.in + job.in_off;
-  T*                 out = (T*)p.out + job.out_off;
-  const uint32_t     E = job.E, cols = E / p.Qm;
-  const float        inv = 1.0f / (float)max(cols, 1u);
-  const uint32_t     fk0 = fcount(p, p.k0), fN = fcount(p, p.Ncb), P = p.Ncb - fN;
-  const uint32_t     cover = max(p.Ncb, p.end_ex);
-  const uint32_t     p0    = blockIdx.x * 256u * V + threadIdx.x;
-  uint32_t           k[V];
-  T                  cur[V];
-#pragma unroll
-  for (uint32_t i = 0; i < V; i++) {
-    const uint32_t pos = p0 + i * 256u;
-    k[i]               = pos < cover ? rx_rank(p, E, P, fk0, fN, pos) : 0xffffffffu;
-    if (k[i] != 0xffffffffu) { // positions this transmission does not reach are neither read nor written
-      cur[i] = out[pos];
+  if (P == 0) {
+    return;
+  }
+  const uint32_t lo = lap * P, hi = min(E, lo + P); // ranks of this lap
+  for (uint32_t s = 0; s < spl; s++) {
+    const uint32_t j = (blockIdx.x * spl + s) * 256u + threadIdx.x;
+    if (j >= cols) {
+      break;
     }
-  }
-#pragma unroll
-  for (uint32_t i = 0; i < V; i++) {
-    if (k[i] != 0xffffffffu) {
-      out[p0 + i * 256u] = rx_accumulate<T>(p, in, E, cols, inv, P, k[i], cur[i]);
+    for (uint32_t i = 0; i < p.Qm; i++) {
+      const uint32_t k = i * cols + j;
+      if (k >= lo && k < hi) {
+        const uint32_t pos = rx_position(p, fi, fe, A, k - lo);
+        out[pos]           = Acc<T>::add(out[pos], in[j * p.Qm + i]);
+      }
     }
   }
 }
@@ -248,24 +245,30 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p)
 
 } // namespace
 
-hipError_t launch_rm_rx(const RmParams& p, hipStream_t stream)
+hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream)
 {
   if (p.n_cb == 0) {
     return hipSuccess;
   }
-  const uint32_t cover = p.Ncb > p.end_ex ? p.Ncb : p.end_ex;
-  const uint32_t es    = p.type == T_I8 ? 1 : (p.type == T_I16 ? 2 : 4);
-  dim3           grid(ceil_div(cover, 256u * (16u / es)), p.n_cb);
-  switch (p.type) {
-    case T_I8:
-      hipLaunchKernelGGL(rm_rx_kernel<int8_t>, grid, dim3(256), 0, stream, p);
-      break;
-    case T_I16:
-      hipLaunchKernelGGL(rm_rx_kernel<int16_t>, grid, dim3(256), 0, stream, p);
-      break;
-    default:
-      hipLaunchKernelGGL(rm_rx_kernel<float>, grid, dim3(256), 0, stream, p);
-      break;
+  // symbol tiles (the longest code block decides; shorter ones leave early) + tiles that write the filler positions;
+  // one launch per lap of the circular buffer
+  const uint32_t fi = p.ini_ex < p.Ncb ? p.ini_ex : p.Ncb, fe = p.end_ex < p.Ncb ? p.end_ex : p.Ncb;
+  const uint32_t P  = p.Ncb - (fe - fi);
+  const uint32_t laps = P ? ceil_div(max_E ? max_E : 1u, P) : 1u;
+  const uint32_t spl = p.Qm >= 8 ? 1u : 8u / p.Qm;
+  dim3           grid(ceil_div(ceil_div(max_E, p.Qm), 256u * spl) + ceil_div(p.end_ex - p.ini_ex, 256u), p.n_cb);
+  for (uint32_t lap = 0; lap < laps; lap++) {
+    switch (p.type) {
+      case T_I8:
+        hipLaunchKernelGGL(rm_rx_kernel<int8_t>, grid, dim3(256), 0, stream, p, lap);
+        break;
+      case T_I16:
+        hipLaunchKernelGGL(rm_rx_kernel<int16_t>, grid, dim3(256), 0, stream, p, lap);
+        break;
+      default:
+        hipLaunchKernelGGL(rm_rx_kernel<float>, grid, dim3(256), 0, stream, p, lap);
+        break;
+    }
   }
   return hipGetLastError();
 }

@@ -32,7 +32,8 @@ hipError_t launch_rx(const void* d_in, void* d_out, const uint16_t* d_tables, co
 // output-driven form: d_inverse[j] = index of the transmitted bit that lands on soft-buffer position j (0xffff: none),
 // out_span = soft-buffer positions covered (3K+12 natural, 3(K+32)+12 decoder layout); jobs as above (d_jobs or uni)
 hipError_t launch_rx_gather(const void* d_in, void* d_out, const uint16_t* d_inverse, uint32_t out_span, const RxJob* d_jobs,
-                            const RxJob& uni, uint32_t in_stride, uint32_t out_stride, int n_jobs, bool elem8, hipStream_t stream);
+                            const RxJob& uni, uint32_t in_stride, uint32_t out_stride, int n_jobs, bool elem8, hipStream_t stream,
+                            uint32_t max_in_len = 0); // max_in_len: largest in_len of the batch (0: unknown); small inputs are staged in LDS
 
 // uniform batch: job b = `first` with offsets advanced by b * (in_stride, out_stride); no descriptor array
 hipError_t launch_rx_uniform(const void* d_in, void* d_out, const uint16_t* d_table, const RxJob& first, uint32_t in_stride,

@@ -142,7 +142,7 @@ int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out,
   }
   const rm::RxJob first = {0, in_len, 0, 3 * K + 12, 0};
   const uint32_t  span  = nof_sb ? 3 * (K + 32) + 12 : 3 * K + 12;
-  PHY_HIP_CHECK(rm::launch_rx_gather(d_in, d_out, tab, span, nullptr, first, in_stride, out_stride, (int)n_cb, elem8, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(rm::launch_rx_gather(d_in, d_out, tab, span, nullptr, first, in_stride, out_stride, (int)n_cb, elem8, st, in_len), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }
 

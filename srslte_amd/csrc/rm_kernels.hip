@@ -109,9 +109,114 @@ __global__ __launch_bounds__(256) void rm_rx_gather_kernel(const T* in, T* out, 
   }
 }
 
-hipError_t launch_rx_gather(const void* d_in, void* d_out, const uint16_t* d_inverse, uint32_t out_span, const RxJob* d_jobs,
-                            const RxJob& uni, uint32_t in_stride, uint32_t out_stride, int n_jobs, bool elem8, hipStream_t stream)
+// Same operation with the code block's input staged in LDS: one workgroup per code block loads the E soft bits with
+// coalesced 16-byte loads, then walks the soft buffer (16 bytes per lane, one table dwordx4, gathers from LDS, one
+// read-modify-write).  The global gathers of the kernel above (2 bytes out of every line they touch) were its limit.
+template <typename T>
+__global__ __launch_bounds__(512) void rm_rx_gather_lds_kernel(const T* in, T* out, const uint16_t* inverse, const RxJob* jobs, const RxJob uni,
+                                                               uint32_t in_stride, uint32_t out_stride, uint32_t out_span)
 {
+  extern __shared__ uint4 stage[];
+  RxJob jb;
+  if (jobs) {
+    jb = jobs[blockIdx.x];
+  } else {
+    jb = uni;
+    jb.in_offset += blockIdx.x * in_stride;
+    jb.out_offset += blockIdx.x * out_stride;
+  }
+  constexpr int   V   = 16 / sizeof(T);
+  const T*        x   = in + jb.in_offset;
+  T*              dst = out + jb.out_offset;
+  const uint16_t* inv = inverse + jb.table;
+  T*              xs  = reinterpret_cast<T*>(stage);
+  // stage: aligned middle part as uint4, ragged ends element-wise
+  const uint32_t head = min(jb.in_len, (uint32_t)(((16u - ((uintptr_t)x & 15u)) & 15u) / sizeof(T)));
+  const uint32_t nq   = (jb.in_len - head) / V;
+  for (uint32_t i = threadIdx.x; i < head; i += blockDim.x) {
+    xs[i] = x[i];
+  }
+  for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + head + q * V);
+    T           t[V];
+    *reinterpret_cast<uint4*>(t) = v;
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      xs[head + q * V + i] = t[i]; // head shifts the alignment: element-wise LDS stores
+    }
+  }
+  for (uint32_t i = head + nq * V + threadIdx.x; i < jb.in_len; i += blockDim.x) {
+    xs[i] = x[i];
+  }
+  __syncthreads();
+  auto gather = [&](uint32_t k) {
+    int acc = 0;
+    if (k != 0xffffu) {
+      for (uint32_t i = k; i < jb.in_len; i += jb.out_len) {
+        acc += xs[i];
+      }
+    }
+    return acc;
+  };
+  const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(inv)) & 15u) == 0;
+  for (uint32_t j0 = threadIdx.x * V; j0 < out_span; j0 += blockDim.x * V) {
+    if (aligned && j0 + V <= out_span) {
+      uint16_t k[V];
+      if (V == 8) {
+        const uint4    q    = *reinterpret_cast<const uint4*>(inv + j0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          k[i] = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+          k[i] = inv[j0 + i];
+        }
+      }
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+        any = any || (k[i] != 0xffffu && k[i] < jb.in_len);
+      }
+      if (!any) {
+        continue;
+      }
+      uint4 cur = *reinterpret_cast<uint4*>(dst + j0);
+      T*    e   = reinterpret_cast<T*>(&cur);
+#pragma unroll
+      for (int i = 0; i < V; i++) {
+        e[i] = (T)(e[i] + gather(k[i]));
+      }
+      *reinterpret_cast<uint4*>(dst + j0) = cur;
+    } else {
+      for (uint32_t j = j0; j < j0 + V && j < out_span; j++) {
+        const uint32_t k = inv[j];
+        if (k != 0xffffu && k < jb.in_len) {
+          dst[j] = (T)(dst[j] + gather(k));
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_rx_gather(const void* d_in, void* d_out, const uint16_t* d_inverse, uint32_t out_span, const RxJob* d_jobs,
+                            const RxJob& uni, uint32_t in_stride, uint32_t out_stride, int n_jobs, bool elem8, hipStream_t stream,
+                            uint32_t max_in_len)
+{
+  const size_t stage_bytes = (((size_t)max_in_len * (elem8 ? 1 : 2)) + 15) & ~(size_t)15;
+  if (max_in_len && stage_bytes <= 40 * 1024) { // up to 4 workgroups per CU
+    dim3 grid(n_jobs);
+    if (elem8) {
+      hipLaunchKernelGGL(rm_rx_gather_lds_kernel<signed char>, grid, dim3(512), stage_bytes, stream, (const signed char*)d_in, (signed char*)d_out,
+                         d_inverse, d_jobs, uni, in_stride, out_stride, out_span);
+    } else {
+      hipLaunchKernelGGL(rm_rx_gather_lds_kernel<short>, grid, dim3(512), stage_bytes, stream, (const short*)d_in, (short*)d_out, d_inverse, d_jobs,
+                         uni, in_stride, out_stride, out_span);
+    }
+    return hipGetLastError();
+  }
   const uint32_t per_wg = 256 * (elem8 ? 16 : 8);
   dim3           grid((out_span + per_wg - 1) / per_wg, n_jobs);
   if (elem8) {

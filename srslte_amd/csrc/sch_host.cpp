@@ -229,7 +229,11 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
       return SRSRAN_ERROR;
     }
     // softbuffer += rate-matched soft bits (srsran_rm_turbo_rx_lut, sch.c:414), in the decoder's sub-block layout
-    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, false, st), SRSRAN_ERROR);
+    uint32_t max_in = 0;
+    for (uint32_t i = 0; i < m; i++) {
+      max_in = std::max(max_in, work[g.second[i]].job.in_len);
+    }
+    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, false, st, max_in), SRSRAN_ERROR);
     if (turbo::batch_run_early_stop(dec, d_softbuf, false, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {
       return SRSRAN_ERROR;
     }

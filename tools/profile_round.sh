@@ -22,7 +22,15 @@ python tools/rocpd_summary.py $OUT/trace > $OUT/kernel_stats.txt &&
 python tools/rocpd_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > $OUT/pmc.txt &&
 rocprofv3 --kernel-trace -d $OUT/trace_nr -o nr -- python tools/bench_nr.py > /dev/null 2> $OUT/trace_nr.err &&
 rocprofv3 --kernel-trace -d $OUT/trace_sync -o sync -- python tools/bench_sync.py > /dev/null 2> $OUT/trace_sync.err &&
-python tools/rocpd_summary.py $OUT/trace_nr $OUT/trace_sync > $OUT/kernel_stats_nr_sync.txt
+python tools/rocpd_summary.py $OUT/trace_nr $OUT/trace_sync > $OUT/kernel_stats_nr_sync.txt &&
+rocprofv3 --kernel-trace -d $OUT/trace_pusch -o p -- python tools/bench_pusch_rx.py > /dev/null 2> $OUT/trace_pusch.err &&
+rocprofv3 --kernel-trace -d $OUT/trace_nrrx -o p -- python tools/bench_nr_rx.py > /dev/null 2> $OUT/trace_nrrx.err &&
+python tools/rocpd_summary.py $OUT/trace_pusch $OUT/trace_nrrx > $OUT/kernel_stats_chains.txt &&
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_nr -o p -- python tools/bench_nr.py --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_fetch_nr.err &&
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_nr -o p -- python tools/bench_nr.py --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_write_nr.err &&
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_pusch -o p -- python tools/bench_pusch_rx.py --steps 2 > /dev/null 2> $OUT/pmc_fetch_pusch.err &&
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_pusch -o p -- python tools/bench_pusch_rx.py --steps 2 > /dev/null 2> $OUT/pmc_write_pusch.err &&
+python tools/rocpd_summary.py $OUT/pmc_fetch_nr $OUT/pmc_write_nr $OUT/pmc_fetch_pusch $OUT/pmc_write_pusch > $OUT/pmc_chains.txt
 echo "profile pass rc=$?"
 rm -rf $OUT/trace/*/*.db.tmp 2>/dev/null
 du -sh $OUT

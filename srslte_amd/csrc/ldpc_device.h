@@ -25,9 +25,10 @@ struct Params {
   int             sf; // (int)(scaling_fctr * 100)
   int             n_cw;
   int             cpb; // code words per workgroup
+  int             max_slots; // c2v slabs behind c2v_ws: upper bound of the grid
   int             dtype;
   float           sf_f;     // scaling factor of the float decoder
-  void*           c2v_ws;   // LDPC_MAX_SLOTS x cpb x n_edges x Z check-to-variable messages (HBM, L2 / Infinity Cache resident)
+  void*           c2v_ws;   // max_slots x cpb x n_edges x Z check-to-variable messages (HBM, L2 / Infinity Cache resident)
   void*           soft_out; // optional: n_cw x bgN*Z a-posteriori soft bits (parity aid)
   // flooded schedule (int8 only): edges of every variable node in row order over ALL rows; word = edge index | shift << 16
   int             flood;

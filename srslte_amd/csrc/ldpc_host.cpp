@@ -82,6 +82,36 @@ extern "C" int create_compact_pcm(uint16_t* pcm, int8_t (*positions)[MAX_CNCT], 
 
 // ------------------------------------------------------------------------------------------------ batch object
 
+// Code words per workgroup.  Small lifting sizes share a 256-lane workgroup.  Large ones are balanced over the four SIMDs of
+// a CU: a 6-wave workgroup (Z = 384) loads them 2 + 2 + 1 + 1, and whether a second workgroup complements that is up to the
+// dispatcher; two code words in one 12-wave workgroup are 3 + 3 + 3 + 3 by construction (measured 50.4 -> 44.3 ms).  The
+// score is code words per busiest-SIMD wave; ties go to the smaller workgroup.
+static int choose_cpb(int Z, size_t soft_bytes_per_cw)
+{
+  if (Z <= 128) {
+    int cpb = 256 / Z;
+    while (cpb > 1 && (size_t)cpb * soft_bytes_per_cw > 62 * 1024) {
+      cpb--;
+    }
+    return cpb;
+  }
+  int    best = 1;
+  double best_score = 0;
+  for (int cpb = 1; cpb * Z <= 768; cpb++) {
+    if ((size_t)cpb * soft_bytes_per_cw > 150 * 1024) {
+      break;
+    }
+    const int    waves = (cpb * Z + 63) / 64;
+    const double score = (double)cpb / (double)((waves + 3) / 4);
+    if (score > best_score + 1e-9) {
+      best_score = score;
+      best       = cpb;
+    }
+  }
+  return best;
+}
+
+
 struct srsran_hip_ldpc_batch {
   int      bg = 0, Z = 0, N = 0, M = 0, K = 0, E = 0;
   int      max_iter = 0;
@@ -89,6 +119,8 @@ struct srsran_hip_ldpc_batch {
   float    sf_f     = 0.f;
   int      dtype    = ldpc::DT_I8; // message type: int8 (ldpc_dec_c.c), int16 (ldpc_dec_s.c) or float (ldpc_dec_f.c)
   bool     flood    = false;       // flooded schedule (ldpc_dec_c_flood.c), int8 only
+  int      cpb      = 1;           // code words per workgroup (choose_cpb)
+  int      slots    = 1;           // c2v slabs allocated = most workgroups a launch may use
   int*     d_col_start = nullptr;
   int*     d_col_edges = nullptr;
   uint32_t* d_crc_mult = nullptr; // x^((Z-1-c) bgK) mod g for the generator below (CRC early stop)
@@ -209,9 +241,11 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   {
     // one slab of check-to-variable messages per resident workgroup slot and code word it holds (<= 256 / Z words)
     const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
-    const size_t cpb = ls <= 128 ? 256 / ls : 1;
+    const size_t cpb = (size_t)choose_cpb(ls, (size_t)d.N * ls * (dtype == ldpc::DT_F32 ? 4 : 2));
     size_t       slots = ((size_t)(max_nof_cw ? max_nof_cw : 1) + cpb - 1) / cpb;
-    slots              = slots < LDPC_MAX_SLOTS ? slots : LDPC_MAX_SLOTS;
+    slots              = slots < 1024 ? slots : 1024; // 256 CUs x at most 4 resident workgroups
+    h->cpb             = (int)cpb;
+    h->slots           = (int)slots;
     PHY_HIP_CHECK(hipMalloc(&h->d_c2v, slots * cpb * d.E * ls * es), SRSRAN_ERROR);
   }
   *hh = h;
@@ -343,11 +377,10 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.n_col_edges = h->E;
   p.col_start  = h->d_col_start;
   p.col_edges  = h->d_col_edges;
-  p.cpb        = Z <= 128 ? (int)(256 / Z) : 1;
-  // keep the workgroup's LDS slab under 64 KB when several words share it
-  while (p.cpb > 1 && ldpc::lds_bytes(p) > 64 * 1024) {
-    p.cpb--;
-  }
+  // with CRC early stop a workgroup lasts as long as its slowest code word: large lifting sizes then keep one word per
+  // workgroup (the slab area holds cpb times as many single-word slabs)
+  p.cpb        = (crc_order && Z > 128) ? 1 : h->cpb;
+  p.max_slots  = h->slots * h->cpb / p.cpb;
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }

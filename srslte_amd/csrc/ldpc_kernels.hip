@@ -204,7 +204,7 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
 
 // ES: CRC early stop (decode_crc_c), its own instantiation so that its state costs the plain decoders no registers
 template <class POL, bool FLOOD, bool ES>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(ES ? 4 : POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : POL::kMinWaves, 8))) void ldpc_layered_kernel(const Params p)
 {
   typedef typename POL::T  T;
   typedef typename POL::TS TS;
@@ -453,9 +453,9 @@ int grid_slots(const Params& p)
   per_cu           = per_cu < by_lds ? per_cu : by_lds;
   per_cu           = per_cu < 1 ? 1 : per_cu;
   int slots        = cus * per_cu;
-  slots            = slots > LDPC_MAX_SLOTS ? LDPC_MAX_SLOTS : slots;
+  slots            = slots > p.max_slots ? p.max_slots : slots;
   if (const char* e = getenv("LDPC_SLOTS")) { // development knob
-    slots = atoi(e) > 0 && atoi(e) <= LDPC_MAX_SLOTS ? atoi(e) : slots;
+    slots = atoi(e) > 0 && atoi(e) <= p.max_slots ? atoi(e) : slots;
   }
   const int groups = (p.n_cw + p.cpb - 1) / p.cpb;
   return groups < slots ? groups : slots;

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // to their place by multiplication with x^(W (NB-1-d)) mod g and XOR-ed across the lanes of the code block.
   uint8_t*       out       = p.output + (desc ? (size_t)desc[cb].out_off : (size_t)cb * p.out_stride);
   const uint32_t out_bytes = desc ? desc[cb].out_bytes : K / 8;
-  auto decide = [&](bool write) -> uint32_t {
+  auto decide = [&](bool write, bool final_try) -> uint32_t {
     short*         o16   = (p.dec_llr && live && write) ? p.dec_llr + (size_t)cb * K : nullptr;
     const bool     whole = (long_sb & 7) == 0;
     const uint32_t bps   = long_sb >> 3; // bytes per sub-block
@@ -689,7 +689,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
     }
-    if (!whole && write) {
+    uint32_t crc = 0;
+    if (crc_poly) {
+      auto mulmod = [&](uint32_t a, uint32_t m) { // a(x) m(x) mod g(x), all below x^24
+        uint32_t r = 0;
+#pragma unroll 4
+        for (int i = 23; i >= 0; i--) {
+          r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+          r ^= ((m >> i) & 1u) ? a : 0u;
+        }
+        return r;
+      };
+      crc = mulmod(c0, p.crc_mult[2 * pl]) ^ mulmod(c1, p.crc_mult[2 * pl + 1]);
+#pragma unroll
+      for (int off = LPC / 2; off > 0; off >>= 1) {
+        crc ^= __shfl_xor(crc, off, LPC);
+      }
+    }
+    // ragged sub-blocks (long_sb not a multiple of 8): bytes are assembled bit by bit.  With early stop this runs only when the
+    // block has just passed its CRC or on the last half iteration allowed (earlier attempts would be overwritten anyway).
+    if (!whole && write && (!crc_poly || crc == 0 || final_try)) {
       const short* sd = reinterpret_cast<const short*>(D);
       for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
         uint32_t byte = 0;
@@ -706,23 +725,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (live && jb < out_bytes) {
           out[jb] = (uint8_t)byte;
         }
-      }
-    }
-    uint32_t crc = 0;
-    if (crc_poly) {
-      auto mulmod = [&](uint32_t a, uint32_t m) { // a(x) m(x) mod g(x), all below x^24
-        uint32_t r = 0;
-#pragma unroll 4
-        for (int i = 23; i >= 0; i--) {
-          r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
-          r ^= ((m >> i) & 1u) ? a : 0u;
-        }
-        return r;
-      };
-      crc = mulmod(c0, p.crc_mult[2 * pl]) ^ mulmod(c1, p.crc_mult[2 * pl + 1]);
-#pragma unroll
-      for (int off = LPC / 2; off > 0; off >>= 1) {
-        crc ^= __shfl_xor(crc, off, LPC);
       }
     }
     return crc;
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // match (its bits are written then and never again), the wave stops when all its code blocks have
       const bool     fin = n + 1 == p.n_end;
       const bool     wr  = !done; // bits of the last half iteration THIS code block took part in
-      const uint32_t crc = decide(wr);
+      const uint32_t crc = decide(wr, fin);
       if (!done) {
         noi++;
         done = crc == 0;
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 
   if (!crc_poly) {
-    decide(true);
+    decide(true, true);
   } else if (p.noi && live && pl == 0) {
     p.noi[cb_raw]    = (int)noi;
     p.crc_ok[cb_raw] = done ? 1 : 0;

@@ -79,8 +79,9 @@ SRSRAN_API int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs);
 /* ---- transmit side: turbo encoder (lib/include/srsran/phy/fec/turbo/turbocoder.h:46-58, turbocoder.c:40-185) ----
  * srsran_tcod_encode: input long_cb bits (one per byte; 100 = SRSRAN_TX_NULL filler, encoded as 0 and passed through on the
  * systematic and first parity outputs), output 3 long_cb + 12 bytes: [d0 d1 d2] per bit, then the 12 tail bits.
- * Not provided: the byte-packed srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut pair; the batched call below covers what
- * encode_tb (sch.c:230-330) does with them. */
+ * srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut (turbocoder.h:60-66, rm_turbo.h:52-59) are the byte-packed per-block pair
+ * encode_tb (sch.c:230-330) chains: same arguments, outputs and return values; the w_buff contents between redundancy versions
+ * are private (as the reference's are).  The batched srsran_hip_sch_encode below is the throughput path. */
 typedef struct SRSRAN_API {
   uint32_t max_long_cb;
   uint8_t* temp;
@@ -88,6 +89,14 @@ typedef struct SRSRAN_API {
 SRSRAN_API int  srsran_tcod_init(srsran_tcod_t* h, uint32_t max_long_cb);
 SRSRAN_API void srsran_tcod_free(srsran_tcod_t* h);
 SRSRAN_API int  srsran_tcod_encode(srsran_tcod_t* h, uint8_t* input, uint8_t* output, uint32_t long_cb);
+SRSRAN_API void srsran_tcod_gentable(void);
+/* input: the block's payload bytes; on return it also holds the CRC bytes this call appended and, in byte long_cb / 8, the
+ * systematic tail nibble.  parity: long_cb / 4 + 1 bytes.  crc_tb: running CRC24A state; crc_cb: CRC24B object or NULL.
+ * Returns 3 long_cb + 12, or -1. */
+SRSRAN_API int  srsran_tcod_encode_lut(srsran_tcod_t* h, srsran_crc_t* crc_tb, srsran_crc_t* crc_cb, uint8_t* input, uint8_t* parity,
+                                       uint32_t cblen_idx, bool last_cb);
+SRSRAN_API int  srsran_rm_turbo_tx_lut(uint8_t* w_buff, uint8_t* systematic, uint8_t* parity, uint8_t* output, uint32_t cb_idx, uint32_t out_len,
+                                       uint32_t w_offset, uint32_t rv_idx);
 /* device resident: n_cb code blocks of long_cb bits, strides in bytes */
 SRSRAN_API int srsran_hip_tcod_encode_batch(const uint8_t* d_in, uint32_t in_stride, uint8_t* d_out, uint32_t out_stride, uint32_t n_cb,
                                             uint32_t long_cb, void* stream);

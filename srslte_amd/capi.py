@@ -396,6 +396,9 @@ def lib():
             "srsran_tcod_free": (None, [C.POINTER(Tcod)]),
             "srsran_tcod_encode": (i32, [C.POINTER(Tcod), vp, vp, u32]),
             "srsran_hip_tcod_encode_batch": (i32, [vp, u32, vp, u32, u32, u32, vp]),
+            "srsran_tcod_gentable": (None, []),
+            "srsran_tcod_encode_lut": (i32, [C.POINTER(Tcod), C.POINTER(Crc), C.POINTER(Crc), vp, vp, u32, C.c_bool]),
+            "srsran_rm_turbo_tx_lut": (i32, [vp, vp, vp, vp, u32, u32, u32, u32]),
             "srsran_hip_sch_enc_create": (i32, [C.POINTER(vp)]),
             "srsran_hip_sch_enc_free": (None, [vp]),
             "srsran_hip_sch_encode": (i32, [vp, vp, C.POINTER(HipTb), u32, vp, vp]),

@@ -22,7 +22,7 @@ const uint8_t kColPerm[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22,
 // positions, in the receiver's buffer, of the 3(K+4) soft bits of one redundancy version in transmission order
 //   natural buffer (nof_sb == 0): stream s in {0,1,2}, index i in [0, K+4)  ->  3 i + s
 //   decoder layout (nof_sb > 0) : i < K: s (K+32) + (i mod W) nof_sb + i / W with W = K / nof_sb; tail: 3 (K+32) + ...
-std::vector<uint16_t> build_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
+std::vector<uint16_t> build_table(uint32_t K, uint32_t rv, uint32_t nof_sb, uint32_t* start_index = nullptr)
 {
   const int D = (int)K + 4, R = (D + 31) / 32, Kp = 32 * R, ND = Kp - D;
   // circular buffer w: stream / index of every entry, -1 = <NULL>
@@ -41,6 +41,13 @@ std::vector<uint16_t> build_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
   }
   const int Ncb = 3 * Kp;
   const int k0  = R * (2 * ((Ncb + 8 * R - 1) / (8 * R)) * (int)rv + 2);
+  if (start_index) { // place of the first transmitted bit in the buffer without its <NULL> entries (k0_vec[..][1] in rm_turbo.c)
+    uint32_t r0 = 0;
+    for (int j = 0; j < k0; j++) {
+      r0 += w[j] >= 0;
+    }
+    *start_index = r0 % (uint32_t)(3 * D);
+  }
   std::vector<uint16_t> t;
   t.reserve(3 * D);
   for (int j = 0; (int)t.size() < 3 * D; j++) {
@@ -290,6 +297,12 @@ const uint16_t* device_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
 const uint16_t* device_fwd_table(uint32_t K, uint32_t rv, uint32_t* len)
 {
   return fwd_table_on_device(K, rv, len);
+}
+uint32_t tx_start_index(uint32_t K, uint32_t rv)
+{
+  uint32_t r0 = 0;
+  (void)build_table(K, rv, 0, &r0);
+  return r0;
 }
 std::vector<uint16_t> host_table(uint32_t K, uint32_t rv, uint32_t nof_sb)
 {

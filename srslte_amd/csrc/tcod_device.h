@@ -39,6 +39,26 @@ struct TbParams {
   uint32_t        n_cb, n_tb;
 };
 hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream);
+
+struct LutEncParams { // srsran_tcod_encode_lut for one code block
+  const uint8_t* in;      // n_data_bytes packed payload bytes
+  uint8_t*       out_sys; // K / 8 + 1 bytes: the block with its CRCs, then the systematic tail nibble
+  uint8_t*       out_par; // K / 4 + 1 bytes: [parity 0 | tail | parity 1 | tail]
+  uint32_t*      crc_state; // [0]: transport-block checksum in / out; [1]: code-block checksum out
+  uint32_t       K, f1, f2, n_data_bytes;
+  uint32_t       tb_poly, cb_poly;
+  uint32_t       has_cb_crc, last_cb;
+};
+hipError_t launch_lut_encode(const LutEncParams& p, hipStream_t stream);
+
+struct LutRmParams { // srsran_rm_turbo_tx_lut for one code block
+  const uint8_t*  sys;
+  const uint8_t*  par;
+  uint8_t*        out; // E bits packed from bit 0
+  const uint16_t* table;
+  uint32_t        table_len, K, E;
+};
+hipError_t launch_lut_rm(const LutRmParams& p, hipStream_t stream);
 hipError_t launch_tb_encode(const TbParams& p, hipStream_t stream);
 
 } // namespace tcod

@@ -13,6 +13,7 @@ using namespace phyhip;
 namespace phyhip {
 namespace rm {
 const uint16_t* device_fwd_table(uint32_t K, uint32_t rv, uint32_t* len); // rm_host.cpp
+uint32_t        tx_start_index(uint32_t K, uint32_t rv);
 }
 } // namespace phyhip
 
@@ -120,6 +121,167 @@ extern "C" int srsran_tcod_encode(srsran_tcod_t* h, uint8_t* input, uint8_t* out
   PHY_HIP_CHECK(hipMemcpyAsync(output, c->d_out, 3 * long_cb + 12, hipMemcpyDeviceToHost, c->st), -1);
   PHY_HIP_CHECK(hipStreamSynchronize(c->st), -1);
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ byte-packed per-block entry points
+extern "C" void srsran_tcod_gentable(void) {} // turbocoder.c:345-400: nothing to precompute here
+
+// turbocoder.c:188-343.  crc_tb carries the running transport-block checksum from block to block (only its crcinit is read and
+// written, masked to the CRC's order); crc_cb, when given, is left holding the code-block checksum.
+extern "C" int srsran_tcod_encode_lut(srsran_tcod_t* h, srsran_crc_t* crc_tb, srsran_crc_t* crc_cb, uint8_t* input, uint8_t* parity,
+                                      uint32_t cblen_idx, bool last_cb)
+{
+  if (cblen_idx >= 188 || !h || !crc_tb || !input || !parity) {
+    return -1;
+  }
+  const uint32_t K = (uint32_t)srsran_cbsegm_cbsize(cblen_idx);
+  Ctx*           c = reinterpret_cast<Ctx*>(h->temp);
+  if (!c) {
+    return -1;
+  }
+  if (crc_tb->order != 24 || (crc_cb && crc_cb->order != 24)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tcod_encode_lut: only 24-bit CRCs are supported\n");
+    return -1;
+  }
+  tcod::LutEncParams p{};
+  if (!qpp_params(K, &p.f1, &p.f2)) {
+    return -1;
+  }
+  const uint32_t crc_bits = (crc_cb ? 24u : 0u) + (last_cb ? 24u : 0u);
+  if (K < crc_bits) {
+    return -1;
+  }
+  p.K            = K;
+  p.n_data_bytes = (K - crc_bits) / 8;
+  p.in           = c->d_in;
+  p.out_sys      = c->d_out;
+  p.out_par      = c->d_out + 1024;
+  p.crc_state    = reinterpret_cast<uint32_t*>(c->d_out + 4096);
+  p.tb_poly      = (uint32_t)crc_tb->polynom;
+  p.cb_poly      = crc_cb ? (uint32_t)crc_cb->polynom : 0;
+  p.has_cb_crc   = crc_cb ? 1 : 0;
+  p.last_cb      = last_cb ? 1 : 0;
+  uint32_t state[2] = {(uint32_t)(crc_tb->crcinit & crc_tb->crcmask), 0};
+  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, input, p.n_data_bytes, hipMemcpyHostToDevice, c->st), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(p.crc_state, state, sizeof(state), hipMemcpyHostToDevice, c->st), -1);
+  PHY_HIP_CHECK(tcod::launch_lut_encode(p, c->st), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(input, p.out_sys, K / 8 + 1, hipMemcpyDeviceToHost, c->st), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(parity, p.out_par, K / 4 + 1, hipMemcpyDeviceToHost, c->st), -1);
+  PHY_HIP_CHECK(hipMemcpyAsync(state, p.crc_state, sizeof(state), hipMemcpyDeviceToHost, c->st), -1);
+  PHY_HIP_CHECK(hipStreamSynchronize(c->st), -1);
+  crc_tb->crcinit = state[0];
+  if (crc_cb) {
+    crc_cb->crcinit = state[1];
+  }
+  return (int)(3 * K + 12);
+}
+
+namespace {
+struct TxStage {
+  hipStream_t st   = nullptr;
+  uint8_t*    d_sp = nullptr; // systematic + parity streams
+  uint8_t*    d_out = nullptr;
+  size_t      cap_out = 0;
+  bool        tried = false;
+  ~TxStage()
+  {
+    (void)hipFree(d_sp);
+    (void)hipFree(d_out);
+    if (st) {
+      (void)hipStreamDestroy(st);
+    }
+  }
+  bool ready()
+  {
+    if (!tried) {
+      tried = true;
+      if (device_available() && (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipMalloc(&d_sp, 4096) != hipSuccess)) {
+        st = nullptr;
+      }
+    }
+    return st != nullptr;
+  }
+};
+
+// srsran_bit_copy (bit.c:685-698) of `len` bits from the packed array `src` (bit 0 first) to dst at bit offset `dst_off`.  With
+// both offsets byte aligned in the reference (src_aligned tells whether its source offset was) whole bytes are copied and the
+// unused low bits of a last partial byte are ZEROED; otherwise the bits outside the range are preserved (bitarray_copy).
+void bit_copy_like_reference(uint8_t* dst, uint32_t dst_off, const uint8_t* src, uint32_t src_off, uint32_t len, bool src_aligned)
+{
+  auto get = [&](uint32_t i) { return (src[(src_off + i) >> 3] >> (7u - ((src_off + i) & 7u))) & 1u; };
+  for (uint32_t i = 0; i < len; i++) {
+    const uint32_t o = dst_off + i;
+    dst[o >> 3]      = (uint8_t)((dst[o >> 3] & ~(0x80u >> (o & 7u))) | (get(i) << (7u - (o & 7u))));
+  }
+  if ((dst_off & 7u) == 0 && src_aligned && (len & 7u)) {
+    dst[(dst_off + len) >> 3] &= (uint8_t)(0xff00u >> (len & 7u));
+  }
+}
+} // namespace
+
+// rm_turbo.c:340-378.  w_buff keeps the block's byte-packed streams between redundancy versions (its layout is private to
+// this function, as the reference's is to its own): [systematic K/8 + 1 bytes | parity K/4 + 1 bytes].
+extern "C" int srsran_rm_turbo_tx_lut(uint8_t* w_buff, uint8_t* systematic, uint8_t* parity, uint8_t* output, uint32_t cb_idx, uint32_t out_len,
+                                      uint32_t w_offset, uint32_t rv_idx)
+{
+  if (rv_idx >= 4 || cb_idx >= 188 || !w_buff || !output) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  static thread_local TxStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_tx_lut: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  const uint32_t K = (uint32_t)srsran_cbsegm_cbsize(cb_idx), in_len = 3 * K + 12;
+  const uint32_t nsys = K / 8 + 1, npar = K / 4 + 1;
+  if (rv_idx == 0) {
+    if (!systematic || !parity) {
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    memcpy(w_buff, systematic, nsys);
+    memcpy(w_buff + nsys, parity, npar);
+  }
+  if (out_len == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  const size_t out_bytes = (out_len + 7) / 8;
+  if (out_bytes > s.cap_out) {
+    (void)hipFree(s.d_out);
+    s.d_out   = nullptr;
+    s.cap_out = 0;
+    PHY_HIP_CHECK(hipMalloc(&s.d_out, out_bytes + 1024), SRSRAN_ERROR);
+    s.cap_out = out_bytes + 1024;
+  }
+  tcod::LutRmParams p{};
+  p.table = rm::device_fwd_table(K, rv_idx, &p.table_len);
+  if (!p.table) {
+    return SRSRAN_ERROR;
+  }
+  p.sys = s.d_sp;
+  p.par = s.d_sp + nsys;
+  p.out = s.d_out;
+  p.K   = K;
+  p.E   = out_len;
+  std::vector<uint8_t> bits(out_bytes);
+  PHY_HIP_CHECK(hipMemcpyAsync(s.d_sp, w_buff, nsys + npar, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(tcod::launch_lut_rm(p, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(bits.data(), s.d_out, out_bytes, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  // the reference copies the circular buffer piece by piece (rm_turbo.c:362-374); only the alignment rule of each piece matters here
+  uint32_t w_len = 0, r_ptr = rm::tx_start_index(K, rv_idx);
+  while (w_len < out_len) {
+    uint32_t cp = out_len - w_len;
+    if (cp + r_ptr >= in_len) {
+      cp = in_len - r_ptr;
+    }
+    bit_copy_like_reference(output, w_len + w_offset, bits.data(), w_len, cp, (r_ptr & 7u) == 0);
+    r_ptr += cp;
+    if (r_ptr >= in_len) {
+      r_ptr -= in_len;
+    }
+    w_len += cp;
+  }
+  return SRSRAN_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------------------ transport blocks, transmit side

@@ -244,6 +244,111 @@ __global__ __launch_bounds__(64) void tb_encode_kernel(const TbParams p)
   }
 }
 
+// ---- byte-packed per-block entry points (srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut, turbocoder.c:188-343, rm_turbo.c:340-378)
+// One code block per launch: these exist for link-level compatibility; the batched transport-block kernel above is the
+// throughput path.
+
+__device__ __forceinline__ uint32_t wave_crc24(const uint8_t* d, uint32_t n, uint32_t poly) // remainder of d[3 i], i < n (zero start)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t L    = (n + 63u) / 64u;
+  const uint32_t i0 = min(lane * L, n), i1 = min(i0 + L, n);
+  uint32_t       v = 0;
+  for (uint32_t i = i0; i < i1; i++) {
+    v = crc24_bit(v, d[3u * i], poly);
+  }
+  return wave_xor(mulmod24(v, xpow24(n - i1, poly), poly));
+}
+
+__global__ __launch_bounds__(64) void lut_encode_kernel(const LutEncParams p)
+{
+  extern __shared__ uint8_t sm[]; // the natural code word d
+  const uint32_t K = p.K, lane = threadIdx.x;
+  uint32_t       n = 8u * p.n_data_bytes;
+  for (uint32_t i = lane; i < n; i += 64) {
+    sm[3u * i] = (p.in[i >> 3] >> (7u - (i & 7u))) & 1u;
+  }
+  __syncthreads();
+  // running transport-block checksum over the data bytes of this block (turbocoder.c:222-228,268-272)
+  const uint32_t tb_poly = p.tb_poly & 0xffffffu, cb_poly = p.cb_poly & 0xffffffu;
+  uint32_t       tb      = wave_crc24(sm, n, tb_poly) ^ mulmod24(p.crc_state[0] & 0xffffffu, xpow24(n, tb_poly), tb_poly);
+  if (p.last_cb) { // :233-247 / :275-287: the transport-block CRC closes the last block
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (tb >> (23u - lane)) & 1u;
+    }
+    n += 24;
+    __syncthreads();
+  }
+  uint32_t cb = 0;
+  if (p.has_cb_crc) { // :249-258
+    cb = wave_crc24(sm, n, cb_poly);
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (cb >> (23u - lane)) & 1u;
+    }
+    n += 24;
+    __syncthreads();
+  }
+  encode_block(sm, K, p.f1, p.f2);
+  __syncthreads();
+  // systematic bytes + the systematic tail nibble (:338)
+  for (uint32_t b = lane; b <= K / 8; b += 64) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t i = b * 8 + k;
+      const uint32_t bit = i < K ? sm[3u * i] : (i < K + 4 ? sm[3u * K + 3u * (i - K)] : 0u);
+      v |= bit << (7u - k);
+    }
+    p.out_sys[b] = (uint8_t)v;
+  }
+  // parity bit array [p1 (K) | p1 tail (4) | p2 (K) | p2 tail (4)] (:212-216,294-303,340-342)
+  for (uint32_t b = lane; b < (2 * K + 8) / 8; b += 64) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t q = b * 8 + k;
+      uint32_t       bit;
+      if (q < K) {
+        bit = sm[3u * q + 1];
+      } else if (q < K + 4) {
+        bit = sm[3u * K + 3u * (q - K) + 1];
+      } else if (q < 2 * K + 4) {
+        bit = sm[3u * (q - K - 4) + 2];
+      } else {
+        bit = sm[3u * K + 3u * (q - 2 * K - 4) + 2];
+      }
+      v |= bit << (7u - k);
+    }
+    p.out_par[b] = (uint8_t)v;
+  }
+  if (lane == 0) {
+    p.crc_state[0] = tb;
+    p.crc_state[1] = cb;
+  }
+}
+
+// E rate-matched bits (packed from bit 0) of one block given its byte-packed streams
+__global__ __launch_bounds__(256) void lut_rm_kernel(const LutRmParams p)
+{
+  const uint32_t K = p.K;
+  auto           bit_of = [&](const uint8_t* a, uint32_t i) { return (uint32_t)(a[i >> 3] >> (7u - (i & 7u))) & 1u; };
+  for (uint32_t byte = threadIdx.x; byte < (p.E + 7) / 8; byte += 256) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 8 && byte * 8 + k < p.E; k++) {
+      const uint32_t t = p.table[(byte * 8 + k) % p.table_len];
+      uint32_t       i, s;
+      if (t < 3 * K) {
+        i = t / 3u;
+        s = t - 3u * i;
+      } else {
+        i = K + (t - 3 * K) / 3u;
+        s = (t - 3 * K) % 3u;
+      }
+      const uint32_t bit = s == 0 ? bit_of(p.sys, i) : (s == 1 ? bit_of(p.par, i) : bit_of(p.par, K + 4 + i));
+      v |= bit << (7u - k);
+    }
+    p.out[byte] = (uint8_t)v;
+  }
+}
+
 } // namespace
 
 hipError_t launch_encode(const EncParams& p, hipStream_t stream)
@@ -252,6 +357,21 @@ hipError_t launch_encode(const EncParams& p, hipStream_t stream)
     return hipSuccess;
   }
   hipLaunchKernelGGL(encode_kernel, dim3(p.n_cb), dim3(64), 3 * p.K + 16, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_lut_encode(const LutEncParams& p, hipStream_t stream)
+{
+  hipLaunchKernelGGL(lut_encode_kernel, dim3(1), dim3(64), 3 * p.K + 16, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_lut_rm(const LutRmParams& p, hipStream_t stream)
+{
+  if (p.E == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(lut_rm_kernel, dim3(1), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

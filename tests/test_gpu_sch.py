@@ -221,3 +221,45 @@ def test_transport_block_encode(hiplib):
     assert np.array_equal(out[:, :tbs // 8], payload)
     lib.srsran_hip_sch_free(hd)
     lib.srsran_hip_sch_enc_free(h)
+
+
+def test_byte_packed_encoder_and_rate_matcher(hiplib):
+    """srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut (turbocoder.c:188-343, rm_turbo.c:340-378) against the reference's recorded
+    outputs: CRC bytes and tail nibble written into `input`, parity bytes, the running transport-block checksum, and the
+    rate-matched bits at several bit offsets / lengths / redundancy versions including the bits the copy leaves untouched or clears"""
+    import ctypes as C
+    import os
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tcod_lut_ref.npz"))
+    tc = capi.Tcod()
+    assert lib.srsran_tcod_init(C.byref(tc), 6144) == 0
+    lib.srsran_tcod_gentable()
+    for key in d["cases"]:
+        key = str(key)
+        idx, K, with_cb, last, state0, state1, ret = [int(v) for v in d[key + "_meta"]]
+        crc_tb, crc_cb = capi.Crc(), capi.Crc()
+        for c, poly in ((crc_tb, 0x1864CFB), (crc_cb, 0x1800063)):
+            c.polynom, c.order, c.crcmask, c.crchighbit = poly, 24, 0xFFFFFF, 1 << 23
+        crc_tb.crcinit = state0
+        inp = np.zeros(K // 8 + 8, np.uint8)
+        inp[:d[key + "_in"].size] = d[key + "_in"]
+        par = np.zeros(K // 4 + 8, np.uint8)
+        got = lib.srsran_tcod_encode_lut(C.byref(tc), C.byref(crc_tb), C.byref(crc_cb) if with_cb else None, O.P(inp), O.P(par), idx, bool(last))
+        assert got == ret == 3 * K + 12
+        assert np.array_equal(inp[:K // 8 + 1], d[key + "_sys"]), key
+        assert np.array_equal(par[:K // 4 + 1], d[key + "_par"]), key
+        assert (crc_tb.crcinit & 0xFFFFFF) == state1, key
+        w_buff = np.zeros(3 * 6176, np.uint8)
+        at = 0
+        for rv, out_len, w_off, size in d[key + "_txpar"]:
+            o = np.full(int(size), 0xA5, np.uint8)
+            assert lib.srsran_rm_turbo_tx_lut(O.P(w_buff), O.P(inp), O.P(par), O.P(o), idx, int(out_len), int(w_off), int(rv)) == 0
+            assert np.array_equal(o, d[key + "_tx"][at:at + int(size)]), (key, int(rv), int(out_len), int(w_off))
+            at += int(size)
+    assert lib.srsran_tcod_encode_lut(C.byref(tc), C.byref(crc_tb), None, O.P(inp), O.P(par), 188, False) == -1
+    assert lib.srsran_rm_turbo_tx_lut(O.P(w_buff), O.P(inp), O.P(par), O.P(o), 0, 8, 0, 4) == capi.SRSRAN_ERROR_INVALID_INPUTS
+    lib.srsran_tcod_free(C.byref(tc))

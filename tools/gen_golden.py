@@ -21,6 +21,8 @@ No reference source text is stored.
   tests/golden/sch_tx_ref.npz  transmit side of transport blocks as encode_tb_off (sch.c:238-345) chains the reference's
                                srsran_crc_*, srsran_tcod_encode_lut and srsran_rm_turbo_tx_lut: payload bytes -> packed e bits
   tests/golden/ldpc_flood_ref.npz reference SRSRAN_LDPC_DECODER_C_FLOOD (scalar flooded schedule) outputs on seeded LLRs
+  tests/golden/tcod_lut_ref.npz reference srsran_tcod_encode_lut (inputs after the call, parity bytes, running CRC state) and
+                               srsran_rm_turbo_tx_lut (outputs at several bit offsets / lengths / redundancy versions)
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -411,6 +413,56 @@ def sch_tx():
     print("sch_tx_ref.npz", os.path.getsize(os.path.join(OUT, "sch_tx_ref.npz")))
 
 
+def tcod_lut():
+    class Tcod(C.Structure):
+        _fields_ = [("max_long_cb", C.c_uint32), ("temp", C.c_void_p)]
+
+    class Crc(C.Structure):
+        _fields_ = [("table", C.c_uint64 * 256), ("polynom", C.c_int), ("order", C.c_int), ("crcinit", C.c_uint64), ("crcmask", C.c_uint64),
+                    ("crchighbit", C.c_uint64), ("out", C.c_uint32)]
+
+    tc = Tcod()
+    assert ref.srsran_tcod_init(C.byref(tc), 6144) == 0
+    ref.srsran_rm_turbo_gentables()
+    rng = np.random.default_rng(41)
+    d, cases = {}, []
+    for idx in (0, 9, 60, 120, 187):
+        K = ref.srsran_cbsegm_cbsize(idx)
+        for with_cb, last in ((0, 1), (1, 0), (1, 1)):
+            crc_tb, crc_cb = Crc(), Crc()
+            assert ref.srsran_crc_init(C.byref(crc_tb), C.c_uint32(0x1864CFB), 24) == 0 and ref.srsran_crc_init(C.byref(crc_cb), C.c_uint32(0x1800063), 24) == 0
+            # a previous block leaves the running transport-block checksum in a non-trivial state
+            warm = rng.integers(0, 256, 6144 // 8 + 8).astype(np.uint8)
+            wpar = np.zeros(3 * 6144 // 8 + 64, np.uint8)
+            ref.srsran_tcod_encode_lut(C.byref(tc), C.byref(crc_tb), C.byref(crc_cb), P(warm), P(wpar), C.c_uint32(187), C.c_bool(False))
+            state0 = int(crc_tb.crcinit & crc_tb.crcmask)
+            nd = (K - 24 * with_cb - 24 * last) // 8
+            if nd < 1:
+                continue
+            inp = np.zeros(K // 8 + 8, np.uint8)
+            inp[:nd] = rng.integers(0, 256, nd)
+            before = inp.copy()
+            par = np.zeros(K // 4 + 8, np.uint8)
+            ret = ref.srsran_tcod_encode_lut(C.byref(tc), C.byref(crc_tb), C.byref(crc_cb) if with_cb else None, P(inp), P(par), C.c_uint32(idx), C.c_bool(bool(last)))
+            key = "k%d_c%d_l%d" % (idx, with_cb, last)
+            d[key + "_in"], d[key + "_sys"], d[key + "_par"] = before[:nd], inp[:K // 8 + 1], par[:K // 4 + 1]
+            d[key + "_meta"] = np.array([idx, K, with_cb, last, state0, int(crc_tb.crcinit & crc_tb.crcmask), ret], dtype=np.int64)
+            in_len = 3 * K + 12
+            w_buff = np.zeros(3 * 6176, np.uint8)
+            outs, pars = [], []
+            for rv in (0, 2, 3, 1):
+                for out_len, w_off in ((100, 0), (in_len - 5, 3), (in_len + 77, 7), (2 * in_len + 13, 0), (64, 5)):
+                    o = np.full((out_len + w_off) // 8 + 3, 0xA5, np.uint8)
+                    assert ref.srsran_rm_turbo_tx_lut(P(w_buff), P(inp), P(par), P(o), C.c_uint32(idx), C.c_uint32(out_len), C.c_uint32(w_off), C.c_uint32(rv)) == 0
+                    outs.append(o)
+                    pars.append([rv, out_len, w_off, o.size])
+            d[key + "_tx"], d[key + "_txpar"] = np.concatenate(outs), np.array(pars, dtype=np.int64)
+            cases.append(key)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "tcod_lut_ref.npz"), **d)
+    print("tcod_lut_ref.npz", os.path.getsize(os.path.join(OUT, "tcod_lut_ref.npz")))
+
+
 def modem():
     d = {}
     cases = []
@@ -466,6 +518,6 @@ def modem():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut}[name]()

@@ -300,7 +300,10 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
                           void* stream, uint32_t crc_poly, int crc_order, int* d_n_iter)
 {
-  if (!h || !d_llrs || !d_message || n_cw == 0 || n_cw > (h->max_cw ? h->max_cw : 1)) {
+  if (h && n_cw == 0) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!h || !d_llrs || !d_message || n_cw > (h->max_cw ? h->max_cw : 1)) {
     set_error("ldpc batch: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

@@ -296,7 +296,10 @@ extern "C" uint32_t srsran_hip_ofdm_batch_sf_re(srsran_hip_ofdm_batch_t* h)
 static int batch_run(srsran_hip_ofdm_batch_t* h, const void* d_in, void* d_out, uint32_t n_sf, bool tx, bool with_shift,
                      hipStream_t stream, bool with_ramp = true)
 {
-  if (!h || !d_in || !d_out || n_sf == 0 || h->tx != tx) {
+  if (h && n_sf == 0 && h->tx == tx) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!h || !d_in || !d_out || h->tx != tx) {
     set_error("ofdm batch: invalid arguments or wrong direction");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

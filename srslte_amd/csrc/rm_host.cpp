@@ -135,7 +135,10 @@ int rx_batch(const void* d_in, uint32_t in_stride, uint32_t in_len, void* d_out,
              uint32_t rv, uint32_t nof_sb, bool elem8, hipStream_t st)
 {
   const int idx = srsran_cbsegm_cbindex(K);
-  if (!d_in || !d_out || n_cb == 0 || rv > 3 || idx < 0 || (uint32_t)srsran_cbsegm_cbsize(idx) != K ||
+  if (n_cb == 0 && rv <= 3 && idx >= 0) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!d_in || !d_out || rv > 3 || idx < 0 || (uint32_t)srsran_cbsegm_cbsize(idx) != K ||
       (nof_sb && (K % nof_sb || (nof_sb != 8 && nof_sb != 16 && nof_sb != 32)))) {
     set_error("rm_turbo batch: invalid arguments (K=%u rv=%u nof_sb=%u)", K, rv, nof_sb);
     return SRSRAN_ERROR_INVALID_INPUTS;

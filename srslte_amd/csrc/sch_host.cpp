@@ -124,7 +124,10 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
                                      uint32_t max_iterations, int16_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
                                      srsran_hip_tb_result_t* results, void* stream)
 {
-  if (!h || !d_e_bits || !tbs || n_tb == 0 || !d_softbuf || !cb_crc || !d_data || !results || max_iterations == 0) {
+  if (h && n_tb == 0) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!h || !d_e_bits || !tbs || !d_softbuf || !cb_crc || !d_data || !results || max_iterations == 0) {
     set_error("sch decode: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

@@ -328,7 +328,10 @@ extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
 extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_data, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
                                      void* stream)
 {
-  if (!h || !d_data || !tbs || !d_e_bits || n_tb == 0) {
+  if (h && n_tb == 0) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!h || !d_data || !tbs || !d_e_bits) {
     set_error("sch encode: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

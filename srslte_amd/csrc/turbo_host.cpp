@@ -307,7 +307,10 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
                                 int sb_layout, bool want_llr, hipStream_t stream)
 {
   const int16_t* d_input = static_cast<const int16_t*>(d_input_v);
-  if (!h || !d_output || (!d_input && n_begin == 0) || n_cb == 0 || n_cb > h->max_cb || n_end <= n_begin) {
+  if (h && n_cb == 0) {
+    return SRSRAN_SUCCESS; // an empty batch is a no-op
+  }
+  if (!h || !d_output || (!d_input && n_begin == 0) || n_cb > h->max_cb || n_end <= n_begin) {
     set_error("tdec batch: invalid arguments (n_cb=%u max=%u)", n_cb, h ? h->max_cb : 0);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

@@ -136,3 +136,32 @@ def test_nr_chain(hiplib):
             assert np.array_equal(out[i], want[0]) and np.array_equal(out[i], msgs[i])
         lib.srsran_hip_nr_sch_free(h)
         lib.srsran_hip_demod_free(dem)
+
+
+def test_empty_batches_are_no_ops(hiplib):
+    """every batched entry point accepts an empty batch (as the reference's loops over zero code blocks do nothing)"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    d = S.DeviceBuffer(4096)
+    td = S.TdecBatch(512, 4)
+    assert lib.srsran_hip_tdec_batch_run(td._h, d.ptr, 3 * 512 + 12, d.ptr, 64, 0, 4, 0, None) == 0
+    ld = S.LdpcBatch(0, 8, 0.8, 4, 4)
+    assert lib.srsran_hip_ldpc_batch_run(ld._h, d.ptr, 66 * 8, d.ptr, 22 * 8, 0, 66 * 8, None, None) == 0
+    of = S.OfdmBatch(6)
+    assert lib.srsran_hip_ofdm_batch_rx(of._h, d.ptr, d.ptr, 0, None) == 0
+    assert lib.srsran_hip_rm_turbo_rx_batch(d.ptr, 100, 100, d.ptr, 3 * 72 + 12, 0, 40, 0, 0, None) == 0
+    for create, free, call in ((lib.srsran_hip_sch_create, lib.srsran_hip_sch_free,
+                                lambda h: lib.srsran_hip_sch_decode(h, d.ptr, None, 0, 4, d.ptr, None, d.ptr, None, None)),
+                               (lib.srsran_hip_sch_enc_create, lib.srsran_hip_sch_enc_free, lambda h: lib.srsran_hip_sch_encode(h, d.ptr, None, 0, d.ptr, None)),
+                               (lib.srsran_hip_demod_create, lib.srsran_hip_demod_free, lambda h: lib.srsran_hip_demod_run(h, d.ptr, d.ptr, 0, None, 0, None)),
+                               (lib.srsran_hip_nr_sch_create, lib.srsran_hip_nr_sch_free,
+                                lambda h: lib.srsran_hip_ldpc_rm_rx_batch(h, 1, d.ptr, d.ptr, None, 0, 0, 0, 8, 0, 1, 66 * 8, None))):
+        h = C.c_void_p()
+        assert create(C.byref(h)) == 0
+        assert call(h) == 0
+        free(h)
+    assert lib.srsran_hip_tcod_encode_batch(d.ptr, 40, d.ptr, 132, 0, 40, None) == 0
+    assert lib.srsran_hip_predecoding_single(d.ptr, d.ptr, d.ptr, None, 0, 1.0, 0.0, None) == 0
+    capi.check(lib.srsran_hip_stream_sync(None), "sync")

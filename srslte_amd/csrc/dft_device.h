@@ -22,7 +22,9 @@ struct Params {
   int         real_mode; // 0 complex; 1 real -> half-complex (FFTW_R2HC); 2 half-complex -> real (FFTW_HC2R)
 };
 
-hipError_t launch(const Params& p, hipStream_t stream);
+hipError_t launch(const Params& p, hipStream_t stream); // picks a compile-time plan (dft_fixed_kernels.hip) when one applies
+bool       has_fixed_plan(const Params& p);
+hipError_t launch_fixed(const Params& p, hipStream_t stream);
 hipError_t launch_large_twiddle(void* y, int N1, int N2, bool backward, hipStream_t stream);
 hipError_t launch_large_reorder(const void* in, void* out, int N, bool backward, bool dc, hipStream_t stream);
 

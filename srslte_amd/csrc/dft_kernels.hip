@@ -265,6 +265,9 @@ hipError_t launch_large_reorder(const void* in, void* out, int N, bool backward,
 
 hipError_t launch(const Params& p, hipStream_t stream)
 {
+  if (has_fixed_plan(p)) {
+    return launch_fixed(p, stream);
+  }
   hipLaunchKernelGGL(dft_kernel, dim3(p.how_many), dim3(256), 2 * (size_t)p.N * sizeof(float2), stream, p);
   return hipGetLastError();
 }

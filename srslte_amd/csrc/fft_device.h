@@ -122,6 +122,40 @@ struct Dft<8, INV> {
 };
 
 template <bool INV>
+struct Dft<9, INV> {
+  static __device__ __forceinline__ void run(float2 (&v)[9])
+  {
+    const float c1 = 0.76604444311897803520f, s1 = 0.64278760968653932632f; // 2 pi / 9
+    const float c2 = 0.17364817766693034885f, s2 = 0.98480775301220805937f; // 4 pi / 9
+    const float c4 = -0.93969262078590838405f, s4 = 0.34202014332566873304f; // 8 pi / 9
+    float2      y[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+      float2 t[3] = {v[n2], v[n2 + 3], v[n2 + 6]};
+      Dft<3, INV>::run(t);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        y[n2][k] = t[k];
+      }
+    }
+    // twiddles w9^(n2*k1)
+    y[1][1] = mul_w<INV>(y[1][1], c1, s1);
+    y[1][2] = mul_w<INV>(y[1][2], c2, s2);
+    y[2][1] = mul_w<INV>(y[2][1], c2, s2);
+    y[2][2] = mul_w<INV>(y[2][2], c4, s4);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+      float2 t[3] = {y[0][k1], y[1][k1], y[2][k1]};
+      Dft<3, INV>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < 3; k2++) {
+        v[k1 + 3 * k2] = t[k2];
+      }
+    }
+  }
+};
+
+template <bool INV>
 struct Dft<16, INV> {
   static __device__ __forceinline__ void run(float2 (&v)[16])
   {

@@ -101,7 +101,7 @@ def test_transform_precoding(hiplib):
     for is_tx in (True, False):
         q = capi.DftPrecoding()
         assert hiplib.srsran_dft_precoding_init(C.byref(q), 100, is_tx) == 0
-        for n_prb in (1, 2, 6, 25, 45, 81, 96, 100):
+        for n_prb in valid:  # every length has its own compile-time plan (dft_fixed_kernels.hip)
             n = 12 * n_prb
             x = (rng.standard_normal((12, n)) + 1j * rng.standard_normal((12, n))).astype(np.complex64)
             y = np.zeros_like(x)
@@ -143,7 +143,27 @@ def test_batch_sc_fdma_config4(hiplib):
     assert _err(y, ref.astype(np.complex64)) < TOL
     for i in (0, 311, how - 1):
         assert _err(y[i], _oracle(x[i], n, 1, 0, 0, 1)) < TOL
+    # a count that does not fill the last workgroup, in place, with a guard row behind the batch
+    how2 = how - 1
+    d_io = S.DeviceBuffer.from_numpy(x)
+    capi.check(hiplib.srsran_hip_dft_batch_run(h, d_io.ptr, d_io.ptr, how2, None), "run in place")
+    capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+    z = d_io.to_numpy(np.complex64, (how, n))
+    assert np.array_equal(z[:how2], y[:how2]) and np.array_equal(z[how2], x[how2])
     hiplib.srsran_hip_dft_batch_free(h)
+    # forward / un-normalised flavour of the same plan and a small length with many transforms per workgroup
+    for n2, back, norm, how3 in ((1200, False, False, 5), (72, True, True, 1001), (12, False, True, 777)):
+        x2 = (rng.standard_normal((how3, n2)) + 1j * rng.standard_normal((how3, n2))).astype(np.complex64)
+        capi.check(hiplib.srsran_hip_dft_batch_create(C.byref(h), n2, capi.DFT_BACKWARD if back else capi.DFT_FORWARD, False, False, norm), "create")
+        d_in, d_out = S.DeviceBuffer.from_numpy(x2), S.DeviceBuffer(x2.nbytes)
+        capi.check(hiplib.srsran_hip_dft_batch_run(h, d_in.ptr, d_out.ptr, how3, None), "run")
+        capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+        y2 = d_out.to_numpy(np.complex64, (how3, n2))
+        f = np.fft.ifft(x2.astype(np.complex128), axis=1) * n2 if back else np.fft.fft(x2.astype(np.complex128), axis=1)
+        ref2 = (f / (np.sqrt(n2) if norm else 1.0)).astype(np.complex64)
+        assert _err(y2, ref2) < TOL, (n2, back, norm)
+        assert _err(y2[how3 - 1], _oracle(x2[how3 - 1], n2, 1 if back else 0, 0, 0, 1 if norm else 0)) < TOL
+        hiplib.srsran_hip_dft_batch_free(h)
 
 
 @pytest.mark.parametrize("n", [8, 12, 62, 127, 128, 1200, 2048, 4096])

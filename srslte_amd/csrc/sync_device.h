@@ -32,6 +32,7 @@ struct PssParams {
   int         n_cap;
   int         n_blocks;
   int         hop;        // outputs per block = 4096 - fft_size
+  int         part_span;  // outputs behind one part_val / part_idx entry (hop, or 256 on the direct path)
   int         fft_size;
   int         frame_size;
   int         n_out;      // frame_size + fft_size - 2 (pss.c:493)

@@ -239,6 +239,7 @@ int pss_engine_run(PssEngine* e, const void* d_in, uint32_t n_cap, int mask, int
   p.n_cap       = (int)n_cap;
   p.n_blocks    = e->n_blocks;
   p.hop         = e->hop;
+  p.part_span   = e->direct ? 256 : e->hop;
   p.fft_size    = (int)e->fft_size;
   p.frame_size  = (int)e->frame_size;
   p.n_out       = e->n_out;

@@ -172,15 +172,27 @@ __global__ __launch_bounds__(256) void pss_peak_kernel(const PssParams p, PssRes
   const int   peak = s_i[0];
   const float pv   = s_v[0];
   const int   len  = p.n_out + 1; // conv_output_len = L - 1
+  // the slopes of the main lobe are walked by one lane (a serial chain of dependent reads): serve it from an LDS
+  // copy of the neighbourhood of the peak, global memory only beyond it
+  constexpr int WIN = 1024;
+  __shared__ float s_win[2 * WIN];
+  const int        w0 = peak - WIN;
+  __syncthreads();
+  for (int i = tid; i < 2 * WIN; i += 256) {
+    const int g = w0 + i;
+    s_win[i]    = (g >= 0 && g <= len + 1) ? corr[g] : 0.f;
+  }
+  __syncthreads();
+  auto at = [&](int i) { return (i >= w0 && i < w0 + 2 * WIN) ? s_win[i - w0] : corr[i]; };
   if (tid == 0) {
     int pl_ub = peak + 1;
-    while (corr[pl_ub + 1] <= corr[pl_ub] && pl_ub < len) {
+    while (at(pl_ub + 1) <= at(pl_ub) && pl_ub < len) {
       pl_ub++;
     }
     int pl_lb;
     if (peak > 2) {
       pl_lb = peak - 1;
-      while (corr[pl_lb - 1] <= corr[pl_lb] && pl_lb > 1) {
+      while (at(pl_lb - 1) <= at(pl_lb) && pl_lb > 1) {
         pl_lb--;
       }
     } else {
@@ -193,13 +205,36 @@ __global__ __launch_bounds__(256) void pss_peak_kernel(const PssParams p, PssRes
   const int pl_lb = s_lb, pl_ub = s_ub;
   int       dist_right = len - 1 - pl_ub;
   dist_right           = dist_right < 0 ? 0 : dist_right;
-  // side lobe = max(max(corr[pl_ub .. pl_ub+dist_right-1]) or corr[pl_ub], max(corr[0 .. pl_lb-1]) or corr[0])
-  float m = fmaxf(corr[pl_ub], corr[0]);
-  for (int i = tid; i < dist_right; i += 256) {
-    m = fmaxf(m, corr[pl_ub + i]);
+  // side lobe = max(max(corr[pl_ub .. pl_ub+dist_right-1]) or corr[pl_ub], max(corr[0 .. pl_lb-1]) or corr[0]).
+  // A maximum does not depend on the order: blocks that lie wholly inside one of the two ranges contribute their
+  // partial maximum (part_val, written by the correlation kernel from the very values stored in corr), the blocks cut
+  // by a range boundary are scanned.
+  float     m    = fmaxf(corr[pl_ub], corr[0]);
+  const int r_lo = pl_ub, r_hi = pl_ub + dist_right; // right range [r_lo, r_hi), left range [0, pl_lb)
+  for (int k = tid; k < p.n_blocks; k += 256) {
+    const int b_lo = k * p.part_span;
+    const int b_hi = min(b_lo + p.part_span, p.n_out);
+    if (b_hi <= b_lo) {
+      continue;
+    }
+    if (b_hi <= pl_lb || (b_lo >= r_lo && b_hi <= r_hi)) {
+      m = fmaxf(m, p.part_val[((size_t)cap * 3 + h) * p.n_blocks + k]);
+    }
   }
-  for (int i = tid; i < pl_lb; i += 256) {
-    m = fmaxf(m, corr[i]);
+  for (int k = 0; k < p.n_blocks; k++) { // at most four blocks are cut (two per range)
+    const int b_lo = k * p.part_span;
+    const int b_hi = min(b_lo + p.part_span, p.n_out);
+    if (b_hi <= b_lo || b_hi <= pl_lb || (b_lo >= r_lo && b_hi <= r_hi)) {
+      continue;
+    }
+    const int l_hi = min(b_hi, pl_lb); // part of the left range inside this block
+    for (int i = b_lo + tid; i < l_hi; i += 256) {
+      m = fmaxf(m, corr[i]);
+    }
+    const int rr_lo = max(b_lo, r_lo), rr_hi = min(b_hi, r_hi);
+    for (int i = rr_lo + tid; i < rr_hi; i += 256) {
+      m = fmaxf(m, corr[i]);
+    }
   }
   __syncthreads();
   s_v[tid] = m;
@@ -221,10 +256,13 @@ __global__ __launch_bounds__(256) void pss_peak_kernel(const PssParams p, PssRes
 }
 
 // ------------------------------------------------------------------------------------------------ SSS
-// One 64-lane workgroup per (capture, hypothesis): the 62 SSS sub-carriers by direct DFT (exact twiddle
-// table), normalisation, c0/c1 unmasking, the 2 x 31 correlations and their arg-max (find_sss.c).
-__global__ __launch_bounds__(64) void sss_kernel(const SssParams p, const PssResult* pss, SssResult* res)
+// One workgroup per (capture, hypothesis): the 62 SSS sub-carriers by direct DFT (exact twiddle table; symbol and
+// table staged in LDS, the sum over n split over the four waves), normalisation, c0/c1 unmasking, the 2 x 31
+// correlations and their arg-max (find_sss.c) on the first wave.  fft_size <= 2048 (sss.c:38, checked by the host).
+__global__ __launch_bounds__(256) void sss_kernel(const SssParams p, const PssResult* pss, SssResult* res)
 {
+  extern __shared__ float2 s_stage[]; // [N] symbol, [N] twiddles
+  __shared__ float2 s_part[4][62];
   __shared__ float2 y[2][31];
   __shared__ float  corr[2][31];
   __shared__ float  s_pow[2];
@@ -253,20 +291,41 @@ __global__ __launch_bounds__(64) void sss_kernel(const SssParams p, const PssRes
   const float*  st = p.s_tilde;
   const float*  ct = p.c_tilde;
   const float*  zt = p.z_tilde;
-  if (lane < 62) {
-    // mirrored + dc-removed spectrum index N/2-31+lane  ->  FFT bin (find_sss.c:81-84, dft_fftw.c:310-320)
-    const int bin = lane < 31 ? N - 31 + lane : 1 + (lane - 31);
-    float     re = 0.f, im = 0.f;
-    int       idx = 0;
-    for (int n = 0; n < N; n++) {
-      const float2 w = tw[idx];
-      const float2 v = x[n];
-      re += v.x * w.x - v.y * w.y;
-      im += v.x * w.y + v.y * w.x;
-      idx += bin;
-      idx = idx >= N ? idx - N : idx;
+  float2* s_x  = s_stage;
+  float2* s_tw = s_stage + N;
+  for (int n = lane; n < N; n += 256) {
+    s_x[n]  = x[n];
+    s_tw[n] = tw[n];
+  }
+  __syncthreads();
+  {
+    // mirrored + dc-removed spectrum index N/2-31+k  ->  FFT bin (find_sss.c:81-84, dft_fftw.c:310-320)
+    const int k = lane & 63, wv = lane >> 6;
+    if (k < 62) {
+      const int bin   = k < 31 ? N - 31 + k : 1 + (k - 31);
+      const int chunk = (N + 3) / 4;
+      const int n0 = wv * chunk, n1 = min(n0 + chunk, N);
+      float     re = 0.f, im = 0.f;
+      int       idx = (int)(((long)bin * n0) % N);
+      for (int n = n0; n < n1; n++) {
+        const float2 w = s_tw[idx];
+        const float2 v = s_x[n];
+        re += v.x * w.x - v.y * w.y;
+        im += v.x * w.y + v.y * w.x;
+        idx += bin;
+        idx = idx >= N ? idx - N : idx;
+      }
+      s_part[wv][k] = make_float2(re, im);
     }
-    float2 v = make_float2(re, im);
+  }
+  __syncthreads();
+  if (lane < 62) {
+    float2 v = s_part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      v.x += s_part[w][lane].x;
+      v.y += s_part[w][lane].y;
+    }
     if (p.ce) { // find_sss.c:73-76: divide by the channel estimate
       const float2 c = reinterpret_cast<const float2*>(p.ce)[((size_t)cap * 3 + h) * 62 + lane];
       const float  d = c.x * c.x + c.y * c.y;
@@ -416,7 +475,7 @@ hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream)
 
 hipError_t launch_sss(const SssParams& p, const PssResult* d_pss, SssResult* d_res, hipStream_t stream)
 {
-  hipLaunchKernelGGL(sss_kernel, dim3(3, p.n_cap), dim3(64), 0, stream, p, d_pss, d_res);
+  hipLaunchKernelGGL(sss_kernel, dim3(3, p.n_cap), dim3(256), 2 * (size_t)p.fft_size * sizeof(float2), stream, p, d_pss, d_res);
   return hipGetLastError();
 }
 

@@ -180,7 +180,7 @@ def test_ragged_batch_and_empty(hiplib):
         out = dec.decode(llr[:n], 8)
         assert np.array_equal(ref[:n], out)
     rc = S.lib().srsran_hip_tdec_batch_run(dec._h, None, 0, None, 0, 0, 8, 0, None)
-    assert rc == capi.SRSRAN_ERROR_INVALID_INPUTS
+    assert rc == capi.SRSRAN_SUCCESS  # an empty batch is a no-op (a subframe without grants)
     h = C.c_void_p()
     assert S.lib().srsran_hip_tdec_batch_create(C.byref(h), 41, 1, capi.TDEC_AUTO) == capi.SRSRAN_ERROR_INVALID_INPUTS
     assert S.lib().srsran_hip_tdec_batch_create(C.byref(h), 40, 1, capi.TDEC_AVX_WINDOW) == capi.SRSRAN_ERROR_INVALID_INPUTS

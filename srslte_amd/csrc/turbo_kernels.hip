@@ -333,10 +333,11 @@ __device__ __forceinline__ uint32_t permute_pair(uint32_t v, uint32_t sel)
 // of branching on the ragged last block), so the block costs one memory round trip, not eight.
 template <int LPC, class AR, typename T>
 __device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32_t K, uint32_t long_sb, uint32_t nblk,
-                                              int lane, int pl, uint32_t* S, uint32_t* P0, uint32_t* P1, short* TL)
+                                              int lane, int pl, uint32_t* S, uint32_t* P0, uint32_t* P1, short* TL,
+                                              uint32_t b_first = 0, bool tails = true)
 {
   constexpr int NB = 2 * LPC;
-  for (uint32_t b = 0; b < nblk; b++) {
+  for (uint32_t b = b_first; b < nblk; b++) {
     const int nv = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8; // valid steps in this block
     short     r[2][24];
     if (sb_layout) {
@@ -373,7 +374,7 @@ __device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32
     store_block(P0, b * 64 + lane, y0);
     store_block(P1, b * 64 + lane, y1);
   }
-  if (pl == 0) {
+  if (pl == 0 && tails) {
     const uint32_t tb = sb_layout ? 3 * (K + 32) : 3 * K;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -514,8 +515,8 @@ __device__ __forceinline__ void extract_input_natural16(const short* in_wave, ui
 // Fast input extraction for the rm_turbo sub-block layout (int16): element (step k, sub-block d) of stream a sits at
 // in[a (K+32) + k NB + d], i.e. the 8 steps of a block are 8 * NB contiguous int16 per code block and stream.  The LPC
 // lanes of a code block fetch them with two dwordx4 each (128 contiguous bytes per code block and instruction) and the
-// [step][sub-block pair] image is turned into "8 steps of pair p" through the 2 KB LDS stage.  Needs W % 8 == 0 and
-// 16-byte aligned code blocks.
+// [step][sub-block pair] image is turned into "8 steps of pair p" through the 2 KB LDS stage.  Handles the `nblk` full
+// 8-step blocks it is given (a ragged last block goes through extract_input); needs 16-byte aligned code blocks.
 template <int LPC, class AR>
 __device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, uint32_t nblk, int lane, int pl, uint32_t* S,
                                                    uint32_t* P0, uint32_t* P1, short* TL, uint32_t* stage)
@@ -605,10 +606,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const int first = blockIdx.x * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
                                        S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
-    } else if (!p.in_is8 && p.sb_layout && (long_sb & 7u) == 0 &&
+    } else if (!p.in_is8 && p.sb_layout &&
                __all(((reinterpret_cast<uintptr_t>(p.input) + 2 * (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride)) & 15u) == 0)) {
+      // K = 5824 (the code block size of the largest 20 MHz transport blocks) has sub-blocks of 364 steps: 45 full blocks + 4 steps
       const short* in = p.input + (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride);
-      extract_input_sb16<LPC, AR>(in, K, nblk, lane, pl, S, P0, P1, TL, Tr);
+      extract_input_sb16<LPC, AR>(in, K, long_sb >> 3, lane, pl, S, P0, P1, TL, Tr);
+      if (long_sb & 7u) {
+        extract_input<LPC, AR>(in, 1, K, long_sb, nblk, lane, pl, S, P0, P1, TL, long_sb >> 3, false);
+      }
     } else if (p.in_is8) {
       const signed char* in = reinterpret_cast<const signed char*>(p.input) + (desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride);
       extract_input<LPC, AR>(in, p.sb_layout, K, long_sb, nblk, lane, pl, S, P0, P1, TL);
@@ -630,20 +635,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // to their place by multiplication with x^(W (NB-1-d)) mod g and XOR-ed across the lanes of the code block.
   uint8_t*       out       = p.output + (desc ? (size_t)desc[cb].out_off : (size_t)cb * p.out_stride);
   const uint32_t out_bytes = desc ? desc[cb].out_bytes : K / 8;
+  // Early stop: a code block that has matched its CRC (or a lane group behind the end of the batch) stays in the wave until
+  // the wave's last block is done, but its vectors are dead.  Its block / row indices are masked to 0 so that it keeps
+  // re-touching one cached line per array instead of streaming its workspace through HBM: m_own covers the accesses a lane
+  // makes for its own sub-blocks, m_row the 16-byte row pieces it fetches for the lane group that owns those columns.
+  uint32_t m_own_v = ~0u, m_row_v = ~0u;
+  auto     set_masks = [&](bool dead) {
+    const unsigned long long dm = __ballot(dead);
+    const int                og = ((4 * (lane & 15)) / LPC) * LPC; // first lane of the group owning columns 4 (lane % 16) .. + 3
+    m_own_v                     = dead ? 0u : ~0u;
+    m_row_v                     = ((dm >> og) & 1ull) ? 0u : ~0u;
+  };
+  if (ES) {
+    set_masks(!live);
+  }
+#define M_OWN (ES ? m_own_v : ~0u)
+#define M_ROW (ES ? m_row_v : ~0u)
   auto decide = [&](bool write, bool final_try) -> uint32_t {
     short*         o16   = (p.dec_llr && live && write) ? p.dec_llr + (size_t)cb * K : nullptr;
     const bool     whole = (long_sb & 7) == 0;
     const uint32_t bps   = long_sb >> 3; // bytes per sub-block
     const uint32_t poly  = crc_poly & 0xffffffu;
     uint32_t       c0 = 0, c1 = 0;
-    if (whole || crc_poly) {
+    // ragged sub-blocks (long_sb not a multiple of 8): the hard bits of every sub-block are first packed MSB first into a
+    // byte image in LDS (the beta buffer is idle between half iterations), sub-block d at sbuf[d][.] with a zero byte
+    // behind it, and the natural-order bytes are cut out of that image afterwards
+    const uint32_t sbs  = nblk + 1;
+    uint8_t*       sbuf = reinterpret_cast<uint8_t*>(&Bl[0][0][0]) + (size_t)(lane / LPC) * NB * sbs;
+    static_assert(sizeof(Bl) >= 64 / LPC * 2 * LPC * (6144 / (2 * LPC) / 8 + 2), "byte image does not fit");
+    if (!whole) {
+      sbuf[(2 * pl) * sbs + nblk]     = 0;
+      sbuf[(2 * pl + 1) * sbs + nblk] = 0;
+    }
+    {
       const bool wide = whole && ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0) && out_bytes == K / 8;
       uint32_t   w0 = 0, w1 = 0;
       uint32_t   t[8], tn[8];
       issue_rows(D, 0, lane, t);
       for (uint32_t b = 0; b < nblk; b++) {
         if (b + 1 < nblk) {
-          issue_rows(D, b + 1, lane, tn);
+          issue_rows(D, (b + 1) & M_ROW, lane, tn);
         }
         uint32_t r[8];
         rows_to_lane(Tr, lane, t, r);
@@ -664,6 +695,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
               o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
             }
           }
+        }
+        if (!whole) {
+          sbuf[(2 * pl) * sbs + b]     = (uint8_t)b0;
+          sbuf[(2 * pl + 1) * sbs + b] = (uint8_t)b1;
         }
         if (whole && write && live) {
           if (wide) {
@@ -706,27 +741,55 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         crc ^= __shfl_xor(crc, off, LPC);
       }
     }
-    // ragged sub-blocks (long_sb not a multiple of 8): bytes are assembled bit by bit.  With early stop this runs only when the
-    // block has just passed its CRC or on the last half iteration allowed (earlier attempts would be overwritten anyway).
+    // ragged sub-blocks: with early stop the bytes are cut out only when the block has just passed its CRC or on the last
+    // half iteration allowed (earlier attempts would be overwritten anyway)
+    __syncthreads();
     if (!whole && write && (!crc_poly || crc == 0 || final_try)) {
-      const short* sd = reinterpret_cast<const short*>(D);
-      for (uint32_t jb = pl; jb < K / 8; jb += LPC) {
-        uint32_t byte = 0;
-        for (int tt = 0; tt < 8; tt++) {
-          uint32_t nn = jb * 8 + tt;
-          uint32_t d = nn / long_sb, k = nn % long_sb;
-          uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
-          short    v = sd[e];
-          byte |= (v > 0 ? 0x80u : 0u) >> tt;
-          if (o16) {
-            o16[nn] = v;
+      const uint32_t nbytes = K / 8;
+      const uint32_t lim    = out_bytes < nbytes ? out_bytes : nbytes;
+      const bool     al     = (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+      for (uint32_t w = pl; w * 4 < nbytes; w += LPC) {
+        uint32_t d = (w * 32) / long_sb, k = w * 32 - d * long_sb;
+        uint32_t word = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (w * 4 + t < nbytes) {
+            // 8 bits of sub-block d from step k (zeros past its end), completed from the head of sub-block d + 1
+            const uint8_t* q = sbuf + d * sbs + (k >> 3);
+            uint32_t       v = ((((uint32_t)q[0] << 8) | q[1]) >> (8 - (k & 7))) & 0xffu;
+            if (k + 8 > long_sb && d + 1 < (uint32_t)NB) {
+              v |= (uint32_t)sbuf[(d + 1) * sbs] >> (long_sb - k);
+            }
+            word |= v << (8 * t);
+          }
+          k += 8;
+          if (k >= long_sb) {
+            k -= long_sb;
+            d++;
           }
         }
-        if (live && jb < out_bytes) {
-          out[jb] = (uint8_t)byte;
+        if (live) {
+          if (al && w * 4 + 3 < lim) {
+            *reinterpret_cast<uint32_t*>(out + 4 * w) = word;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              if (w * 4 + t < lim) {
+                out[w * 4 + t] = (uint8_t)(word >> (8 * t));
+              }
+            }
+          }
+        }
+      }
+      if (o16) { // parity aid: decision LLRs in natural order
+        const short* sd = reinterpret_cast<const short*>(D);
+        for (uint32_t nn = pl; nn < K; nn += LPC) {
+          const uint32_t d = nn / long_sb, k = nn % long_sb;
+          o16[nn] = sd[(k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1)];
         }
       }
     }
+    __syncthreads();
     return crc;
   };
   bool     done = false; // early stop: the CRC of this code block has matched
@@ -747,13 +810,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     auto issue = [&](uint32_t b, Ops& q) {
       if (dec1) {
-        load_block(S, b * 64 + lane, q.x);
+        load_block(S, (b & M_OWN) * 64 + lane, q.x);
       } else {
-        issue_rows(A2, b, lane, q.x);
+        issue_rows(A2, b & M_ROW, lane, q.x);
       }
-      load_block(Y, b * 64 + lane, q.y);
+      load_block(Y, (b & M_OWN) * 64 + lane, q.y);
       if (has_app) {
-        issue_rows(A1, b, lane, q.a);
+        issue_rows(A1, b & M_ROW, lane, q.a);
       }
     };
     auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
@@ -821,7 +884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int i = 0; i < 8; i++) {
         ck[i] = to_u(o[i]);
       }
-      store_block(CK, nblk * 64 + lane, ck);
+      store_block(CK, (nblk & M_OWN) * 64 + lane, ck);
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
     if (nblk > 1) {
@@ -844,7 +907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int i = 0; i < 8; i++) {
               ck[i] = to_u(o[i]);
             }
-            store_block(CK, b * 64 + lane, ck);
+            store_block(CK, ((uint32_t)b & M_OWN) * 64 + lane, ck);
           }
           if (AR::norm_at(k)) {
             AR::normalize(o);
@@ -905,7 +968,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool last = (n + 1 == p.n_end) || crc_poly; // with early stop every half iteration may be the last
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
-    load_block(CK, 64 + lane, ck);
+    load_block(CK, (1u & M_OWN) * 64 + lane, ck);
     load_lut(lut, pl, tr);
     if (nblk > 1) {
       issue(1, nxt);
@@ -917,7 +980,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         issue(b + 2, nx2);
       }
       if (b + 1 < nblk) {
-        load_block(CK, (b + 2) * 64 + lane, ckn);
+        load_block(CK, ((b + 2) & M_OWN) * 64 + lane, ckn);
         load_lut(lut, (b + 1) * LPC + pl, trn);
       }
       prep(cur, xs, ys, ap);
@@ -971,13 +1034,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         if (j < len) {
-          const uint32_t row = tr[j] & 0xffffu;
+          const uint32_t row = tr[j] & 0xffffu & M_OWN;
           dst[(size_t)row * 64 + lane] = permute_pair<LPC>(outv[j], tr[j] >> 16);
           if (last) {
             // what tdec_decision_byte reads (turbodecoder.c:370-378), in natural order: ext1 after decoder 1,
             // the de-interleaved ext2 (= app1 before the subtraction) after decoder 2
             if (dec1) {
-              D[(size_t)(b * 8 + j) * 64 + lane] = rawv[j];
+              D[(size_t)((b * 8 + j) & M_OWN) * 64 + lane] = rawv[j];
             } else {
               D[(size_t)row * 64 + lane] = permute_pair<LPC>(rawv[j], tr[j] >> 16);
             }
@@ -1003,6 +1066,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         noi++;
         done = crc == 0;
       }
+      set_masks(done || !live);
       __syncthreads();
       if (__all(done || !live) || fin) {
         break;
@@ -1010,6 +1074,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
 
+#undef M_OWN
+#undef M_ROW
   if (!crc_poly) {
     decide(true, true);
   } else if (p.noi && live && pl == 0) {

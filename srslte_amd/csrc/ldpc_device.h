@@ -41,12 +41,18 @@ struct Params {
   int             crc_order;
   const uint32_t* crc_mult;
   int*            n_iter_out;
+  // two lifted positions per lane (ldpc_packed_kernels.hip): set by the host when packed_applies(); sf_m9 = M with
+  // (x * M) >> 9 == x * sf / 100 for every x in 0..127, or 0 when there is no such M
+  int             packed;
+  int             sf_m9;
 };
 
 #define LDPC_MAX_SLOTS 4096 // resident workgroup slots (256 CUs x up to 4); each owns one c2v slab per code word it holds
 int        grid_slots(const Params& p);
 hipError_t launch(const Params& p, hipStream_t stream);
 size_t     lds_bytes(const Params& p);
+bool       packed_applies(const Params& p); // int8, layered, even lifting size, no per-iteration / soft-bit side outputs
+hipError_t launch_packed(const Params& p, hipStream_t stream);
 
 } // namespace ldpc
 } // namespace phyhip

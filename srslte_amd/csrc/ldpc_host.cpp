@@ -384,6 +384,30 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   // workgroup (the slab area holds cpb times as many single-word slabs)
   p.cpb        = (crc_order && Z > 128) ? 1 : h->cpb;
   p.max_slots  = h->slots * h->cpb / p.cpb;
+  // (x * M) >> 9 == x * sf / 100 on 0..127 with x * M below 2^16: lets the packed kernel scale on the 16-bit multiplier
+  p.sf_m9 = 0;
+  {
+    const int M = (h->sf * 512 + 99) / 100;
+    bool      ok = M > 0 && 127 * M < 65536;
+    for (int x = 0; ok && x <= 127; x++) {
+      ok = ((x * M) >> 9) == x * h->sf / 100;
+    }
+    p.sf_m9 = ok ? M : 0;
+  }
+  p.packed = 0;
+  if (ldpc::packed_applies(p)) {
+    // code words per workgroup for Z / 2 lanes per word (26 KB of soft words for BG1 Z = 384: four words, 12 waves)
+    const int cap  = h->slots * h->cpb; // code-word slabs allocated
+    int       pcpb = (crc_order && Z > 128) ? 1 : choose_cpb((int)Z / 2, (size_t)h->N * (Z / 2) * 2);
+    pcpb           = pcpb > cap ? cap : pcpb;
+    if (const char* e = getenv("LDPC_PCPB")) { // development knob
+      const int v = atoi(e);
+      pcpb        = (v > 0 && v <= cap && v * (int)(Z / 2) <= 768 && (size_t)v * h->N * Z <= 150 * 1024) ? v : pcpb;
+    }
+    p.cpb       = pcpb;
+    p.max_slots = cap / pcpb;
+    p.packed    = 1;
+  }
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }

@@ -489,6 +489,9 @@ static hipError_t launch_pol(const Params& p, hipStream_t stream)
 
 hipError_t launch(const Params& p, hipStream_t stream)
 {
+  if (p.packed) {
+    return launch_packed(p, stream);
+  }
   switch (p.dtype) {
     case DT_I8:
       if (p.crc_order) {

@@ -46,14 +46,9 @@ static __device__ __forceinline__ s2v clip(s2v x, short lim)
 {
   return pmin(pmax(x, splat2((short)-lim)), splat2(lim));
 }
-// bytes 0 and 1 of w, sign-extended to the two halves (swapped: byte 1 to the low half)
-static __device__ __forceinline__ s2v widen(uint32_t w, bool swapped)
-{
-  const uint32_t t = __builtin_amdgcn_perm(0u, w, swapped ? 0x000c010cu : 0x010c000cu); // value << 8 in each half
-  return as_s2(t) >> 8;
-}
-
-template <int DEG>
+// KEEP_A: keep the magnitudes in registers between the two passes (the early-stop instantiation recomputes them instead:
+// its extra state would push the 19-edge rows into scratch)
+template <int DEG, bool KEEP_A>
 __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_t coff, int my_edge, int e0, int c, uint32_t Z, uint32_t H,
                                              unsigned short m9, bool active)
 {
@@ -65,37 +60,47 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
   if (!active) {
     return;
   }
-  const uint32_t row0 = (uint32_t)e0 * H;
-  int            idx[DEG];
-  uint32_t       selw[DEG], sraw[DEG], craw[DEG];
-  bool           swp[DEG];
+  const uint32_t coffb = coff * 2u;        // this lane's byte offset inside an edge's run of messages (32-bit: scalar base + VGPR offset addressing)
+  const uint32_t rowb  = (uint32_t)e0 * Z; // byte offset of this row's first edge (H words of 2 bytes per edge); wave-uniform
+  char*          cbase = reinterpret_cast<char*>(c2v);
+  // (byte-wide d16 loads / stores of the two halves would save the widening and narrowing instructions below, but were
+  // measured 28 % slower: the LDS and vector-memory pipes then take twice the instructions)
+  int  idx[DEG];  // LDS byte offset of the soft word holding the lane's pair
+  bool swp[DEG];  // ... byte-swapped in it (a lane mask in scalar registers)
+  s2v  s[DEG], co[DEG];
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    const uint32_t r  = (uint32_t)c + ((uint32_t)ed[i] >> 16); // < 2 Z
-    const uint32_t j  = min(r, r - Z);                         // (c + shift) mod Z: the wrapped difference is huge when r < Z
-    const uint32_t dw = min(j, j - H);                         // j mod H
-    swp[i]            = dw != j;
-    idx[i]            = (int)((((uint32_t)ed[i] & 0xffffu) >> 1) + dw) * 2; // byte offset of word (node * H + dw)
-    selw[i]           = swp[i] ? 0x0c0c0002u : 0x0c0c0200u;
-    sraw[i]           = *reinterpret_cast<const uint16_t*>(sbase + idx[i]);
-    craw[i]           = c2v[row0 + (uint32_t)i * H + coff];
+    // lane pair (c, c + H) rotated by the shift: word (c + shift) mod H, bytes swapped when floor((c + shift) / H) is odd
+    const uint32_t sh = (uint32_t)ed[i] >> 16;            // scalar, < Z
+    const bool     sq = sh >= H;                          // scalar
+    const uint32_t a  = (uint32_t)c + (sq ? sh - H : sh); // < 2 H
+    const uint32_t dw = min(a, a - H);                    // mod H: the wrapped difference is huge when a < H
+    swp[i]            = sq ? (dw == a) : (dw != a);
+    idx[i]            = (int)(((uint32_t)ed[i] & 0xffffu) + dw * 2u); // node * Z + 2 dw
+    const uint32_t sw = *reinterpret_cast<const uint16_t*>(sbase + idx[i]);
+    const uint32_t cw = *reinterpret_cast<const uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb));
+    // bytes 0 / 1 to the halves of the lane's pair, sign-extended (swapped pairs: byte 1 is the low half)
+    s[i]  = as_s2(__builtin_amdgcn_perm(0u, sw, swp[i] ? 0x000c010cu : 0x010c000cu)) >> 8;
+    co[i] = as_s2(__builtin_amdgcn_perm(0u, cw, 0x010c000cu)) >> 8;
   }
-  s2v      x[DEG], a[DEG];
+  s2v      x[DEG], a[KEEP_A ? DEG : 1];
   s2v      min0 = splat2(127), min1 = splat2(127);
   uint32_t sgn  = 0;
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    const s2v s  = widen(sraw[i], swp[i]);
-    const s2v co = widen(craw[i], false);
-    // ldpc_dec_c.c:338-363: +-127 (and -128) pass as infinity, everything else is clip(s - c, +-63).  g = sign(s) for the
-    // infinite values and 0 otherwise; pushing s - c out by 512 g makes the clip produce +-63, 64 g completes it to +-127.
-    const s2v g  = clip(s, 127) - clip(s, 126);
-    const s2v t  = (s - co) + g * splat2(512);
-    const s2v xv = clip(t, 63) + g * splat2(64);
+    // ldpc_dec_c.c:338-363: +-127 passes as infinity, everything else is clip(s - c, +-63).  Soft words only hold -63..63
+    // and +-127 (the kernel normalises the channel LLRs when it loads them), so h = s - clip(s) is +-64 for the
+    // infinite values and 0 otherwise; pushing s - c out by 8 h makes the clip produce +-63, h completes it to +-127.
+    const s2v h  = s[i] - clip(s[i], 63);
+    const s2v t  = (s[i] - co[i]) + h * splat2(8);
+    const s2v xv = clip(t, 63) + h;
     x[i]         = xv;
-    a[i]         = pmax(xv, splat2(0) - xv);
-    min1         = pmax(pmin(a[i], min1), pmin(pmax(a[i], min1), min0)); // second smallest of {a, min0, min1}
-    min0         = pmin(a[i], min0);
+    const s2v av = pmax(xv, splat2(0) - xv);
+    if (KEEP_A) {
+      a[i] = av;
+    }
+    min1         = pmax(pmin(av, min1), pmin(pmax(av, min1), min0)); // second smallest of {a, min0, min1}
+    min0         = pmin(av, min0);
     sgn ^= as_u32(xv);
   }
   // :275-278
@@ -106,16 +111,17 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     // the edge(s) holding the minimum get the second minimum (equal magnitudes: both are the same number)
-    const s2v ne  = pmin(a[i] - min0, splat2(1)); // 0 where a == min0, else 1
+    const s2v av  = KEEP_A ? a[i] : pmax(x[i], splat2(0) - x[i]);
+    const s2v ne  = pmin(av - min0, splat2(1)); // 0 where a == min0, else 1
     const s2v mag = s1 + ne * ds;
     const s2v m   = as_s2(sgn ^ as_u32(x[i])) >> 15; // all ones where the product of the OTHER signs is negative
     const s2v cn  = (mag ^ m) - m;
-    c2v[row0 + (uint32_t)i * H + coff] = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cn), 0x0c0c0200u);
-    // :308-315: t > 63 -> 127, t < -63 -> -127
-    const s2v t   = cn + x[i];
-    const s2v k   = clip(t, 63);
-    const s2v res = k + clip((t - k) * splat2(64), 64); // (written so that it is not recognised as a signum and expanded into compares)
-    *reinterpret_cast<uint16_t*>(sbase + idx[i]) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(res), selw[i]);
+    *reinterpret_cast<uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb)) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cn), 0x0c0c0200u);
+    // :308-315: t > 63 -> 127, t < -63 -> -127.  u = clip(t, 64) reaches +-64 exactly when t is out of range, and then
+    // u - clip(u, 63) = +-1 (written with a multiplication so that it is not expanded into compares as a signum)
+    const s2v u   = clip(cn + x[i], 64);
+    const s2v res = u + (u - clip(u, 63)) * splat2(63);
+    *reinterpret_cast<uint16_t*>(sbase + idx[i]) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(res), swp[i] ? 0x0c0c0002u : 0x0c0c0200u);
   }
 }
 
@@ -161,7 +167,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       soft2[c]     = 0;
       soft2[H + c] = 0;
       for (int n = 2; n < p.bgN; n++) {
-        const uint32_t lo = (uint8_t)llr[(n - 2) * Z + c], hi = (uint8_t)llr[(n - 2) * Z + H + c];
+        // values the first variable-to-check pass treats alike are stored alike: |llr| >= 127 is infinity (+-127), anything
+        // else enters as clip(llr, +-63) (its check-to-variable messages are still zero then, ldpc_dec_c.c:345-353)
+        auto norm = [](int v) { return v >= 127 ? 127 : (v <= -127 ? -127 : (v > 63 ? 63 : (v < -63 ? -63 : v))); };
+        const uint32_t lo = (uint8_t)norm(llr[(n - 2) * Z + c]), hi = (uint8_t)norm(llr[(n - 2) * Z + H + c]);
         soft2[n * H + c] = (uint16_t)(lo | (hi << 8));
       }
       for (int e = 0; e < p.n_edges; e++) {
@@ -183,10 +192,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
           degn         = __builtin_amdgcn_readfirstlane(row_start[ln + 1]) - e0n;
           edgn         = edges[e0n + (lane < degn ? lane : 0)];
         }
+
         switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer_packed<D>(sbase, c2v, coff, my_edge, e0, c, Z, H, m9, active);                                               \
+    layer_packed<D, !ES>(sbase, c2v, coff, my_edge, e0, c, Z, H, m9, active);                                               \
     break;
           LDPC_CASE(1)
           LDPC_CASE(2)

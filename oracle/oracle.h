@@ -132,6 +132,18 @@ int orc_ldpc_rm_tx(const uint8_t* input, uint8_t* output, uint32_t E, int bg, ui
 int orc_ldpc_rm_rx(int type, const void* input, void* output, uint32_t E, uint32_t F, int bg, uint32_t ls, uint32_t rv, uint32_t Qm,
                    uint32_t Nref);
 
+/* ---------------- NR shared channel, transport-block loop (sch_nr.c, cbsegm.c:159-285): orc_sch_nr.c ---------------- */
+typedef struct { /* srsran_sch_nr_tb_info_t, sch_nr.h */
+  uint32_t bg, Qm, A, L_tb, L_cb, B, Bp, Kp, Kr, F, Z, G, Nl, Nref, C;
+} orc_nr_tb_info_t;
+int      orc_sch_nr_select_basegraph(uint32_t tbs, double R);
+int      orc_sch_nr_tb_info(uint32_t tbs, double R, uint32_t Qm, uint32_t nof_bits, uint32_t N_L, uint32_t Nref, orc_nr_tb_info_t* cfg);
+uint32_t orc_sch_nr_get_E(const orc_nr_tb_info_t* cfg, uint32_t j);
+int      orc_sch_nr_encode_tb(const orc_nr_tb_info_t* cfg, uint32_t rv, const uint8_t* data, uint8_t* e_bits);
+int      orc_sch_nr_decode_tb(const orc_nr_tb_info_t* cfg, uint32_t rv, float scaling_fctr, int max_nof_iter, const int8_t* e_bits,
+                              int8_t* softbuf, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* cb_data, uint32_t data_stride, uint8_t* payload,
+                              int* crc_ok, float* avg_iter);
+
 /* crc.c:  bit-per-byte CRC as srsran_crc_checksum (no reversal) */
 uint32_t orc_crc_bits(uint32_t poly, int order, const uint8_t* bits, int len);
 

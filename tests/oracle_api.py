@@ -546,3 +546,45 @@ def ldpc_decode_flood(bg, ls, llr, scaling_fctr, max_iter, cdwd_rm_length, crc=N
     poly, order = crc if crc else (0, 0)
     ret = f(C.byref(g), scaling_fctr, max_iter, P(llr), P(out), cdwd_rm_length, poly, order, P(soft))
     return out, soft, ret
+
+
+# ---------------------------------------------------------------- NR transport-block loop (orc_sch_nr.c)
+class NrTbInfo(C.Structure):  # orc_nr_tb_info_t
+    _fields_ = [(n, C.c_uint32) for n in ("bg", "Qm", "A", "L_tb", "L_cb", "B", "Bp", "Kp", "Kr", "F", "Z", "G", "Nl", "Nref", "C")]
+
+
+def sch_nr_tb_info(tbs, R, mod, nof_bits, N_L, Nref):
+    cfg = NrTbInfo()
+    f = orc().orc_sch_nr_tb_info
+    f.argtypes = [C.c_uint32, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    assert f(tbs, R, QM[mod], nof_bits, N_L, Nref, C.byref(cfg)) == 0
+    return cfg
+
+
+def sch_nr_get_E(cfg, j):
+    f = orc().orc_sch_nr_get_E
+    f.argtypes, f.restype = [C.c_void_p, C.c_uint32], C.c_uint32
+    return f(C.byref(cfg), j)
+
+
+def sch_nr_encode_tb(cfg, rv, payload):
+    """orc_sch_nr_encode_tb: payload bytes -> G bits (one per byte)"""
+    e = np.zeros(sum(sch_nr_get_E(cfg, r) for r in range(cfg.C)), np.uint8)
+    f = orc().orc_sch_nr_encode_tb
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    assert f(C.byref(cfg), rv, P(np.ascontiguousarray(payload, np.uint8)), P(e)) == 0
+    return e
+
+
+def sch_nr_decode_tb(cfg, rv, scaling_fctr, max_iter, llr, softbuf, cb_crc, cb_data):
+    """orc_sch_nr_decode_tb: softbuf [C, stride] int8, cb_crc [C] uint8 and cb_data [C, stride] uint8 are updated; returns
+    (payload bytes, crc_ok, avg_iter)"""
+    out = np.zeros(cfg.A // 8, np.uint8)
+    ok, avg = C.c_int(0), C.c_float(0)
+    f = orc().orc_sch_nr_decode_tb
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                  C.c_void_p, C.c_void_p]
+    llr = np.ascontiguousarray(llr, np.int8)
+    assert f(C.byref(cfg), rv, scaling_fctr, max_iter, P(llr) if llr.size else None, P(softbuf), softbuf.shape[1], P(cb_crc), P(cb_data),
+             cb_data.shape[1], P(out), C.byref(ok), C.byref(avg)) == 0
+    return out, ok.value, avg.value

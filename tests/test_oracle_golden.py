@@ -264,3 +264,33 @@ def test_live_against_compiled_reference():
         for n in (8, 40, 41, 47, 1000, 8424):
             bits = rng.integers(0, 2, n).astype(np.uint8)
             assert ref.srsran_crc_checksum(crc, O.P(bits), n) == O.orc().orc_crc_bits(poly, order, O.P(bits), n), (poly, n)
+
+
+def test_sch_nr_matches_reference_chain():
+    """orc_sch_nr.c (segmentation, sch_nr_encode, sch_nr_decode) against the fixture made from the reference's own blocks in the
+    order sch_nr.c calls them (tools/gen_golden.py sch_nr): e bits, code-block verdicts, iteration sums, soft buffers, payload, TB CRC"""
+    import zlib
+
+    d = np.load(os.path.join(G, "sch_nr_ref.npz"))
+    for key in d["cases"]:
+        tbs, R1000, mod, rv, Nl, Gb, Nref, max_iter, Cn, Z, Kr, Kp, F, L_tb, L_cb, bg, n_tx = [int(v) for v in d[key + "_par"]]
+        cfg = O.sch_nr_tb_info(tbs, R1000 / 1000.0, mod, Gb, Nl, Nref)
+        assert (cfg.bg, cfg.C, cfg.Z, cfg.Kr, cfg.Kp, cfg.F, cfg.L_tb, cfg.L_cb) == (bg, Cn, Z, Kr, Kp, F, L_tb, L_cb), key
+        N = Z * (66 if bg == 0 else 50)
+        softbuf = np.zeros((Cn, N), np.int8)
+        cb_crc = np.zeros(Cn, np.uint8)
+        cb_data = np.zeros((Cn, (Kr + 7) // 8), np.uint8)
+        for t in range(n_tx):
+            k = "%s_t%d" % (key, t)
+            rv_t = rv if t == 0 else 2
+            e = O.sch_nr_encode_tb(cfg, rv_t, d[key + "_payload"])
+            assert np.array_equal(np.packbits(e), d[k + "_e"]), k
+            assert np.array_equal(cb_crc, d[k + "_crc_in"])
+            out, ok, avg = O.sch_nr_decode_tb(cfg, rv_t, 0.8, max_iter, d[k + "_llr"], softbuf, cb_crc, cb_data)
+            assert np.array_equal(cb_crc, d[k + "_crc_out"]), k
+            assert (ok, round(avg * Cn)) == tuple(int(v) for v in d[k + "_res"]), k
+            assert zlib.crc32(softbuf.tobytes()) == int(d[k + "_soft_crc"][0]), k
+            if cb_crc.all():
+                assert np.array_equal(out, d[k + "_out"]), k
+                if ok:
+                    assert np.array_equal(out, d[key + "_payload"]), k

@@ -23,6 +23,8 @@ No reference source text is stored.
   tests/golden/ldpc_flood_ref.npz reference SRSRAN_LDPC_DECODER_C_FLOOD (scalar flooded schedule) outputs on seeded LLRs
   tests/golden/tcod_lut_ref.npz reference srsran_tcod_encode_lut (inputs after the call, parity bytes, running CRC state) and
                                srsran_rm_turbo_tx_lut (outputs at several bit offsets / lengths / redundancy versions)
+  tests/golden/sch_nr_ref.npz  NR transport blocks through the reference's blocks in the order of sch_nr.c (segmentation, CRCs, LDPC encoder,
+                               rate matcher both ways, decoder with CRC early stop): LLRs in, verdicts / iterations / payload out
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
 """
 import ctypes as C
@@ -516,8 +518,150 @@ def modem():
     print("modem_ref.npz", os.path.getsize(os.path.join(OUT, "modem_ref.npz")))
 
 
+def sch_nr():
+    """NR transport blocks as sch_nr.c chains the reference's blocks (sch_nr_encode :375-520, sch_nr_decode :522-713; segmentation by
+    srsran_cbsegm_ldpc_bg1/2): payload -> e bits -> noisy int8 LLRs -> code-block verdicts, iterations, payload, TB CRC; one case
+    with a second transmission (rv 2) for the code blocks the first left undecoded"""
+    class Cbsegm(C.Structure):  # srsran_cbsegm_t, cbsegm.h
+        _fields_ = [(n, C.c_uint32) for n in ("F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs", "L_tb", "L_cb", "Z")]
+
+    class Args(C.Structure):
+        _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_int)]
+
+    def crc_new(poly, order):
+        q = C.create_string_buffer(4096)
+        assert ref.srsran_crc_init(q, C.c_uint32(poly), C.c_int(order)) == 0
+        return q
+
+    ref.srsran_crc_checksum_byte.restype = C.c_uint32
+    crc24a, crc24b, crc16 = crc_new(0x1864CFB, 24), crc_new(0x1800063, 24), crc_new(0x11021, 16)
+    QMS = [1, 2, 4, 6, 8]
+    rng = np.random.default_rng(2104)
+    d, cases = {}, []
+    #        tbs    R     mod rv Nl  G      Nref  amp  sigma  max_iter retransmit
+    cfgs = ((24, 0.2, 1, 0, 1, 240, 0, 10.0, 8.0, 10, False),
+            (3000, 0.5, 1, 0, 1, 6400, 0, 12.0, 9.0, 10, False),
+            (3840, 0.5, 2, 1, 1, 8000, 0, 12.0, 7.0, 8, False),
+            (20040, 0.8, 3, 0, 2, 26400, 0, 14.0, 5.5, 10, False),
+            (20040, 0.8, 3, 0, 1, 25200, 17000, 14.0, 4.0, 6, False),
+            (50184, 0.75, 4, 0, 1, 67200, 0, 16.0, 5.0, 10, False),
+            (50184, 0.9, 4, 0, 1, 55680, 0, 16.0, 6.8, 4, True))
+    for tbs, R, mod, rv, Nl, G, Nref_in, amp, sigma, max_iter, retx in cfgs:
+        bg = 1 if (tbs <= 292 or (tbs <= 3824 and R <= 0.67) or R <= 0.25) else 0
+        seg = Cbsegm()
+        assert (ref.srsran_cbsegm_ldpc_bg2 if bg else ref.srsran_cbsegm_ldpc_bg1)(C.byref(seg), C.c_uint32(tbs)) == 0
+        Cn, Z, Kr, L_tb, L_cb, Qm = seg.C, seg.Z, seg.K1, seg.L_tb, seg.L_cb, QMS[mod]
+        Bp = tbs + L_tb + L_cb * Cn
+        assert Bp % Cn == 0
+        Kp = Bp // Cn
+        F = Kr - Kp
+        N = Z * (66 if bg == 0 else 50)
+        Nref = Nref_in if Nref_in else N
+        crc_tb = crc24a if L_tb == 24 else crc16
+
+        def get_E(j):
+            q = Nl * Qm
+            return q * (G // (q * Cn)) if j <= Cn - (G // q) % Cn - 1 else q * -(-G // (q * Cn))
+
+        payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+        checksum_tb = ref.srsran_crc_checksum_byte(crc_tb, P(payload), C.c_int(tbs))
+        enc = C.create_string_buffer(256)
+        assert ref.srsran_ldpc_encoder_init(enc, 0, bg, C.c_uint16(Z)) == 0
+        rmt = C.create_string_buffer(64)
+        assert ref.srsran_ldpc_rm_tx_init(rmt) == 0
+        bits = np.unpackbits(payload)
+
+        def transmit(rv_):
+            out, inp = [], 0
+            for r in range(Cn):
+                cb_len = Kp - L_cb - (L_tb if r == Cn - 1 else 0)
+                cb = np.zeros(Kr, np.uint8)
+                cb[:cb_len] = bits[inp:inp + cb_len]
+                if r == Cn - 1:
+                    cb[cb_len:cb_len + L_tb] = [(checksum_tb >> (L_tb - 1 - i)) & 1 for i in range(L_tb)]
+                inp += cb_len // 8 * 8
+                if L_cb:
+                    ref.srsran_crc_attach(crc24b, P(cb), C.c_int(Kp - L_cb))
+                cb[Kp:] = 254
+                cw = np.zeros(N, np.uint8)
+                assert ref.srsran_ldpc_encoder_encode(enc, P(cb), P(cw), C.c_uint32(Kr)) == 0
+                E = get_E(r)
+                tx = np.zeros(E, np.uint8)
+                ref.srsran_ldpc_rm_tx(rmt, P(cw), P(tx), C.c_uint32(E), C.c_int(bg), C.c_uint32(Z), C.c_uint8(rv_), C.c_int(mod), C.c_uint32(Nref))
+                out.append(tx)
+            return out
+
+        def channel(tx):
+            y = amp * (1.0 - 2.0 * tx) + sigma * rng.standard_normal(tx.size)
+            return np.clip(np.round(y), -63, 63).astype(np.int8)
+
+        dec = C.create_string_buffer(4096)
+        a = Args(2, bg, Z, 0.8, max_iter)
+        assert ref.srsran_ldpc_decoder_init(dec, C.byref(a)) == 0
+        rmr = C.create_string_buffer(64)
+        assert ref.srsran_ldpc_rm_rx_init_c(rmr) == 0
+        softbuf = np.zeros((Cn, N), np.int8)
+        cb_crc = np.zeros(Cn, np.uint8)
+        cb_data = np.zeros((Cn, (Kr + 7) // 8), np.uint8)
+        key = "tbs%d_m%d_rv%d_g%d_n%d" % (tbs, mod, rv, G, Nref_in)
+        rounds = [rv] + ([2] if retx else [])
+        for ti, rv_ in enumerate(rounds):
+            segs = transmit(rv_)
+            llr_all = np.concatenate([channel(segs[r]) for r in range(Cn) if not cb_crc[r]] + [np.zeros(0, np.int8)])
+            crc_before = cb_crc.copy()
+            inp, it_sum, its = 0, 0, []
+            for r in range(Cn):
+                E = get_E(r)
+                if cb_crc[r]:
+                    its.append(-1)
+                    continue
+                n_llr = ref.srsran_ldpc_rm_rx_c(rmr, P(llr_all[inp:inp + E].copy()), P(softbuf[r]), C.c_uint32(E), C.c_uint32(F), C.c_int(bg), C.c_uint32(Z),
+                                                C.c_uint8(rv_), C.c_int(mod), C.c_uint32(Nref))
+                assert n_llr > 0
+                crc = crc24b if L_cb else crc_tb
+                temp = np.zeros(Kr, np.uint8)
+                ret = ref.srsran_ldpc_decoder_decode_crc_c(dec, P(softbuf[r]), P(temp), C.c_uint32(n_llr), crc)
+                assert ret >= 0
+                its.append(ret)
+                it_sum += max_iter if ret == 0 else ret
+                cb_len = Kp - L_cb
+                cb_crc[r] = 1 if (ret != 0 and temp[:cb_len].any()) else 0
+                if cb_crc[r]:
+                    cb_data[r, :cb_len // 8] = np.packbits(temp[:cb_len])
+                inp += E
+            out = np.zeros(tbs // 8, np.uint8)
+            crc_ok = 0
+            if cb_crc.all():
+                parts = []
+                for r in range(Cn):
+                    cb_len = Kp - L_cb - (L_tb if r == Cn - 1 else 0)
+                    parts.append(cb_data[r, :cb_len // 8])
+                out = np.concatenate(parts)
+                if Cn == 1:
+                    crc_ok = 1
+                else:
+                    last = np.unpackbits(cb_data[Cn - 1])[Kp - L_cb - L_tb:Kp - L_cb]
+                    c2 = int("".join(map(str, last)), 2)
+                    crc_ok = int(ref.srsran_crc_checksum_byte(crc_tb, P(out), C.c_int(tbs)) == c2)
+            k = key + "_t%d" % ti
+            d[k + "_llr"], d[k + "_crc_in"], d[k + "_crc_out"], d[k + "_its"] = llr_all, crc_before, cb_crc.copy(), np.array(its, np.int32)
+            d[k + "_res"] = np.array([crc_ok, it_sum], np.int32)
+            d[k + "_out"] = out
+            d[k + "_e"] = np.packbits(np.concatenate(segs))
+            d[k + "_soft_crc"] = np.array([zlib.crc32(softbuf.tobytes())], np.int64)
+        d[key + "_par"] = np.array([tbs, int(round(R * 1000)), mod, rv, Nl, G, Nref, max_iter, Cn, Z, Kr, Kp, F, L_tb, L_cb, bg, len(rounds)], np.int32)
+        d[key + "_payload"] = payload
+        cases.append(key)
+        ref.srsran_ldpc_decoder_free(dec)
+        print(key, "C", Cn, "Z", Z, "F", F, "crc", [int(x) for x in d[key + "_t%d_res" % (len(rounds) - 1)]], "cb", d[key + "_t%d_crc_out" % (len(rounds) - 1)].tolist(),
+              [d[key + "_t%d_its" % t].tolist() for t in range(len(rounds))])
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "sch_nr_ref.npz"), **d)
+    print("sch_nr_ref.npz", os.path.getsize(os.path.join(OUT, "sch_nr_ref.npz")))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr}[name]()

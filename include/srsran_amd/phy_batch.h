@@ -75,6 +75,12 @@ SRSRAN_API int  srsran_hip_ldpc_batch_run_typed(srsran_hip_ldpc_batch_t* h, cons
 SRSRAN_API int  srsran_hip_ldpc_batch_run_crc(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride, uint8_t* d_message,
                                               uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint32_t crc_polynom,
                                               uint32_t crc_order, int32_t* d_nof_iterations, void* stream);
+/* The same with an indirection: code word i of the batch lives in row d_cw_map[i] of the LLR / message arrays (strides as above);
+ * d_nof_iterations is indexed by i.  What sch_nr_decode (sch_nr.c:567-665) needs to decode the not yet decoded code blocks of a
+ * soft buffer in place. */
+SRSRAN_API int  srsran_hip_ldpc_batch_run_crc_map(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                                                  uint32_t msg_stride, const uint32_t* d_cw_map, uint32_t n_cw, uint32_t cdwd_rm_length,
+                                                  uint32_t crc_polynom, uint32_t crc_order, int32_t* d_nof_iterations, void* stream);
 SRSRAN_API void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h);
 /* d_llrs   : n_cw x (N-2Z) int8 (only the first cdwd_rm_length... all N-2Z are read, as the reference does),
  *            `llr_stride` bytes apart;  d_message: n_cw x K bytes, one bit per byte, `msg_stride` apart.

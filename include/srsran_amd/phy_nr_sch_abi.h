@@ -104,6 +104,42 @@ SRSRAN_API int srsran_hip_ldpc_rm_tx_batch(srsran_hip_nr_sch_t* h, const uint8_t
 SRSRAN_API int srsran_hip_ldpc_encode_batch(srsran_hip_nr_sch_t* h, const uint8_t* d_messages, uint8_t* d_codewords,
                                             const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb, srsran_basegraph_t bg, uint32_t ls, void* stream);
 
+/* ---- NR shared channel, receive side for batches of transport blocks: sch_nr_decode (lib/src/phy/phch/sch_nr.c:522-713, reached
+ * through srsran_dlsch_nr_decode / srsran_ulsch_nr_decode :724-749) with segmentation by srsran_cbsegm_ldpc_bg1/2 (cbsegm.c:159-285).
+ * Buffers are device resident except `cb_crc` (the softbuffer.rx->cb_crc flags, host, in / out) and the results.
+ *   d_softbuffer : rows of `sb_stride` int8, one per code block: softbuffer buffer_b[r], accumulated over transmissions
+ *   d_cb_data    : rows of `data_stride` bytes: softbuffer.rx->data[r], the packed bits of decoded code blocks
+ * A transport block names its first row in both (first_cb); rows of different transport blocks must not overlap. */
+typedef struct {
+  double   R;              /* target code rate (base-graph choice, sch_nr.c:35-45) */
+  uint32_t tbs;            /* transport block size A in bits */
+  uint32_t mod;            /* srsran_mod_t */
+  uint32_t rv;
+  uint32_t N_L;            /* layers */
+  uint32_t nof_bits;       /* G */
+  uint32_t Nref;           /* limited-buffer rate-matching size (sch_nr.c:119-126 derive it from the carrier); 0: full buffer */
+  uint32_t e_offset;       /* first LLR of this transport block in d_e_bits (those of its still undecoded blocks, back to back, :665) */
+  uint32_t payload_offset; /* bytes into d_payload */
+  uint32_t first_cb;
+  uint32_t reserved;
+} srsran_hip_nr_tb_t;
+
+typedef struct {
+  int32_t  crc_ok;      /* res->crc (false when not every code block is decoded, where the reference leaves it untouched) */
+  int32_t  all_decoded; /* every code block has its CRC: payload written */
+  float    avg_iter;    /* res->avg_iter */
+  uint32_t nof_cb;
+} srsran_hip_nr_tb_result_t;
+
+typedef struct srsran_hip_sch_nr srsran_hip_sch_nr_t;
+/* scaling_fctr: 0 / NaN -> 0.8 (sch_nr.c:275); max_nof_iter 0 -> 10; max_cb: rows in the soft buffer / data arrays */
+SRSRAN_API int  srsran_hip_sch_nr_create(srsran_hip_sch_nr_t** h, float scaling_fctr, uint32_t max_nof_iter, uint32_t max_cb);
+SRSRAN_API void srsran_hip_sch_nr_free(srsran_hip_sch_nr_t* h);
+/* synchronises `stream` before it returns (verdicts and iteration counts come back to the host) */
+SRSRAN_API int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
+                                        int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,
+                                        uint8_t* d_payload, srsran_hip_nr_tb_result_t* res, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,6 +147,15 @@ class HipLdpcCb(C.Structure):
     _fields_ = [("in_offset", C.c_uint32), ("out_offset", C.c_uint32), ("E", C.c_uint32)]
 
 
+class HipNrTb(C.Structure):  # srsran_hip_nr_tb_t
+    _fields_ = [("R", C.c_double)] + [(n, C.c_uint32) for n in ("tbs", "mod", "rv", "N_L", "nof_bits", "Nref", "e_offset", "payload_offset",
+                                                                 "first_cb", "reserved")]
+
+
+class HipNrTbResult(C.Structure):
+    _fields_ = [("crc_ok", C.c_int32), ("all_decoded", C.c_int32), ("avg_iter", C.c_float), ("nof_cb", C.c_uint32)]
+
+
 class HipCell(C.Structure):
     _fields_ = [("peak_pos", C.c_int32), ("peak_value", C.c_float), ("psr", C.c_float), ("sss_available", C.c_int32),
                 ("m0", C.c_uint32), ("m1", C.c_uint32), ("m0_value", C.c_float), ("m1_value", C.c_float), ("N_id_1", C.c_int32),
@@ -234,6 +243,10 @@ def lib():
             "srsran_hip_ldpc_batch_create_typed": (i32, [C.POINTER(vp), i32, C.c_uint16, C.c_float, u32, u32, i32]),
             "srsran_hip_ldpc_batch_run_typed": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_run_crc": (i32, [vp, vp, u32, vp, u32, u32, u32, u32, u32, vp, vp]),
+            "srsran_hip_ldpc_batch_run_crc_map": (i32, [vp, vp, u32, vp, u32, vp, u32, u32, u32, u32, vp, vp]),
+            "srsran_hip_sch_nr_create": (i32, [C.POINTER(vp), C.c_float, u32, u32]),
+            "srsran_hip_sch_nr_free": (None, [vp]),
+            "srsran_hip_sch_nr_decode": (i32, [vp, vp, C.POINTER(HipNrTb), u32, vp, u32, vp, vp, u32, vp, C.POINTER(HipNrTbResult), vp]),
             "srsran_hip_ldpc_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_free": (None, [vp]),
             "srsran_hip_ldpc_batch_run": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),

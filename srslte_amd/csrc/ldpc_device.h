@@ -45,6 +45,9 @@ struct Params {
   // (x * M) >> 9 == x * sf / 100 for every x in 0..127, or 0 when there is no such M
   int             packed;
   int             sf_m9;
+  // optional indirection: code word i of the batch reads its LLRs from / writes its message to row cw_map[i] (the NR
+  // transport-block loop decodes the not-yet-decoded code blocks of a soft buffer in place); n_iter_out stays indexed by i
+  const uint32_t* cw_map;
 };
 
 #define LDPC_MAX_SLOTS 4096 // resident workgroup slots (256 CUs x up to 4); each owns one c2v slab per code word it holds

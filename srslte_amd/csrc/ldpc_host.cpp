@@ -268,7 +268,7 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
 
 static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
-                          void* stream, uint32_t crc_poly = 0, int crc_order = 0, int* d_n_iter = nullptr);
+                          void* stream, uint32_t crc_poly = 0, int crc_order = 0, int* d_n_iter = nullptr, const uint32_t* d_cw_map = nullptr);
 
 extern "C" int srsran_hip_ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride,
                                          uint8_t* d_message, uint32_t msg_stride, uint32_t n_cw,
@@ -298,7 +298,7 @@ extern "C" SRSRAN_API int srsran_hip_ldpc_batch_run_dbg(srsran_hip_ldpc_batch_t*
 
 static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32_t llr_stride, uint8_t* d_message,
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
-                          void* stream, uint32_t crc_poly, int crc_order, int* d_n_iter)
+                          void* stream, uint32_t crc_poly, int crc_order, int* d_n_iter, const uint32_t* d_cw_map)
 {
   if (h && n_cw == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
@@ -347,6 +347,7 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.crc_order  = 0;
   p.crc_mult   = nullptr;
   p.n_iter_out = nullptr;
+  p.cw_map     = d_cw_map;
   if (crc_order) {
     if (crc_order < 8 || crc_order > 24 || h->dtype != ldpc::DT_I8 || !d_n_iter) {
       set_error("ldpc batch: CRC early stop needs the int8 decoder, a generator of order 8..24 and an iteration array");
@@ -421,6 +422,19 @@ extern "C" int srsran_hip_ldpc_batch_run_crc(srsran_hip_ldpc_batch_t* h, const i
   }
   return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, nullptr, nullptr, stream, crc_polynom, (int)crc_order,
                         (int*)d_nof_iterations);
+}
+
+// the same with an indirection: code word i lives in row d_cw_map[i] of the LLR / message arrays (the NR transport-block loop
+// decodes the undecoded code blocks of a soft buffer where they lie); d_nof_iterations stays indexed by i
+extern "C" int srsran_hip_ldpc_batch_run_crc_map(srsran_hip_ldpc_batch_t* h, const int8_t* d_llrs, uint32_t llr_stride, uint8_t* d_message,
+                                                 uint32_t msg_stride, const uint32_t* d_cw_map, uint32_t n_cw, uint32_t cdwd_rm_length,
+                                                 uint32_t crc_polynom, uint32_t crc_order, int32_t* d_nof_iterations, void* stream)
+{
+  if (!crc_order || !d_nof_iterations || !d_cw_map) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  return ldpc_batch_run(h, d_llrs, llr_stride, d_message, msg_stride, n_cw, cdwd_rm_length, nullptr, nullptr, stream, crc_polynom, (int)crc_order,
+                        (int*)d_nof_iterations, d_cw_map);
 }
 
 // ------------------------------------------------------------------------------------------------ handle ABI

@@ -247,13 +247,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : PO
   for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
   const int  cw     = cw0 + cwl;
   const bool present = (cwl < p.cpb) && (cw < p.n_cw);
+  const int  cwi     = (present && p.cw_map) ? (int)p.cw_map[cw] : cw; // row of the LLR / message arrays
   bool       active  = present; // cleared once this code word's CRC matches (early stop): its state is then frozen
   int        it_done = 0;
   __syncthreads(); // the previous code word's message extraction has finished reading soft[]
 
   // init_ldpc_dec_c (ldpc_dec_c.c:170-188): punctured nodes 0,1 start at 0, all c2v at 0
   if (active) {
-    const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cw * p.llr_stride;
+    const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cwi * p.llr_stride;
     soft[c]     = 0;
     soft[Z + c] = 0;
     for (int n = 2; n < p.bgN; n++) {
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : PO
       // still applies).  Lane = position inside the lifted variable node.
       __syncthreads(); // all messages of this iteration are written
       if (active) {
-        const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cw * p.llr_stride;
+        const T* llr = reinterpret_cast<const T*>(p.llrs) + (size_t)cwi * p.llr_stride;
         for (int v = 0; v < p.bgN; v++) {
           typename POL::A acc = v < 2 ? 0 : (typename POL::A)llr[(v - 2) * Z + c];
           for (int ce = col_start[v]; ce < col_start[v + 1]; ce++) {
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : PO
     }
   }
   if (present) {
-    uint8_t* m = p.msg + (size_t)cw * p.msg_stride;
+    uint8_t* m = p.msg + (size_t)cwi * p.msg_stride;
     for (int i = c; i < liftK; i += Z) {
       m[i] = soft[i] < 0;
     }

@@ -157,13 +157,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
     const int  cw      = cw0 + cwl;
     const bool present = (cwl < p.cpb) && (cw < p.n_cw);
+    const int  cwi     = (present && p.cw_map) ? (int)p.cw_map[cw] : cw; // row of the LLR / message arrays
     bool       active  = present;
     int        it_done = 0;
     __syncthreads(); // the previous code word's message extraction has finished reading the soft words
 
     // init_ldpc_dec_c (ldpc_dec_c.c:170-188)
     if (active) {
-      const int8_t* llr = reinterpret_cast<const int8_t*>(p.llrs) + (size_t)cw * p.llr_stride;
+      const int8_t* llr = reinterpret_cast<const int8_t*>(p.llrs) + (size_t)cwi * p.llr_stride;
       soft2[c]     = 0;
       soft2[H + c] = 0;
       for (int n = 2; n < p.bgN; n++) {
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
     // extract_ldpc_message_c (:323-336)
     if (present) {
-      uint8_t* m   = p.msg + (size_t)cw * p.msg_stride;
+      uint8_t* m   = p.msg + (size_t)cwi * p.msg_stride;
       uint32_t col = 0, pos = (uint32_t)c;
       for (int i = c; i < liftK; i += (int)H) {
         const uint32_t half = pos >= H ? 1u : 0u;

@@ -50,5 +50,24 @@ struct EncParams {
 
 hipError_t launch_encode(const EncParams& p, hipStream_t stream);
 
+// ---- transport-block loop of sch_nr_decode (sch_nr.c:620-712) behind the decoder
+struct CbFin {       // one code block that has just been through the decoder
+  uint32_t msg_row;  // row of the decoder's message array (one bit per byte)
+  uint32_t cb_index; // global code-block index: flag and packed-data row
+  uint32_t cb_len;   // Kp - L_cb bits (a multiple of 8)
+};
+struct TbFin {
+  uint32_t first_cb, C, Kp, L_cb, L_tb, tbs, payload_off;
+};
+struct TbFinRes {
+  int32_t all_decoded; // every code block of the transport block has its flag set
+  int32_t crc_ok;      // :696-705 (single code block: true; otherwise the transport CRC over the payload matches)
+};
+// flag = (iterations != 0) && !all_zeros (:633-639); flagged blocks are packed MSB first into their data row (:650-652)
+hipError_t launch_cb_finish(const uint8_t* d_msg, uint32_t msg_stride, const CbFin* d_jobs, const int* d_n_iter, uint32_t n, uint8_t* d_flags,
+                            uint8_t* d_cb_data, uint32_t data_stride, hipStream_t stream);
+hipError_t launch_tb_finish(const uint8_t* d_cb_data, uint32_t data_stride, const uint8_t* d_flags, const TbFin* d_jobs, uint32_t n, uint8_t* d_payload,
+                            TbFinRes* d_res, hipStream_t stream);
+
 } // namespace nrsch
 } // namespace phyhip

@@ -291,5 +291,136 @@ hipError_t launch_encode(const EncParams& p, hipStream_t stream)
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ transport-block loop
+// sch_nr.c:633-652: a code block counts as decoded when the CRC stopped the decoder AND its bits are not all zero; its bits are
+// then packed MSB first.  One workgroup per code block.
+__global__ __launch_bounds__(256) void cb_finish_kernel(const uint8_t* msg, uint32_t msg_stride, const CbFin* jobs, const int* n_iter, uint8_t* flags,
+                                                        uint8_t* cb_data, uint32_t data_stride)
+{
+  const CbFin    jb   = jobs[blockIdx.x];
+  const uint8_t* bits = msg + (size_t)jb.msg_row * msg_stride;
+  const uint32_t nb   = (jb.cb_len + 7) / 8;
+  int            any  = 0;
+  for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+    for (uint32_t k = 0; k < 8 && b * 8 + k < jb.cb_len; k++) {
+      any |= bits[b * 8 + k];
+    }
+  }
+  const bool ok = __syncthreads_or(any) != 0 && n_iter[blockIdx.x] != 0;
+  if (threadIdx.x == 0) {
+    flags[jb.cb_index] = ok ? 1 : 0;
+  }
+  if (!ok) {
+    return;
+  }
+  uint8_t* d = cb_data + (size_t)jb.cb_index * data_stride;
+  for (uint32_t b = threadIdx.x; b < nb; b += 256) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 8 && b * 8 + k < jb.cb_len; k++) {
+      v |= (uint32_t)(bits[b * 8 + k] & 1u) << (7 - k);
+    }
+    d[b] = (uint8_t)v;
+  }
+}
+
+__device__ __forceinline__ uint32_t gf_mulmod_n(uint32_t a, uint32_t b, uint32_t poly, uint32_t order)
+{
+  const uint32_t mask = (1u << order) - 1u;
+  uint32_t       r    = 0;
+  for (int i = (int)order - 1; i >= 0; i--) {
+    r = ((r << 1) & mask) ^ (((r >> (order - 1)) & 1u) ? poly : 0u);
+    r ^= ((b >> i) & 1u) ? a : 0u;
+  }
+  return r;
+}
+
+// sch_nr.c:667-705: when every code block of a transport block is decoded, append their payload parts, take the transport CRC
+// carried behind the payload in the last block and compare it with the CRC of the payload (CRC24A above 3824 bits, else CRC16;
+// crc.c, MSB first, zero initial state).  One workgroup per transport block; the CRC is split over the lanes and recombined with
+// x^(bits behind the lane's chunk) mod g.
+__global__ __launch_bounds__(256) void tb_finish_kernel(const uint8_t* cb_data, uint32_t data_stride, const uint8_t* flags, const TbFin* jobs,
+                                                        uint8_t* payload, TbFinRes* res)
+{
+  __shared__ uint32_t red[256];
+  const TbFin jb  = jobs[blockIdx.x];
+  int         bad = 0;
+  for (uint32_t r = threadIdx.x; r < jb.C; r += 256) {
+    bad |= flags[jb.first_cb + r] ? 0 : 1;
+  }
+  if (__syncthreads_or(bad)) {
+    if (threadIdx.x == 0) {
+      res[blockIdx.x].all_decoded = 0;
+      res[blockIdx.x].crc_ok      = 0;
+    }
+    return;
+  }
+  const uint32_t per = (jb.Kp - jb.L_cb) / 8; // payload bytes of every code block but the last
+  const uint32_t nb  = jb.tbs / 8;
+  auto byte_at = [&](uint32_t i) {
+    const uint32_t r = i / per;
+    return cb_data[(size_t)(jb.first_cb + r) * data_stride + (i - r * per)];
+  };
+  const uint32_t order = jb.L_tb, mask = (1u << order) - 1u, poly = (order == 24 ? 0x1864CFBu : 0x11021u) & mask;
+  const uint32_t c  = (nb + 255) / 256;
+  const uint32_t lo = threadIdx.x * c, hi = lo + c < nb ? lo + c : nb;
+  uint32_t       crc = 0;
+  uint8_t*       out = payload + jb.payload_off;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t byte = byte_at(i);
+    out[i]              = (uint8_t)byte;
+    for (int b = 7; b >= 0; b--) {
+      crc = ((crc << 1) & mask) ^ ((((crc >> (order - 1)) ^ (byte >> b)) & 1u) ? poly : 0u);
+    }
+  }
+  if (lo < nb) {
+    uint32_t e = 8 * (nb - hi), result = 1, base = 2; // x^e mod g
+    while (e) {
+      if (e & 1) {
+        result = gf_mulmod_n(result, base, poly, order);
+      }
+      base = gf_mulmod_n(base, base, poly, order);
+      e >>= 1;
+    }
+    crc = gf_mulmod_n(crc, result, poly, order);
+  }
+  red[threadIdx.x] = lo < nb ? crc : 0u;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x] ^= red[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint32_t       checksum2 = 0;
+    const uint32_t last      = jb.C - 1, at = nb - last * per; // byte behind the payload part of the last block
+    for (uint32_t i = 0; i < order / 8; i++) {
+      checksum2 = (checksum2 << 8) | cb_data[(size_t)(jb.first_cb + last) * data_stride + at + i];
+    }
+    res[blockIdx.x].all_decoded = 1;
+    res[blockIdx.x].crc_ok      = (jb.C == 1 || red[0] == checksum2) ? 1 : 0;
+  }
+}
+
+hipError_t launch_cb_finish(const uint8_t* d_msg, uint32_t msg_stride, const CbFin* d_jobs, const int* d_n_iter, uint32_t n, uint8_t* d_flags,
+                            uint8_t* d_cb_data, uint32_t data_stride, hipStream_t stream)
+{
+  if (n == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(cb_finish_kernel, dim3(n), dim3(256), 0, stream, d_msg, msg_stride, d_jobs, d_n_iter, d_flags, d_cb_data, data_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_tb_finish(const uint8_t* d_cb_data, uint32_t data_stride, const uint8_t* d_flags, const TbFin* d_jobs, uint32_t n, uint8_t* d_payload,
+                            TbFinRes* d_res, hipStream_t stream)
+{
+  if (n == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(tb_finish_kernel, dim3(n), dim3(256), 0, stream, d_cb_data, data_stride, d_flags, d_jobs, d_payload, d_res);
+  return hipGetLastError();
+}
+
 } // namespace nrsch
 } // namespace phyhip

@@ -1,0 +1,340 @@
+// sch_nr_host.cpp -- NR shared-channel receive side for batches of transport blocks: the loop of sch_nr_decode
+// (lib/src/phy/phch/sch_nr.c:522-713) with every code block of every transport block of a call on the device at once.
+//   segmentation            srsran_cbsegm_ldpc_bg1/2 (cbsegm.c:159-285), srsran_sch_nr_fill_tb_info (sch_nr.c:77-144)
+//   rate de-matching        srsran_ldpc_rm_rx_c into the soft buffer (HARQ combining), one launch per (graph, Z, rv, Qm, Nref, F)
+//   decoding                srsran_ldpc_decoder_decode_crc_c with CRC24B / CRC24A / CRC16 early stop, one launch per (graph, Z, n_llr)
+//   code-block verdict      CRC matched and not all zero (:633-639), bits packed into the per-block data rows (:650-652)
+//   transport block         payload assembly and transport CRC (:667-705)
+// The only value taken from the caller instead of being derived is Nref (:119-126 compute it from the carrier with
+// srsran_ra_nr_tbs, the reference's resource-allocation code, which is outside this library).
+#include "hip_common.h"
+#include "nr_sch_device.h"
+#include "srsran_amd/phy_batch.h"
+#include "srsran_amd/phy_modem_abi.h"
+#include "srsran_amd/phy_nr_sch_abi.h"
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <tuple>
+#include <vector>
+
+using namespace phyhip;
+
+extern "C" const uint8_t LSindex[385]; // ldpc_host.cpp (base_graph.c:50)
+
+namespace {
+
+struct TbCfg { // srsran_sch_nr_tb_info_t
+  int      bg;
+  uint32_t Qm, A, L_tb, L_cb, B, Bp, Kp, Kr, F, Z, G, Nl, Nref, C, N;
+};
+
+// srsran_sch_nr_fill_tb_info with cbsegm_ldpc; false where the reference fails
+bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
+{
+  static const uint32_t qm[5] = {1, 2, 4, 6, 8};
+  if (tb.tbs == 0 || tb.mod > 4 || tb.N_L == 0 || tb.rv > 3) {
+    return false;
+  }
+  c->bg = ((tb.tbs <= 292) || (tb.tbs <= 3824 && tb.R <= 0.67) || (tb.R <= 0.25)) ? 1 : 0; // sch_nr.c:35-45
+  const uint32_t L = tb.tbs <= 3824 ? 16 : 24, K_cb = c->bg == 0 ? 8448 : 3840, B = tb.tbs + L;
+  uint32_t       C, Bp;
+  if (B <= K_cb) { // cbsegm_cb_size, cbsegm.c:51-60
+    C  = 1;
+    Bp = B;
+  } else {
+    C  = (B + (K_cb - 24) - 1) / (K_cb - 24);
+    Bp = B + 24 * C;
+  }
+  const uint32_t Kp  = Bp / C;
+  uint32_t       K_b = 22;
+  if (c->bg == 1) {
+    K_b = B > 640 ? 10 : (B > 560 ? 9 : (B > 192 ? 8 : 6));
+  }
+  uint32_t Z = (Kp + K_b - 1) / K_b;
+  while (Z <= 384 && LSindex[Z] == 0xFF) { // cbsegm_ldpc_select_ls (VOID_LIFTSIZE = 255)
+    Z++;
+  }
+  if (Z > 384) {
+    return false;
+  }
+  c->Qm   = qm[tb.mod];
+  c->A    = tb.tbs;
+  c->L_tb = L;
+  c->L_cb = C > 1 ? 24 : 0;
+  c->B    = B;
+  c->Bp   = B + c->L_cb * C;
+  c->Kp   = c->Bp / C;
+  c->Kr   = Z * (c->bg == 0 ? 22u : 10u);
+  c->F    = c->Kr - c->Kp;
+  c->Z    = Z;
+  c->G    = tb.nof_bits;
+  c->Nl   = tb.N_L;
+  c->N    = Z * (c->bg == 0 ? 66u : 50u);
+  c->Nref = tb.Nref ? tb.Nref : c->N;
+  c->C    = C;
+  return true;
+}
+
+uint32_t get_E(const TbCfg& c, uint32_t j) // sch_nr_get_E, sch_nr.c:146-157 (all code blocks transmitted)
+{
+  const uint32_t q = c.Nl * c.Qm;
+  if (j <= (c.C - (c.G / q) % c.C - 1)) {
+    return q * (c.G / (q * c.C));
+  }
+  return q * ((c.G + q * c.C - 1) / (q * c.C));
+}
+
+struct Job {
+  uint32_t tb, cb, E, in_off, n_llr, cb_len;
+  int      bg;
+  uint32_t Z, rv, mod, Nref, F, poly, order;
+};
+
+template <class T>
+bool ensure(T** d, T** h, size_t* cap, size_t n)
+{
+  if (n <= *cap) {
+    return true;
+  }
+  (void)hipFree(*d);
+  (void)hipHostFree(*h);
+  *d = nullptr, *h = nullptr, *cap = 0;
+  const size_t c = n + n / 2 + 16;
+  if (hipMalloc(d, c * sizeof(T)) != hipSuccess || hipHostMalloc(h, c * sizeof(T)) != hipSuccess) {
+    return false;
+  }
+  *cap = c;
+  return true;
+}
+
+} // namespace
+
+struct srsran_hip_sch_nr {
+  float    scaling = 0.8f;
+  uint32_t max_iter = 10, max_cb = 0;
+  srsran_hip_nr_sch_t*                         rm = nullptr;
+  std::map<uint32_t, srsran_hip_ldpc_batch_t*> dec; // bg << 16 | Z
+  uint8_t*  d_msg   = nullptr; // max_cb x MSG_STRIDE, one bit per byte
+  uint8_t*  d_flags = nullptr; // max_cb
+  uint8_t*  h_flags = nullptr; // pinned
+  int *     d_iter = nullptr, *h_iter = nullptr;
+  size_t    iter_cap = 0;
+  uint32_t *d_map = nullptr, *h_map = nullptr;
+  size_t    map_cap = 0;
+  nrsch::CbFin *d_cbf = nullptr, *h_cbf = nullptr;
+  size_t        cbf_cap = 0;
+  nrsch::TbFin *d_tbf = nullptr, *h_tbf = nullptr;
+  size_t        tbf_cap = 0;
+  nrsch::TbFinRes *d_res = nullptr, *h_res = nullptr;
+  size_t           res_cap = 0;
+};
+static const uint32_t MSG_STRIDE = 8448;
+
+extern "C" int srsran_hip_sch_nr_create(srsran_hip_sch_nr_t** hh, float scaling_fctr, uint32_t max_nof_iter, uint32_t max_cb)
+{
+  if (!hh || max_cb == 0 || max_cb > 65535) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *hh = nullptr;
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  auto* h     = new srsran_hip_sch_nr;
+  h->scaling  = std::isnormal(scaling_fctr) ? scaling_fctr : 0.8f; // sch_nr.c:275
+  h->max_iter = max_nof_iter ? max_nof_iter : 10;                  // ldpc_decoder.c:42,579
+  h->max_cb   = max_cb;
+  if (srsran_hip_nr_sch_create(&h->rm) != SRSRAN_SUCCESS || hipMalloc(&h->d_msg, (size_t)max_cb * MSG_STRIDE) != hipSuccess ||
+      hipMalloc(&h->d_flags, max_cb) != hipSuccess || hipHostMalloc(&h->h_flags, max_cb) != hipSuccess) {
+    srsran_hip_sch_nr_free(h);
+    return SRSRAN_ERROR;
+  }
+  *hh = h;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" void srsran_hip_sch_nr_free(srsran_hip_sch_nr_t* h)
+{
+  if (!h) {
+    return;
+  }
+  srsran_hip_nr_sch_free(h->rm);
+  for (auto& kv : h->dec) {
+    srsran_hip_ldpc_batch_free(kv.second);
+  }
+  (void)hipFree(h->d_msg);
+  (void)hipFree(h->d_flags);
+  (void)hipHostFree(h->h_flags);
+  (void)hipFree(h->d_iter), (void)hipHostFree(h->h_iter);
+  (void)hipFree(h->d_map), (void)hipHostFree(h->h_map);
+  (void)hipFree(h->d_cbf), (void)hipHostFree(h->h_cbf);
+  (void)hipFree(h->d_tbf), (void)hipHostFree(h->h_tbf);
+  (void)hipFree(h->d_res), (void)hipHostFree(h->h_res);
+  delete h;
+}
+
+extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
+                                        int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,
+                                        uint8_t* d_payload, srsran_hip_nr_tb_result_t* res, void* stream)
+{
+  if (h && n_tb == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  if (!h || !d_e_bits || !tbs || !d_softbuffer || !cb_crc || !d_cb_data || !d_payload || !res) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  hipStream_t        st = (hipStream_t)stream;
+  std::vector<TbCfg> cfg(n_tb);
+  std::vector<Job>   jobs;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    TbCfg& c = cfg[t];
+    if (!tb_cfg(tbs[t], &c)) {
+      set_error("sch_nr: transport block %u: invalid size / modulation / layers", t);
+      return SRSRAN_ERROR;
+    }
+    // soft-buffer protection (sch_nr.c:556-559) and the rows this library keeps per code block
+    if (tbs[t].first_cb + c.C > h->max_cb || sb_stride < c.N || data_stride < (c.Kr + 7) / 8 || c.Kr > MSG_STRIDE) {
+      set_error("sch_nr: transport block %u does not fit the soft buffer (%u code blocks of %u soft bits)", t, c.C, c.N);
+      return SRSRAN_ERROR;
+    }
+    uint32_t in = tbs[t].e_offset;
+    for (uint32_t r = 0; r < c.C; r++) {
+      const uint32_t cb = tbs[t].first_cb + r;
+      const uint32_t E  = get_E(c, r);
+      if (cb_crc[cb]) {
+        continue; // :584-588; the input pointer only advances for processed blocks (:665)
+      }
+      // n_llr of srsran_ldpc_rm_rx_c (ldpc_rm.c:704-705)
+      static const uint32_t basek0[4][2] = {{0, 0}, {17, 13}, {33, 25}, {56, 43}};
+      const uint32_t        Ncb = c.N <= c.Nref ? c.N : c.Nref;
+      const uint32_t        k0  = c.N <= c.Nref ? c.Z * basek0[tbs[t].rv][c.bg] : c.Z * ((basek0[tbs[t].rv][c.bg] * c.Nref) / c.N);
+      Job                   j;
+      j.tb = t, j.cb = cb, j.E = E, j.in_off = in, j.n_llr = std::min(k0 + E, Ncb), j.cb_len = c.Kp - c.L_cb;
+      j.bg = c.bg, j.Z = c.Z, j.rv = tbs[t].rv, j.mod = tbs[t].mod, j.Nref = c.Nref, j.F = c.F;
+      j.poly  = c.L_cb ? 0x1800063u : (c.L_tb == 24 ? 0x1864CFBu : 0x11021u); // :611-615
+      j.order = c.L_cb ? 24 : c.L_tb;
+      jobs.push_back(j);
+      in += E;
+    }
+  }
+  const uint32_t n_jobs = (uint32_t)jobs.size();
+  // flags of every code block of these transport blocks -> device
+  uint32_t cb_lo = 0xffffffffu, cb_hi = 0;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    cb_lo = std::min(cb_lo, tbs[t].first_cb);
+    cb_hi = std::max(cb_hi, tbs[t].first_cb + cfg[t].C);
+  }
+  for (uint32_t i = cb_lo; i < cb_hi; i++) {
+    h->h_flags[i] = cb_crc[i] ? 1 : 0;
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(h->d_flags + cb_lo, h->h_flags + cb_lo, cb_hi - cb_lo, hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+
+  if (n_jobs) {
+    // ---- rate de-matching, grouped by the parameters of init_rm
+    std::vector<uint32_t> order(n_jobs);
+    for (uint32_t i = 0; i < n_jobs; i++) {
+      order[i] = i;
+    }
+    auto rm_key = [&](const Job& j) { return std::make_tuple(j.bg, j.Z, j.rv, j.mod, j.Nref, j.F); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rm_key(jobs[a]) < rm_key(jobs[b]); });
+    std::vector<srsran_hip_ldpc_cb_t> cbs;
+    for (uint32_t i = 0; i < n_jobs;) {
+      uint32_t e = i;
+      cbs.clear();
+      while (e < n_jobs && rm_key(jobs[order[e]]) == rm_key(jobs[order[i]])) {
+        const Job& j = jobs[order[e]];
+        cbs.push_back(srsran_hip_ldpc_cb_t{j.in_off, j.cb * sb_stride, j.E});
+        e++;
+      }
+      const Job& j = jobs[order[i]];
+      if (srsran_hip_ldpc_rm_rx_batch(h->rm, SRSRAN_HIP_LLR_BYTE, d_e_bits, d_softbuffer, cbs.data(), (uint32_t)cbs.size(), j.F, (srsran_basegraph_t)j.bg,
+                                      j.Z, j.rv, (srsran_mod_t)j.mod, j.Nref, st) != SRSRAN_SUCCESS) {
+        set_error("sch_nr: rate de-matching refused (E=%u, Z=%u)", j.E, j.Z);
+        return SRSRAN_ERROR;
+      }
+      i = e;
+    }
+    // ---- decoding with CRC early stop, grouped by decoder and code-word length
+    auto dec_key = [&](const Job& j) { return std::make_tuple(j.bg, j.Z, j.n_llr, j.poly); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dec_key(jobs[a]) < dec_key(jobs[b]); });
+    if (!ensure(&h->d_iter, &h->h_iter, &h->iter_cap, n_jobs) || !ensure(&h->d_map, &h->h_map, &h->map_cap, n_jobs) ||
+        !ensure(&h->d_cbf, &h->h_cbf, &h->cbf_cap, n_jobs)) {
+      return SRSRAN_ERROR;
+    }
+    for (uint32_t i = 0; i < n_jobs; i++) {
+      const Job& j = jobs[order[i]];
+      h->h_map[i]  = j.cb;
+      h->h_cbf[i]  = nrsch::CbFin{j.cb, j.cb, j.cb_len};
+    }
+    PHY_HIP_CHECK(hipMemcpyAsync(h->d_map, h->h_map, n_jobs * sizeof(uint32_t), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpyAsync(h->d_cbf, h->h_cbf, n_jobs * sizeof(nrsch::CbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    for (uint32_t i = 0; i < n_jobs;) {
+      uint32_t e = i;
+      while (e < n_jobs && dec_key(jobs[order[e]]) == dec_key(jobs[order[i]])) {
+        e++;
+      }
+      const Job&     j   = jobs[order[i]];
+      const uint32_t key = ((uint32_t)j.bg << 16) | j.Z;
+      auto           it  = h->dec.find(key);
+      if (it == h->dec.end()) {
+        srsran_hip_ldpc_batch_t* d = nullptr;
+        if (srsran_hip_ldpc_batch_create(&d, (srsran_basegraph_t)j.bg, (uint16_t)j.Z, h->scaling, h->max_iter, h->max_cb) != SRSRAN_SUCCESS) {
+          return SRSRAN_ERROR;
+        }
+        it = h->dec.emplace(key, d).first;
+      }
+      if (srsran_hip_ldpc_batch_run_crc_map(it->second, d_softbuffer, sb_stride, h->d_msg, MSG_STRIDE, h->d_map + i, e - i, j.n_llr, j.poly, j.order,
+                                            h->d_iter + i, st) != SRSRAN_SUCCESS) {
+        return SRSRAN_ERROR;
+      }
+      i = e;
+    }
+    PHY_HIP_CHECK(nrsch::launch_cb_finish(h->d_msg, MSG_STRIDE, h->d_cbf, h->d_iter, n_jobs, h->d_flags, d_cb_data, data_stride, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpyAsync(h->h_iter, h->d_iter, n_jobs * sizeof(int), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    // ---- back to transport blocks
+    if (!ensure(&h->d_tbf, &h->h_tbf, &h->tbf_cap, n_tb) || !ensure(&h->d_res, &h->h_res, &h->res_cap, n_tb)) {
+      return SRSRAN_ERROR;
+    }
+    for (uint32_t t = 0; t < n_tb; t++) {
+      h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset};
+    }
+    PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_res, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpyAsync(h->h_flags + cb_lo, h->d_flags + cb_lo, cb_hi - cb_lo, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
+    std::vector<uint32_t> it_sum(n_tb, 0);
+    for (uint32_t i = 0; i < n_jobs; i++) {
+      const Job& j = jobs[order[i]];
+      it_sum[j.tb] += h->h_iter[i] == 0 ? h->max_iter : (uint32_t)h->h_iter[i]; // :629-631
+    }
+    for (uint32_t t = 0; t < n_tb; t++) {
+      for (uint32_t r = 0; r < cfg[t].C; r++) {
+        cb_crc[tbs[t].first_cb + r] = h->h_flags[tbs[t].first_cb + r];
+      }
+      res[t].all_decoded = h->h_res[t].all_decoded;
+      res[t].crc_ok      = h->h_res[t].crc_ok;
+      res[t].avg_iter    = (float)it_sum[t] / (float)cfg[t].C; // :657-661
+      res[t].nof_cb      = cfg[t].C;
+    }
+    return SRSRAN_SUCCESS;
+  }
+  // nothing left to decode (every code block already had its CRC): assembly and transport CRC only
+  if (!ensure(&h->d_tbf, &h->h_tbf, &h->tbf_cap, n_tb) || !ensure(&h->d_res, &h->h_res, &h->res_cap, n_tb)) {
+    return SRSRAN_ERROR;
+  }
+  for (uint32_t t = 0; t < n_tb; t++) {
+    h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset};
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_res, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
+  for (uint32_t t = 0; t < n_tb; t++) {
+    res[t].all_decoded = h->h_res[t].all_decoded;
+    res[t].crc_ok      = h->h_res[t].crc_ok;
+    res[t].avg_iter    = 0.0f;
+    res[t].nof_cb      = cfg[t].C;
+  }
+  return SRSRAN_SUCCESS;
+}

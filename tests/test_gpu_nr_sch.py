@@ -177,3 +177,82 @@ def test_encode_to_decode_chain_on_device(hiplib):
     want = msgs & 1
     assert np.array_equal(out, want)
     lib.srsran_hip_nr_sch_free(h)
+
+
+def test_transport_block_loop_matches_reference_chain(hiplib):
+    """srsran_hip_sch_nr_decode == sch_nr_decode (sch_nr.c:522-713) on the fixture made from the reference's blocks (tools/gen_golden.py
+    sch_nr): verdicts per code block, iteration sums, soft buffers, payload, transport CRC, incl. the second transmission of a
+    block the first one left undecoded; then every fixture block in ONE call (mixed base graphs, lifting sizes, modulations)"""
+    import ctypes as C
+    import os
+    import zlib
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "sch_nr_ref.npz"))
+    SB, DS = 66 * 384, 8448 // 8
+    h = C.c_void_p()
+    pars = {k: [int(v) for v in d[k + "_par"]] for k in d["cases"]}
+    # one handle per decoder iteration limit (the limit belongs to the handle, as decoder_args.max_nof_iter in sch_nr_init_rx)
+    for key in d["cases"]:
+        tbs, R1000, mod, rv, Nl, Gb, Nref, max_iter, Cn, Z, Kr, Kp, F, L_tb, L_cb, bg, n_tx = pars[key]
+        capi.check(hiplib.srsran_hip_sch_nr_create(C.byref(h), 0.8, max_iter, 16), "create")
+        N = Z * (66 if bg == 0 else 50)
+        d_soft = S.DeviceBuffer.from_numpy(np.zeros((16, SB), np.int8))
+        d_data = S.DeviceBuffer.from_numpy(np.zeros((16, DS), np.uint8))
+        d_pay = S.DeviceBuffer.from_numpy(np.zeros(tbs // 8 + 64, np.uint8))
+        cb_crc = np.zeros(16, np.uint8)
+        first = 3
+        for t in range(n_tx):
+            k = "%s_t%d" % (key, t)
+            llr = np.concatenate([np.zeros(5, np.int8), d[k + "_llr"]])
+            d_llr = S.DeviceBuffer.from_numpy(llr if llr.size else np.zeros(1, np.int8))
+            assert np.array_equal(cb_crc[first:first + Cn], d[k + "_crc_in"])
+            tb = (capi.HipNrTb * 1)(capi.HipNrTb(R1000 / 1000.0, tbs, mod, rv if t == 0 else 2, Nl, Gb, Nref, 5, 7, first, 0))
+            res = (capi.HipNrTbResult * 1)()
+            capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, tb, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None), k)
+            assert np.array_equal(cb_crc[first:first + Cn], d[k + "_crc_out"]), k
+            assert cb_crc[:first].sum() == 0 and cb_crc[first + Cn:].sum() == 0
+            ok_ref, it_sum = [int(v) for v in d[k + "_res"]]
+            assert (res[0].crc_ok, res[0].nof_cb, round(res[0].avg_iter * Cn)) == (ok_ref, Cn, it_sum), k
+            assert res[0].all_decoded == int(d[k + "_crc_out"].all())
+            soft = d_soft.to_numpy(np.int8, (16, SB))[first:first + Cn, :N]
+            assert zlib.crc32(np.ascontiguousarray(soft).tobytes()) == int(d[k + "_soft_crc"][0]), k
+            if res[0].all_decoded:
+                pay = d_pay.to_numpy(np.uint8, (tbs // 8 + 64,))
+                assert np.array_equal(pay[7:7 + tbs // 8], d[k + "_out"]), k
+                assert pay[:7].sum() == 0 and pay[7 + tbs // 8:].sum() == 0
+        hiplib.srsran_hip_sch_nr_free(h)
+    # all first transmissions of the blocks that share an iteration limit in one call
+    keys = [k for k in d["cases"] if pars[k][7] == 10]
+    capi.check(hiplib.srsran_hip_sch_nr_create(C.byref(h), 0.8, 10, 32), "create")
+    tb_arr, llrs, off_e, off_p, first = [], [], 0, 0, 0
+    for k in keys:
+        tbs, R1000, mod, rv, Nl, Gb, Nref, max_iter, Cn = pars[k][:9]
+        tb_arr.append(capi.HipNrTb(R1000 / 1000.0, tbs, mod, rv, Nl, Gb, Nref, off_e, off_p, first, 0))
+        llrs.append(d[k + "_t0_llr"])
+        off_e += llrs[-1].size
+        off_p += tbs // 8
+        first += Cn
+    d_llr = S.DeviceBuffer.from_numpy(np.concatenate(llrs))
+    d_soft = S.DeviceBuffer.from_numpy(np.zeros((32, SB), np.int8))
+    d_data = S.DeviceBuffer.from_numpy(np.zeros((32, DS), np.uint8))
+    d_pay = S.DeviceBuffer.from_numpy(np.zeros(off_p, np.uint8))
+    cb_crc = np.zeros(32, np.uint8)
+    res = (capi.HipNrTbResult * len(keys))()
+    arr = (capi.HipNrTb * len(keys))(*tb_arr)
+    capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, arr, len(keys), d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None), "batch")
+    pay = d_pay.to_numpy(np.uint8, (off_p,))
+    for i, k in enumerate(keys):
+        ok_ref, it_sum = [int(v) for v in d[k + "_t0_res"]]
+        Cn = pars[k][8]
+        assert (res[i].crc_ok, round(res[i].avg_iter * Cn)) == (ok_ref, it_sum), k
+        assert np.array_equal(cb_crc[tb_arr[i].first_cb:tb_arr[i].first_cb + Cn], d[k + "_t0_crc_out"]), k
+        if res[i].all_decoded:
+            assert np.array_equal(pay[tb_arr[i].payload_offset:tb_arr[i].payload_offset + pars[k][0] // 8], d[k + "_t0_out"]), k
+    # an empty call and a transport block that does not fit
+    assert hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, arr, 0, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None) == 0
+    bad = (capi.HipNrTb * 1)(capi.HipNrTb(0.8, 50184, 4, 0, 1, 67200, 0, 0, 0, 30, 0))
+    assert hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, bad, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None) == capi.SRSRAN_ERROR
+    hiplib.srsran_hip_sch_nr_free(h)

@@ -15,6 +15,7 @@ python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
 python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
 python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&
 python tools/bench_uplink.py > $OUT/bench_uplink.json 2> $OUT/bench_uplink.err &&
+python tools/bench_sch_nr.py > $OUT/bench_sch_nr.json 2> $OUT/bench_sch_nr.err &&
 python tools/dbg/dft_time.py 1200 900 600 300 144 72 12 > $OUT/dft_time.txt 2> $OUT/dft_time.err &&
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/trace.err &&
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_fetch.err &&

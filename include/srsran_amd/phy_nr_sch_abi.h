@@ -135,6 +135,11 @@ typedef struct srsran_hip_sch_nr srsran_hip_sch_nr_t;
 /* scaling_fctr: 0 / NaN -> 0.8 (sch_nr.c:275); max_nof_iter 0 -> 10; max_cb: rows in the soft buffer / data arrays */
 SRSRAN_API int  srsran_hip_sch_nr_create(srsran_hip_sch_nr_t** h, float scaling_fctr, uint32_t max_nof_iter, uint32_t max_cb);
 SRSRAN_API void srsran_hip_sch_nr_free(srsran_hip_sch_nr_t* h);
+/* sch_nr_encode (sch_nr.c:375-520, reached through srsran_dlsch_nr_encode / srsran_ulsch_nr_encode :715-741) for a batch: transport CRC,
+ * segmentation, CRC24B, filler bits, LDPC encoding, rate matching.  d_payload: tbs / 8 bytes per transport block at payload_offset;
+ * d_e_bits: one bit per byte, the code blocks of a transport block back to back from e_offset (first_cb is not used).  Asynchronous. */
+SRSRAN_API int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d_payload, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
+                                        uint8_t* d_e_bits, void* stream);
 /* synchronises `stream` before it returns (verdicts and iteration counts come back to the host) */
 SRSRAN_API int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
                                         int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,

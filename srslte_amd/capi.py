@@ -246,6 +246,7 @@ def lib():
             "srsran_hip_ldpc_batch_run_crc_map": (i32, [vp, vp, u32, vp, u32, vp, u32, u32, u32, u32, vp, vp]),
             "srsran_hip_sch_nr_create": (i32, [C.POINTER(vp), C.c_float, u32, u32]),
             "srsran_hip_sch_nr_free": (None, [vp]),
+            "srsran_hip_sch_nr_encode": (i32, [vp, vp, C.POINTER(HipNrTb), u32, vp, vp]),
             "srsran_hip_sch_nr_decode": (i32, [vp, vp, C.POINTER(HipNrTb), u32, vp, u32, vp, vp, u32, vp, C.POINTER(HipNrTbResult), vp]),
             "srsran_hip_ldpc_batch_run_dbg": (i32, [vp, vp, u32, vp, u32, u32, u32, vp, vp]),
             "srsran_hip_ldpc_batch_free": (None, [vp]),

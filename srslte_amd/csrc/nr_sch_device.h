@@ -50,6 +50,22 @@ struct EncParams {
 
 hipError_t launch_encode(const EncParams& p, hipStream_t stream);
 
+// ---- transmit side of the transport-block loop (sch_nr_encode, sch_nr.c:375-520), in front of the encoder
+struct TbEnc {
+  uint32_t payload_off, tbs, L_tb;
+};
+struct CbEnc {
+  uint32_t tb;       // index into the TbEnc array
+  uint32_t bit_off;  // first payload bit of this code block
+  uint32_t cb_len;   // payload bits it carries (:431-446)
+  uint32_t Kp, Kr, L_cb, last;
+  uint32_t msg_row;
+};
+// transport CRC of every payload (:426), then the messages: payload bits, transport CRC behind the last block, CRC24B, filler marks
+hipError_t launch_tb_crc_enc(const uint8_t* d_payload, const TbEnc* d_tbs, uint32_t n_tb, uint32_t* d_crc, hipStream_t stream);
+hipError_t launch_cb_build(const uint8_t* d_payload, const CbEnc* d_cbs, uint32_t n_cb, const TbEnc* d_tbs, const uint32_t* d_crc, uint8_t* d_msg,
+                           uint32_t msg_stride, hipStream_t stream);
+
 // ---- transport-block loop of sch_nr_decode (sch_nr.c:620-712) behind the decoder
 struct CbFin {       // one code block that has just been through the decoder
   uint32_t msg_row;  // row of the decoder's message array (one bit per byte)

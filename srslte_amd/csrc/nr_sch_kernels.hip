@@ -402,6 +402,107 @@ __global__ __launch_bounds__(256) void tb_finish_kernel(const uint8_t* cb_data, 
   }
 }
 
+// ---- transmit side: sch_nr_encode (sch_nr.c:375-520) up to the encoder input
+// CRC of `n` bits handed out by bit_at(i), MSB first, zero initial state (crc.c), by all 256 lanes of the workgroup
+template <class F>
+__device__ __forceinline__ uint32_t wg_crc_bits(F bit_at, uint32_t n, uint32_t poly_full, uint32_t order, uint32_t* red)
+{
+  const uint32_t mask = (1u << order) - 1u, poly = poly_full & mask;
+  const uint32_t c  = (n + 255) / 256;
+  const uint32_t lo = threadIdx.x * c, hi = lo + c < n ? lo + c : n;
+  uint32_t       crc = 0;
+  for (uint32_t i = lo; i < hi; i++) {
+    crc = ((crc << 1) & mask) ^ ((((crc >> (order - 1)) ^ bit_at(i)) & 1u) ? poly : 0u);
+  }
+  if (lo < n) {
+    uint32_t e = n - hi, result = 1, base = 2; // x^e mod g
+    while (e) {
+      if (e & 1) {
+        result = gf_mulmod_n(result, base, poly, order);
+      }
+      base = gf_mulmod_n(base, base, poly, order);
+      e >>= 1;
+    }
+    crc = gf_mulmod_n(crc, result, poly, order);
+  } else {
+    crc = 0;
+  }
+  __syncthreads();
+  red[threadIdx.x] = crc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[threadIdx.x] ^= red[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  return red[0];
+}
+
+__global__ __launch_bounds__(256) void tb_crc_enc_kernel(const uint8_t* payload, const TbEnc* tbs, uint32_t* crc_out)
+{
+  __shared__ uint32_t red[256];
+  const TbEnc    tb = tbs[blockIdx.x];
+  const uint8_t* d  = payload + tb.payload_off;
+  const uint32_t c  = wg_crc_bits([&](uint32_t i) { return (uint32_t)(d[i >> 3] >> (7 - (i & 7))) & 1u; }, tb.tbs,
+                                 tb.L_tb == 24 ? 0x1864CFBu : 0x11021u, tb.L_tb, red);
+  if (threadIdx.x == 0) {
+    crc_out[blockIdx.x] = c;
+  }
+}
+
+__global__ __launch_bounds__(256) void cb_build_kernel(const uint8_t* payload, const CbEnc* cbs, const TbEnc* tbs, const uint32_t* tbcrc, uint8_t* msg,
+                                                       uint32_t msg_stride)
+{
+  __shared__ uint8_t  bits[8448];
+  __shared__ uint32_t red[256];
+  const CbEnc    cb = cbs[blockIdx.x];
+  const TbEnc    tb = tbs[cb.tb];
+  const uint8_t* d  = payload + tb.payload_off;
+  for (uint32_t i = threadIdx.x; i < cb.cb_len; i += 256) {
+    const uint32_t b = cb.bit_off + i;
+    bits[i]          = (d[b >> 3] >> (7 - (b & 7))) & 1u;
+  }
+  if (cb.last) { // :437-441
+    const uint32_t c = tbcrc[cb.tb];
+    for (uint32_t i = threadIdx.x; i < tb.L_tb; i += 256) {
+      bits[cb.cb_len + i] = (c >> (tb.L_tb - 1 - i)) & 1u;
+    }
+  }
+  __syncthreads();
+  if (cb.L_cb) { // srsran_crc_attach over Kp - L_cb bits, :451-453
+    const uint32_t n = cb.Kp - cb.L_cb;
+    const uint32_t c = wg_crc_bits([&](uint32_t i) { return (uint32_t)bits[i]; }, n, 0x1800063u, 24, red);
+    for (uint32_t i = threadIdx.x; i < 24; i += 256) {
+      bits[n + i] = (c >> (23 - i)) & 1u;
+    }
+    __syncthreads();
+  }
+  uint8_t* out = msg + (size_t)cb.msg_row * msg_stride;
+  for (uint32_t i = threadIdx.x; i < cb.Kr; i += 256) {
+    out[i] = i < cb.Kp ? bits[i] : (uint8_t)254; // FILLER_BIT, :456-458
+  }
+}
+
+hipError_t launch_tb_crc_enc(const uint8_t* d_payload, const TbEnc* d_tbs, uint32_t n_tb, uint32_t* d_crc, hipStream_t stream)
+{
+  if (n_tb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(tb_crc_enc_kernel, dim3(n_tb), dim3(256), 0, stream, d_payload, d_tbs, d_crc);
+  return hipGetLastError();
+}
+
+hipError_t launch_cb_build(const uint8_t* d_payload, const CbEnc* d_cbs, uint32_t n_cb, const TbEnc* d_tbs, const uint32_t* d_crc, uint8_t* d_msg,
+                           uint32_t msg_stride, hipStream_t stream)
+{
+  if (n_cb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(cb_build_kernel, dim3(n_cb), dim3(256), 0, stream, d_payload, d_cbs, d_tbs, d_crc, d_msg, msg_stride);
+  return hipGetLastError();
+}
+
 hipError_t launch_cb_finish(const uint8_t* d_msg, uint32_t msg_stride, const CbFin* d_jobs, const int* d_n_iter, uint32_t n, uint8_t* d_flags,
                             uint8_t* d_cb_data, uint32_t data_stride, hipStream_t stream)
 {

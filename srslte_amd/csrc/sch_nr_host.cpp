@@ -128,8 +128,17 @@ struct srsran_hip_sch_nr {
   size_t        tbf_cap = 0;
   nrsch::TbFinRes *d_res = nullptr, *h_res = nullptr;
   size_t           res_cap = 0;
+  // transmit side
+  uint8_t*      d_cw = nullptr; // max_cb x CW_STRIDE code words (one bit per byte, filler marks kept)
+  nrsch::TbEnc *d_tbe = nullptr, *h_tbe = nullptr;
+  size_t        tbe_cap = 0;
+  nrsch::CbEnc *d_cbe = nullptr, *h_cbe = nullptr;
+  size_t        cbe_cap = 0;
+  uint32_t*     d_tbcrc = nullptr;
+  size_t        tbcrc_cap = 0;
 };
 static const uint32_t MSG_STRIDE = 8448;
+static const uint32_t CW_STRIDE  = 66 * 384;
 
 extern "C" int srsran_hip_sch_nr_create(srsran_hip_sch_nr_t** hh, float scaling_fctr, uint32_t max_nof_iter, uint32_t max_cb)
 {
@@ -170,6 +179,10 @@ extern "C" void srsran_hip_sch_nr_free(srsran_hip_sch_nr_t* h)
   (void)hipFree(h->d_cbf), (void)hipHostFree(h->h_cbf);
   (void)hipFree(h->d_tbf), (void)hipHostFree(h->h_tbf);
   (void)hipFree(h->d_res), (void)hipHostFree(h->h_res);
+  (void)hipFree(h->d_cw);
+  (void)hipFree(h->d_tbe), (void)hipHostFree(h->h_tbe);
+  (void)hipFree(h->d_cbe), (void)hipHostFree(h->h_cbe);
+  (void)hipFree(h->d_tbcrc);
   delete h;
 }
 
@@ -335,6 +348,113 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
     res[t].crc_ok      = h->h_res[t].crc_ok;
     res[t].avg_iter    = 0.0f;
     res[t].nof_cb      = cfg[t].C;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+// sch_nr_encode (sch_nr.c:375-520) for a batch: payload bytes -> rate-matched bits (one per byte) of every code block, back to back per
+// transport block from e_offset on.  Asynchronous on `stream`.
+extern "C" int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d_payload, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
+                                        void* stream)
+{
+  if (h && n_tb == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  if (!h || !d_payload || !tbs || !d_e_bits) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  struct EJob {
+    int      bg;
+    uint32_t Z, rv, mod, Nref, E, out_off, row;
+  };
+  std::vector<TbCfg> cfg(n_tb);
+  std::vector<EJob>  jobs;
+  if (!ensure(&h->d_tbe, &h->h_tbe, &h->tbe_cap, n_tb)) {
+    return SRSRAN_ERROR;
+  }
+  uint32_t n_cb = 0;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    if (!tb_cfg(tbs[t], &cfg[t])) {
+      set_error("sch_nr: transport block %u: invalid size / modulation / layers", t);
+      return SRSRAN_ERROR;
+    }
+    n_cb += cfg[t].C;
+  }
+  if (n_cb > h->max_cb) {
+    set_error("sch_nr: %u code blocks in one call, the object was created for %u", n_cb, h->max_cb);
+    return SRSRAN_ERROR;
+  }
+  if (!ensure(&h->d_cbe, &h->h_cbe, &h->cbe_cap, n_cb)) {
+    return SRSRAN_ERROR;
+  }
+  if (!h->d_cw) {
+    PHY_HIP_CHECK(hipMalloc(&h->d_cw, (size_t)h->max_cb * CW_STRIDE), SRSRAN_ERROR);
+  }
+  if (n_tb > h->tbcrc_cap) {
+    (void)hipFree(h->d_tbcrc);
+    h->d_tbcrc   = nullptr;
+    h->tbcrc_cap = 0;
+    PHY_HIP_CHECK(hipMalloc(&h->d_tbcrc, ((size_t)n_tb + 16) * sizeof(uint32_t)), SRSRAN_ERROR);
+    h->tbcrc_cap = (size_t)n_tb + 16;
+  }
+  uint32_t row = 0;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    const TbCfg& c = cfg[t];
+    h->h_tbe[t]    = nrsch::TbEnc{tbs[t].payload_offset, c.A, c.L_tb};
+    uint32_t bit = 0, out = tbs[t].e_offset;
+    for (uint32_t r = 0; r < c.C; r++) {
+      const bool     last   = r == c.C - 1;
+      const uint32_t cb_len = c.Kp - c.L_cb - (last ? c.L_tb : 0);
+      h->h_cbe[row]         = nrsch::CbEnc{t, bit, cb_len, c.Kp, c.Kr, c.L_cb, last ? 1u : 0u, row};
+      bit += (cb_len / 8) * 8; // input_ptr += cb_len / 8 (:448)
+      const uint32_t E = get_E(c, r);
+      jobs.push_back(EJob{c.bg, c.Z, tbs[t].rv, tbs[t].mod, c.Nref, E, out, row});
+      out += E;
+      row++;
+    }
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbe, h->h_tbe, n_tb * sizeof(nrsch::TbEnc), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(h->d_cbe, h->h_cbe, n_cb * sizeof(nrsch::CbEnc), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(nrsch::launch_tb_crc_enc(d_payload, h->d_tbe, n_tb, h->d_tbcrc, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(nrsch::launch_cb_build(d_payload, h->d_cbe, n_cb, h->d_tbe, h->d_tbcrc, h->d_msg, MSG_STRIDE, st), SRSRAN_ERROR);
+  // LDPC encoder per (graph, Z), rate matcher per (graph, Z, rv, modulation, Nref)
+  std::vector<uint32_t> order(n_cb);
+  for (uint32_t i = 0; i < n_cb; i++) {
+    order[i] = i;
+  }
+  auto key = [&](const EJob& j) { return std::make_tuple(j.bg, j.Z, j.rv, j.mod, j.Nref); };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(jobs[a]) < key(jobs[b]); });
+  std::vector<srsran_hip_ldpc_cb_t> cbs;
+  for (uint32_t i = 0; i < n_cb;) {
+    uint32_t e = i;
+    while (e < n_cb && jobs[order[e]].bg == jobs[order[i]].bg && jobs[order[e]].Z == jobs[order[i]].Z) {
+      e++;
+    }
+    const EJob&    j = jobs[order[i]];
+    const uint32_t N = j.Z * (j.bg == 0 ? 66u : 50u);
+    cbs.clear();
+    for (uint32_t k = i; k < e; k++) {
+      cbs.push_back(srsran_hip_ldpc_cb_t{jobs[order[k]].row * MSG_STRIDE, jobs[order[k]].row * CW_STRIDE, N});
+    }
+    if (srsran_hip_ldpc_encode_batch(h->rm, h->d_msg, h->d_cw, cbs.data(), (uint32_t)cbs.size(), (srsran_basegraph_t)j.bg, j.Z, st) != SRSRAN_SUCCESS) {
+      return SRSRAN_ERROR;
+    }
+    i = e;
+  }
+  for (uint32_t i = 0; i < n_cb;) {
+    uint32_t e = i;
+    cbs.clear();
+    while (e < n_cb && key(jobs[order[e]]) == key(jobs[order[i]])) {
+      cbs.push_back(srsran_hip_ldpc_cb_t{jobs[order[e]].row * CW_STRIDE, jobs[order[e]].out_off, jobs[order[e]].E});
+      e++;
+    }
+    const EJob& j = jobs[order[i]];
+    if (srsran_hip_ldpc_rm_tx_batch(h->rm, h->d_cw, d_e_bits, cbs.data(), (uint32_t)cbs.size(), (srsran_basegraph_t)j.bg, j.Z, j.rv, (srsran_mod_t)j.mod,
+                                    j.Nref, st) != SRSRAN_SUCCESS) {
+      return SRSRAN_ERROR;
+    }
+    i = e;
   }
   return SRSRAN_SUCCESS;
 }

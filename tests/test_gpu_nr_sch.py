@@ -256,3 +256,52 @@ def test_transport_block_loop_matches_reference_chain(hiplib):
     bad = (capi.HipNrTb * 1)(capi.HipNrTb(0.8, 50184, 4, 0, 1, 67200, 0, 0, 0, 30, 0))
     assert hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, bad, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None) == capi.SRSRAN_ERROR
     hiplib.srsran_hip_sch_nr_free(h)
+
+
+def test_transport_block_encode_matches_reference_chain(hiplib):
+    """srsran_hip_sch_nr_encode == sch_nr_encode (sch_nr.c:375-520) on the recorded outputs of the reference's blocks: every fixture
+    block alone and all of them (both transmissions of the HARQ case) in one call"""
+    import ctypes as C
+    import os
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "sch_nr_ref.npz"))
+    h = C.c_void_p()
+    capi.check(hiplib.srsran_hip_sch_nr_create(C.byref(h), 0.8, 10, 40), "create")
+    tb_arr, pays, want, off_e, off_p = [], [], [], 3, 1
+    for key in d["cases"]:
+        tbs, R1000, mod, rv, Nl, Gb, Nref, max_iter, Cn, Z, Kr, Kp, F, L_tb, L_cb, bg, n_tx = [int(v) for v in d[key + "_par"]]
+        for t in range(n_tx):
+            e = np.unpackbits(d["%s_t%d_e" % (key, t)])
+            n_e = sum(O.sch_nr_get_E(O.sch_nr_tb_info(tbs, R1000 / 1000.0, mod, Gb, Nl, Nref), r) for r in range(Cn))
+            tb_arr.append(capi.HipNrTb(R1000 / 1000.0, tbs, mod, rv if t == 0 else 2, Nl, Gb, Nref, off_e, off_p, 0, 0))
+            pays.append((off_p, d[key + "_payload"]))
+            want.append((off_e, e[:n_e], "%s_t%d" % (key, t)))
+            off_e += n_e + 5
+            off_p += tbs // 8 + 3
+    pay = np.zeros(off_p, np.uint8)
+    for o, p in pays:
+        pay[o:o + p.size] = p
+    d_pay = S.DeviceBuffer.from_numpy(pay)
+    # one by one
+    for i, (o, e, k) in enumerate(want):
+        d_e = S.DeviceBuffer.from_numpy(np.full(off_e, 9, np.uint8))
+        one = (capi.HipNrTb * 1)(tb_arr[i])
+        capi.check(hiplib.srsran_hip_sch_nr_encode(h, d_pay.ptr, one, 1, d_e.ptr, None), k)
+        capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+        got = d_e.to_numpy(np.uint8, (off_e,))
+        assert np.array_equal(got[o:o + e.size], e), k
+        assert (got[:o] == 9).all() and (got[o + e.size:] == 9).all()
+    # all in one call
+    d_e = S.DeviceBuffer.from_numpy(np.full(off_e, 9, np.uint8))
+    arr = (capi.HipNrTb * len(tb_arr))(*tb_arr)
+    for _ in range(2):
+        capi.check(hiplib.srsran_hip_sch_nr_encode(h, d_pay.ptr, arr, len(tb_arr), d_e.ptr, None), "batch")
+    capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+    got = d_e.to_numpy(np.uint8, (off_e,))
+    for o, e, k in want:
+        assert np.array_equal(got[o:o + e.size], e), k
+    assert hiplib.srsran_hip_sch_nr_encode(h, d_pay.ptr, arr, 0, d_e.ptr, None) == 0
+    hiplib.srsran_hip_sch_nr_free(h)

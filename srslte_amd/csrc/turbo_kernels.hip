@@ -391,7 +391,7 @@ __device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32
 // decoder wants step-major data spread over lanes, so every code block of the wave is staged through LDS in chunks of
 // NBK 8-step blocks: the 64 lanes copy the NB contiguous runs of 48*NBK bytes with 8-byte loads (each wave-level load
 // covers >= 256 contiguous bytes), then lane (p', g) assembles the blocked dwords of sub-block pair p' for two blocks
-// and stores them into the slots of the lane that owns that pair.  Needs W % 8 == 0 and 8-byte aligned code blocks.
+// and stores them into the slots of the lane that owns that pair.  Needs W % 4 == 0 and 8-byte aligned code blocks.
 template <int LPC, class AR>
 __device__ __forceinline__ void extract_input_natural16(const short* in_wave, uint32_t in_stride, int n_cb_left, uint32_t K,
                                                         uint32_t long_sb, uint32_t nblk, int lane, uint32_t* S, uint32_t* P0,
@@ -601,7 +601,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   // ---- phase 0: input extraction
   if (p.n_begin == 0) {
-    const bool fast = !desc && !p.in_is8 && !p.sb_layout && (long_sb & 7u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
+    // sub-blocks that are a multiple of 4 steps keep every run 8-byte aligned; a ragged last block (K = 5824: 364 = 45 * 8 + 4 steps) is
+    // fetched whole -- the 4 steps behind it are the head of the next sub-block or the tail LLRs, inside the code block's
+    // 3 K + 12 values, and the decoder never looks at steps >= long_sb
+    const bool fast = !desc && !p.in_is8 && !p.sb_layout && (long_sb & 3u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
     if (fast) {
       const int first = blockIdx.x * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,

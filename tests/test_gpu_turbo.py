@@ -56,7 +56,7 @@ def test_manual_implementations(hiplib, impl_g, impl_o, K):
     _check(S, K, getattr(capi, "TDEC_" + impl_g), impl_o, 5, -1.0, (1, 2, 5, 8), seed=K)
 
 
-@pytest.mark.parametrize("K", [6144, 1024, 512])
+@pytest.mark.parametrize("K", [6144, 5824, 2112, 1024, 1008, 512])
 def test_rm_turbo_subblock_layout(hiplib, K):
     """input in the layout srsran_rm_turbo_rx_lut produces for the window decoders (turbodecoder_iter.h:88-102)"""
     import srslte_amd as S

@@ -21,6 +21,10 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --ste
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_fetch.err &&
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_write.err &&
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES -d $OUT/pmc_sq -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_sq.err &&
+( rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -d $OUT/pmc_lds -o p -- python bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2> $OUT/pmc_lds.err &&
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -d $OUT/pmc_lds_nr -o p -- python tools/bench_nr.py --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_lds_nr.err &&
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -d $OUT/pmc_lds_sync -o p -- python tools/bench_sync.py > /dev/null 2> $OUT/pmc_lds_sync.err &&
+  python tools/rocpd_summary.py $OUT/pmc_lds $OUT/pmc_lds_nr $OUT/pmc_lds_sync > $OUT/pmc_lds.txt ) || echo "LDS counter pass failed (see pmc_lds*.err)"
 python tools/rocpd_summary.py $OUT/trace > $OUT/kernel_stats.txt &&
 python tools/rocpd_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > $OUT/pmc.txt &&
 rocprofv3 --kernel-trace -d $OUT/trace_nr -o nr -- python tools/bench_nr.py > /dev/null 2> $OUT/trace_nr.err &&
@@ -37,5 +41,5 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_pusch -o p -- python tools/bench_pu
 python tools/rocpd_summary.py $OUT/pmc_fetch_nr $OUT/pmc_write_nr $OUT/pmc_fetch_pusch $OUT/pmc_write_pusch > $OUT/pmc_chains.txt
 echo "profile pass rc=$?"
 # the rocpd databases are large (gpurun copies back at most 64 MiB): keep the text summaries only
-rm -rf $OUT/trace $OUT/trace_* $OUT/pmc_fetch* $OUT/pmc_write* $OUT/pmc_sq 2>/dev/null
+rm -rf $OUT/trace $OUT/trace_* $OUT/pmc_fetch* $OUT/pmc_write* $OUT/pmc_sq $OUT/pmc_lds $OUT/pmc_lds_nr $OUT/pmc_lds_sync 2>/dev/null
 du -sh $OUT

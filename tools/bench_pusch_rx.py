@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tbs", type=int, default=2048); ap.add_argument("--snr", type=float, default=19.0)
+    ap.add_argument("--tbs", type=int, default=2496); ap.add_argument("--snr", type=float, default=19.0)  # 2496 x 13 blocks = 4056 waves: two rounds of the 2048 resident ones
     ap.add_argument("--iters", type=int, default=8); ap.add_argument("--cpu-sample", type=int, default=2)
     a = ap.parse_args()
     import torch

@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ues", type=int, default=64); ap.add_argument("--sf", type=int, default=32, help="subframes per UE and step")
+    ap.add_argument("--ues", type=int, default=64); ap.add_argument("--sf", type=int, default=46, help="subframes per UE and step (64 x 46 x 11 blocks = 4048 waves: two rounds of the resident ones)")
     ap.add_argument("--snr", type=float, default=19.0); ap.add_argument("--iters", type=int, default=8)
     a = ap.parse_args()
     import torch

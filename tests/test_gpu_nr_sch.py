@@ -223,6 +223,15 @@ def test_transport_block_loop_matches_reference_chain(hiplib):
                 pay = d_pay.to_numpy(np.uint8, (tbs // 8 + 64,))
                 assert np.array_equal(pay[7:7 + tbs // 8], d[k + "_out"]), k
                 assert pay[:7].sum() == 0 and pay[7 + tbs // 8:].sum() == 0
+        if cb_crc[first:first + Cn].all():
+            # one more call with every code block already decoded (:584-588 skip them all): no input is consumed, the payload is
+            # assembled again, the iteration average is zero
+            capi.check(hiplib.srsran_hip_memset(d_pay.ptr, 0, tbs // 8 + 64, None), "memset")
+            tb = (capi.HipNrTb * 1)(capi.HipNrTb(R1000 / 1000.0, tbs, mod, 3, Nl, Gb, Nref, 0, 7, first, 0))
+            capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, tb, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None), "again")
+            assert (res[0].all_decoded, res[0].crc_ok, res[0].avg_iter) == (1, int(d["%s_t%d_res" % (key, n_tx - 1)][0]), 0.0), key
+            pay = d_pay.to_numpy(np.uint8, (tbs // 8 + 64,))
+            assert np.array_equal(pay[7:7 + tbs // 8], d["%s_t%d_out" % (key, n_tx - 1)]), key
         hiplib.srsran_hip_sch_nr_free(h)
     # all first transmissions of the blocks that share an iteration limit in one call
     keys = [k for k in d["cases"] if pars[k][7] == 10]

@@ -148,7 +148,7 @@ __device__ __forceinline__ void layer(typename POL::TS* soft, typename POL::T* c
       const int x = POL::v2c(sb[i], co[i]);
       v[i]        = x;
       a[i]        = x < 0 ? -x : x;
-      min1        = max(min(a[i], min1), min(max(a[i], min1), min0)); // second smallest of {a, min0, min1}
+      min1        = min(max(a[i], min0), min1); // second smallest of {a, min0, min1}, given min0 <= min1
       min0        = min(a[i], min0);
       sgn ^= x;
     }

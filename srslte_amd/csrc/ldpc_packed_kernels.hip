@@ -99,7 +99,7 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
     if (KEEP_A) {
       a[i] = av;
     }
-    min1         = pmax(pmin(av, min1), pmin(pmax(av, min1), min0)); // second smallest of {a, min0, min1}
+    min1         = pmin(pmax(av, min0), min1); // second smallest of {a, min0, min1}, given min0 <= min1
     min0         = pmin(av, min0);
     sgn ^= as_u32(xv);
   }
@@ -107,13 +107,13 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
   const u2v mm = {m9, m9};
   const s2v s0 = __builtin_bit_cast(s2v, (u2v)((__builtin_bit_cast(u2v, min0) * mm) >> 9));
   const s2v s1 = __builtin_bit_cast(s2v, (u2v)((__builtin_bit_cast(u2v, min1) * mm) >> 9));
-  const s2v ds = s0 - s1;
+  // the edge(s) holding the minimum get the second minimum (equal magnitudes: both are the same number):
+  // max(s0, s1 - 128 (a - min0)) is s1 where a == min0 and s0 (>= 0 > s1 - 128) elsewhere
+  const s2v c1 = s1 + min0 * splat2(128);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    // the edge(s) holding the minimum get the second minimum (equal magnitudes: both are the same number)
     const s2v av  = KEEP_A ? a[i] : pmax(x[i], splat2(0) - x[i]);
-    const s2v ne  = pmin(av - min0, splat2(1)); // 0 where a == min0, else 1
-    const s2v mag = s1 + ne * ds;
+    const s2v mag = pmax(s0, c1 - av * splat2(128));
     const s2v m   = as_s2(sgn ^ as_u32(x[i])) >> 15; // all ones where the product of the OTHER signs is negative
     const s2v cn  = (mag ^ m) - m;
     *reinterpret_cast<uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb)) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cn), 0x0c0c0200u);

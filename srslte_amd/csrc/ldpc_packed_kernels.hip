@@ -90,9 +90,9 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
   for (int i = 0; i < DEG; i++) {
     // ldpc_dec_c.c:338-363: +-127 passes as infinity, everything else is clip(s - c, +-63).  Soft words only hold -63..63
     // and +-127 (the kernel normalises the channel LLRs when it loads them), so h = s - clip(s) is +-64 for the
-    // infinite values and 0 otherwise; pushing s - c out by 8 h makes the clip produce +-63, h completes it to +-127.
+    // infinite values and 0 otherwise; pushing s - c out by 3 h makes the clip produce +-63, h completes it to +-127.
     const s2v h  = s[i] - clip(s[i], 63);
-    const s2v t  = (s[i] - co[i]) + h * splat2(8);
+    const s2v t  = (s[i] - co[i]) + h * splat2(3); // (3, not a power of two: one v_pk_mad_i16 instead of a shift and an add)
     const s2v xv = clip(t, 63) + h;
     x[i]         = xv;
     const s2v av = pmax(xv, splat2(0) - xv);
@@ -108,12 +108,12 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
   const s2v s0 = __builtin_bit_cast(s2v, (u2v)((__builtin_bit_cast(u2v, min0) * mm) >> 9));
   const s2v s1 = __builtin_bit_cast(s2v, (u2v)((__builtin_bit_cast(u2v, min1) * mm) >> 9));
   // the edge(s) holding the minimum get the second minimum (equal magnitudes: both are the same number):
-  // max(s0, s1 - 128 (a - min0)) is s1 where a == min0 and s0 (>= 0 > s1 - 128) elsewhere
-  const s2v c1 = s1 + min0 * splat2(128);
+  // max(s0, s1 - 129 (a - min0)) is s1 where a == min0 and s0 (>= 0 > s1 - 129) elsewhere
+  const s2v c1 = s1 + min0 * splat2(129);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     const s2v av  = KEEP_A ? a[i] : pmax(x[i], splat2(0) - x[i]);
-    const s2v mag = pmax(s0, c1 - av * splat2(128));
+    const s2v mag = pmax(s0, c1 - av * splat2(129)); // 129: a multiply-add, and 129 * 127 + 127 still fits 16 bits
     const s2v m   = as_s2(sgn ^ as_u32(x[i])) >> 15; // all ones where the product of the OTHER signs is negative
     const s2v cn  = (mag ^ m) - m;
     *reinterpret_cast<uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb)) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cn), 0x0c0c0200u);

@@ -70,6 +70,11 @@ SRSRAN_API void srsran_hip_sch_free(srsran_hip_sch_t* h);
 SRSRAN_API int  srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
                                       uint32_t max_iterations, int16_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
                                       srsran_hip_tb_result_t* results, void* stream);
+/* the same with q->llr_is_8bit (sch.c:408-412,426-428): int8 LLRs and soft buffers (same element counts and offsets), 8-bit rate
+ * de-matching and the 8-bit window decoders */
+SRSRAN_API int  srsran_hip_sch_decode_8bit(srsran_hip_sch_t* h, const int8_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
+                                           uint32_t max_iterations, int8_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
+                                           srsran_hip_tb_result_t* results, void* stream);
 /* srsran_cbsegm (cbsegm.h:32-45, cbsegm.c:62-117) */
 typedef struct SRSRAN_API {
   uint32_t F, C, K1, K2, K1_idx, K2_idx, C1, C2, tbs, L_tb, L_cb, Z;

@@ -77,6 +77,8 @@ int orc_rm_turbo_rx_8bit(const int8_t* input, int8_t* output, uint32_t in_len, u
 int orc_cbsegm(uint32_t tbs, uint32_t* C, uint32_t* K1, uint32_t* K2, uint32_t* C1, uint32_t* C2, uint32_t* F);
 int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const int16_t* e_bits, int16_t* softbuf,
                       uint8_t* cb_crc, uint8_t* cb_data, uint32_t max_iterations, uint8_t* data, float* avg_iterations);
+int orc_sch_decode_tb_8bit(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const int8_t* e_bits, int8_t* softbuf,
+                      uint8_t* cb_crc, uint8_t* cb_data, uint32_t max_iterations, uint8_t* data, float* avg_iterations);
 
 /* turbocoder.c:69-160 (bit-per-byte in, 3K+12 bit-per-byte out, natural order) */
 int orc_tcod_encode(const uint8_t* input, uint8_t* output, uint32_t long_cb);

@@ -247,3 +247,65 @@ int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bit
   uint32_t par_tx = ((uint32_t)data[tbs / 8] << 16) | ((uint32_t)data[tbs / 8 + 1] << 8) | data[tbs / 8 + 2];
   return (par_rx == par_tx && par_rx) ? 0 : -1;
 }
+
+/* the same loop with q->llr_is_8bit (sch.c:408-412,426-428): 8-bit rate de-matching and the 8-bit window decoders */
+int orc_sch_decode_tb_8bit(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const int8_t* e_bits, int8_t* softbuf,
+                      uint8_t* cb_crc, uint8_t* cb_data, uint32_t max_iterations, uint8_t* data, float* avg_iterations)
+{
+  uint32_t C, K1, K2, C1, C2, F;
+  if (orc_cbsegm(tbs, &C, &K1, &K2, &C1, &C2, &F) || F || Qm == 0) {
+    return -2;
+  }
+  float it = 0;
+  for (uint32_t i = 0; i < C; i++) {
+    uint32_t K    = i < C1 ? K1 : K2;
+    uint32_t rlen = C == 1 ? K : K - 24;
+    if (cb_crc[i]) {
+      memcpy(&data[i * rlen / 8], &cb_data[(size_t)i * 768], rlen / 8); /* sch.c:466-471 */
+      continue;
+    }
+    uint32_t Gp = nof_e_bits / Qm, gamma = Gp % C, n_e = Qm * (Gp / C);
+    uint32_t rp = i * n_e, n_e2 = n_e;
+    if (i > C - gamma) {
+      n_e2 = n_e + Qm;
+      rp   = (C - gamma) * n_e + (i - (C - gamma)) * n_e2;
+    }
+    int8_t*  sb  = softbuf + (size_t)i * 18600;
+    uint32_t nsb = orc_tdec_autoimp_subblocks_8bit(K);
+    if (!nsb || orc_rm_turbo_rx_8bit(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
+      return -2;
+    }
+    uint8_t* out = &data[i * rlen / 8];
+    uint32_t noi = 0;
+    int      ok  = 0;
+    do {
+      noi++;
+      /* srsran_tdec_iteration noi times from the start = the state after noi half iterations */
+      if (orc_tdec_run_all_8bit(sb, out, noi, K, ORC_TDEC_AUTO, 1, NULL)) {
+        return -2;
+      }
+      it += 1;
+      ok = crc_bytes(C > 1 ? 0x1800063 : 0x1864CFB, out, C > 1 ? K : tbs + 24) == 0;
+    } while (noi < max_iterations && !ok);
+    if (ok) {
+      cb_crc[i] = 1;
+    }
+  }
+  *avg_iterations = it / (float)C;
+  int all = 1;
+  for (uint32_t i = 0; i < C; i++) {
+    all = all && cb_crc[i];
+  }
+  if (!all) { /* sch.c:478-485: keep the good code blocks for the next HARQ round */
+    for (uint32_t i = 0; i < C; i++) {
+      if (cb_crc[i]) {
+        uint32_t K = i < C1 ? K1 : K2, rlen = C == 1 ? K : K - 24;
+        memcpy(&cb_data[(size_t)i * 768], &data[i * rlen / 8], rlen / 8);
+      }
+    }
+    return -1;
+  }
+  uint32_t par_rx = crc_bytes(0x1864CFB, data, tbs);
+  uint32_t par_tx = ((uint32_t)data[tbs / 8] << 16) | ((uint32_t)data[tbs / 8 + 1] << 8) | data[tbs / 8 + 2];
+  return (par_rx == par_tx && par_rx) ? 0 : -1;
+}

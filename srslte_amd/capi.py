@@ -405,6 +405,7 @@ def lib():
             "srsran_hip_sch_create": (i32, [C.POINTER(vp)]),
             "srsran_hip_sch_free": (None, [vp]),
             "srsran_hip_sch_decode": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
+            "srsran_hip_sch_decode_8bit": (i32, [vp, vp, C.POINTER(HipTb), u32, u32, vp, vp, vp, C.POINTER(HipTbResult), vp]),
             "srsran_cbsegm": (i32, [C.POINTER(Cbsegm), u32]),
             "srsran_tcod_init": (i32, [C.POINTER(Tcod), u32]),
             "srsran_tcod_free": (None, [C.POINTER(Tcod)]),

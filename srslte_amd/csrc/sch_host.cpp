@@ -62,7 +62,7 @@ extern "C" int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs)
 
 struct srsran_hip_sch {
   // one turbo batch object per (K, arithmetic is 16 bit), grown on demand
-  std::map<uint32_t, std::pair<srsran_hip_tdec_batch_t*, uint32_t>> dec; // K -> (object, capacity)
+  std::map<uint32_t, std::pair<srsran_hip_tdec_batch_t*, uint32_t>> dec; // K | 8-bit flag << 31 -> (object, capacity)
   void*  d_scratch = nullptr; // job / descriptor / result arrays
   size_t scratch_cap = 0;
 };
@@ -100,9 +100,10 @@ struct CbWork {
   turbo::CbDesc   desc;
 };
 
-srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n)
+srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n, bool llr8)
 {
-  auto it = h->dec.find(K);
+  const uint32_t key = K | (llr8 ? 0x80000000u : 0u);
+  auto           it  = h->dec.find(key);
   if (it != h->dec.end() && it->second.second >= n) {
     return it->second.first;
   }
@@ -111,18 +112,18 @@ srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n
     h->dec.erase(it);
   }
   srsran_hip_tdec_batch_t* b = nullptr;
-  if (srsran_hip_tdec_batch_create(&b, K, n, SRSRAN_TDEC_AUTO)) {
+  if (llr8 ? srsran_hip_tdec_batch_create_8bit(&b, K, n, SRSRAN_TDEC_AUTO) : srsran_hip_tdec_batch_create(&b, K, n, SRSRAN_TDEC_AUTO)) {
     return nullptr;
   }
-  h->dec[K] = std::make_pair(b, n);
+  h->dec[key] = std::make_pair(b, n);
   return b;
 }
 
 } // namespace
 
-extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
-                                     uint32_t max_iterations, int16_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
-                                     srsran_hip_tb_result_t* results, void* stream)
+// decode_tb (sch.c:507-572) for a batch; llr8 = q->llr_is_8bit: 8-bit rate de-matching and the 8-bit window decoders (:408-412,426-428)
+static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint32_t max_iterations, void* d_softbuf,
+                      uint8_t* cb_crc, uint8_t* d_data, srsran_hip_tb_result_t* results, void* stream, bool llr8)
 {
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
@@ -167,7 +168,7 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
         n_e2 = n_e + tb.Qm;
         rp   = (cs.C - gamma) * n_e + (i - (cs.C - gamma)) * n_e2;
       }
-      if (srsran_tdec_autoimp_get_subblocks(K) == 0) {
+      if ((llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K)) == 0) {
         set_error("sch decode: code blocks of %u bits go to the scalar decoder, which has no device early stop; "
                   "use the srsran_tdec_* / srsran_rm_turbo_* entry points for them", K);
         return SRSRAN_ERROR_INVALID_INPUTS;
@@ -225,9 +226,9 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
   for (auto& g : groups) {
     const uint32_t K = (uint32_t)(g.first >> 34), rv = (uint32_t)((g.first >> 32) & 3), poly = (uint32_t)g.first;
     const uint32_t m = (uint32_t)g.second.size();
-    const uint32_t nsb = srsran_tdec_autoimp_get_subblocks(K);
+    const uint32_t nsb = llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K);
     const uint16_t* tab = rm::device_table(K, rv, nsb);
-    srsran_hip_tdec_batch_t* dec = decoder_for(h, K, m);
+    srsran_hip_tdec_batch_t* dec = decoder_for(h, K, m, llr8);
     if (!tab || !dec) {
       return SRSRAN_ERROR;
     }
@@ -236,8 +237,8 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
     for (uint32_t i = 0; i < m; i++) {
       max_in = std::max(max_in, work[g.second[i]].job.in_len);
     }
-    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, false, st, max_in), SRSRAN_ERROR);
-    if (turbo::batch_run_early_stop(dec, d_softbuf, false, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {
+    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, max_in), SRSRAN_ERROR);
+    if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {
       return SRSRAN_ERROR;
     }
     at += m;
@@ -285,4 +286,18 @@ extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bit
     }
   }
   return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_sch_decode(srsran_hip_sch_t* h, const int16_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
+                                     uint32_t max_iterations, int16_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
+                                     srsran_hip_tb_result_t* results, void* stream)
+{
+  return sch_decode(h, d_e_bits, tbs, n_tb, max_iterations, d_softbuf, cb_crc, d_data, results, stream, false);
+}
+
+extern "C" int srsran_hip_sch_decode_8bit(srsran_hip_sch_t* h, const int8_t* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb,
+                                          uint32_t max_iterations, int8_t* d_softbuf, uint8_t* cb_crc, uint8_t* d_data,
+                                          srsran_hip_tb_result_t* results, void* stream)
+{
+  return sch_decode(h, d_e_bits, tbs, n_tb, max_iterations, d_softbuf, cb_crc, d_data, results, stream, true);
 }

@@ -169,9 +169,9 @@ def tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng, payload=None, tx_order=False):
     return np.concatenate(e).astype(np.uint8), np.packbits(b)
 
 
-def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0):
-    """tb_coded_bits + BPSK over AWGN.  Returns (int16 soft bits e, payload bytes incl. the CRC24A)"""
-    tx, payload = tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng)
+def make_tb(tbs, Qm, nof_e_bits, rv, esn0_db, rng, scale=40.0, payload=None):
+    """tb_coded_bits + BPSK over AWGN.  Returns (int16 soft bits e, payload bytes incl. the CRC24A); payload: tbs bits to send again"""
+    tx, payload = tb_coded_bits(tbs, Qm, nof_e_bits, rv, rng, payload=payload)
     tx = tx.astype(np.float64)
     sigma = 10 ** (-esn0_db / 20)
     y = (2.0 * tx - 1.0) + sigma * rng.standard_normal(tx.size)
@@ -207,7 +207,7 @@ def modulate(bits, mod):
 def sch_decode_tb(tbs, Qm, rv, e_bits, softbuf, cb_crc, max_iterations, cb_data=None):
     """oracle decode_tb: returns (ret, data bytes, avg_iterations); softbuf [C, 18600] int16 and cb_crc [C] uint8 are updated.
     cb_data [C, 768] uint8: decoded code blocks kept between HARQ rounds (softbuffer->data)"""
-    f = orc().orc_sch_decode_tb
+    f = orc().orc_sch_decode_tb_8bit if e_bits.dtype == np.int8 else orc().orc_sch_decode_tb  # int8: q->llr_is_8bit
     f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                   C.c_void_p, C.c_void_p]
     data = np.zeros(tbs // 8 + 6, np.uint8)

@@ -77,6 +77,74 @@ def test_batch_of_transport_blocks_vs_oracle(hiplib):
     lib.srsran_hip_sch_free(h)
 
 
+def test_batch_of_transport_blocks_8bit_vs_oracle(hiplib):
+    """q->llr_is_8bit (sch.c:408-412,426-428): int8 LLRs, srsran_rm_turbo_rx_lut_8bit, the 8-bit window decoders (32 / 16 / 8
+    sub-blocks), same loop; incl. a second transmission of a block whose first one fails"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(8)
+    h = C.c_void_p()
+    assert lib.srsran_hip_sch_create(C.byref(h)) == 0
+    cases = [(4584, 2, 9000, 3.0), (75376, 6, 100800, 5.5), (12216, 4, 26000, 3.5), (12216, 2, 15000, -6.0), (936, 2, 2400, 3.0), (36696, 6, 52002, 3.9)]
+    tb_list, e_parts, first_cb, data_off, truth = [], [], 0, 0, []
+    for tbs, Qm, G, snr in cases:
+        e16, payload = O.make_tb(tbs, Qm, G, 0, snr, rng)
+        e = np.clip(np.round(e16 * (10.0 / np.mean(np.abs(e16)))), -100, 100).astype(np.int8)
+        s = O.cbsegm(tbs)
+        tb_list.append(capi.HipTb(tbs, Qm, 0, G, sum(p.size for p in e_parts), data_off, first_cb))
+        e_parts.append(e)
+        truth.append((payload, s))
+        first_cb += s["C"]
+        data_off += tbs // 8 + 6 + 3
+    softbuf = np.zeros((first_cb, SB), np.int8)
+    cb_crc = np.zeros(first_cb, np.uint8)
+    o_soft = [np.zeros((s["C"], SB), np.int8) for _, s in truth]
+    o_crc = [np.zeros(s["C"], np.uint8) for _, s in truth]
+    o_cbd = [np.zeros((s["C"], 768), np.uint8) for _, s in truth]
+    d_data = None
+    active = list(range(len(cases)))
+    for rnd in range(2):
+        if rnd == 1:  # second transmission (rv 2) of the blocks the first one did not recover, fresh noise
+            assert active
+            for i in active:
+                tbs, Qm, G, snr = cases[i]
+                e16, _ = O.make_tb(tbs, Qm, G, 2, snr + 8.0, rng, payload=np.unpackbits(truth[i][0][:tbs // 8]))
+                e_parts[i] = np.clip(np.round(e16 * (10.0 / np.mean(np.abs(e16)))), -100, 100).astype(np.int8)
+                tb_list[i].rv = 2
+        e_off = np.cumsum([0] + [p.size for p in e_parts])
+        for i in range(len(cases)):
+            tb_list[i].e_offset = int(e_off[i])
+        sel = [tb_list[i] for i in active]
+        tbs_arr = (capi.HipTb * len(sel))(*sel)
+        res = (capi.HipTbResult * len(sel))()
+        d_e = S.DeviceBuffer.from_numpy(np.concatenate(e_parts))
+        d_soft = S.DeviceBuffer.from_numpy(softbuf)
+        d_data = d_data or S.DeviceBuffer.from_numpy(np.zeros(data_off, np.uint8))
+        capi.check(lib.srsran_hip_sch_decode_8bit(h, d_e.ptr, tbs_arr, len(sel), 8, d_soft.ptr, O.P(cb_crc), d_data.ptr, res, None), "sch_decode_8bit")
+        softbuf[:] = d_soft.to_numpy(np.int8, softbuf.shape)
+        data = d_data.to_numpy(np.uint8, (data_off,))
+        n_ok, failed = 0, []
+        for j, i in enumerate(active):
+            (tbs, Qm, G, snr), tb, (payload, s) = cases[i], tb_list[i], truth[i]
+            ret, o_data, o_avg = O.sch_decode_tb(tbs, Qm, tb.rv, e_parts[i], o_soft[i], o_crc[i], 8, cb_data=o_cbd[i])
+            assert res[j].crc_ok == ret, (rnd, i, res[j].crc_ok, ret)
+            assert abs(res[j].avg_iterations - o_avg) < 1e-6, (rnd, i, res[j].avg_iterations, o_avg)
+            assert np.array_equal(cb_crc[tb.first_cb:tb.first_cb + s["C"]], o_crc[i]), (rnd, i)
+            for c in range(s["C"]):
+                K = s["K1"] if c < s["C1"] else s["K2"]
+                assert np.array_equal(_mask_tail_slots(softbuf[tb.first_cb + c], K), _mask_tail_slots(o_soft[i][c], K)), (rnd, i, c)
+            if ret == 0:
+                n_ok += 1
+                assert np.array_equal(data[tb.data_offset:tb.data_offset + tbs // 8 + 3], payload[:tbs // 8 + 3]), (rnd, i)
+            else:
+                failed.append(i)
+        assert n_ok >= (3 if rnd == 0 else 1), (rnd, n_ok)
+        active = failed
+    lib.srsran_hip_sch_free(h)
+
+
 def test_harq_retransmission_and_errors(hiplib):
     """first transmission too noisy, the retransmission (rv 2) combines in the soft buffers; code blocks already decoded
     are skipped (their flag is set, their bytes stay in d_data)"""

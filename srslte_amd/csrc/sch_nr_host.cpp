@@ -248,8 +248,14 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
     for (uint32_t i = 0; i < n_jobs; i++) {
       order[i] = i;
     }
-    auto rm_key = [&](const Job& j) { return std::make_tuple(j.bg, j.Z, j.rv, j.mod, j.Nref, j.F); };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rm_key(jobs[a]) < rm_key(jobs[b]); });
+    // (one integer key per job; a call whose blocks all share their parameters -- the usual case -- is already in order)
+    auto rm_key = [&](const Job& j) {
+      return ((uint64_t)j.bg << 60) | ((uint64_t)j.Z << 48) | ((uint64_t)j.rv << 46) | ((uint64_t)j.mod << 40) | ((uint64_t)j.Nref << 20) | (uint64_t)j.F;
+    };
+    auto by_rm = [&](uint32_t a, uint32_t b) { return rm_key(jobs[a]) < rm_key(jobs[b]); };
+    if (!std::is_sorted(order.begin(), order.end(), by_rm)) {
+      std::stable_sort(order.begin(), order.end(), by_rm);
+    }
     std::vector<srsran_hip_ldpc_cb_t> cbs;
     for (uint32_t i = 0; i < n_jobs;) {
       uint32_t e = i;
@@ -268,8 +274,11 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
       i = e;
     }
     // ---- decoding with CRC early stop, grouped by decoder and code-word length
-    auto dec_key = [&](const Job& j) { return std::make_tuple(j.bg, j.Z, j.n_llr, j.poly); };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return dec_key(jobs[a]) < dec_key(jobs[b]); });
+    auto dec_key = [&](const Job& j) { return ((uint64_t)j.bg << 60) | ((uint64_t)j.Z << 48) | ((uint64_t)j.n_llr << 28) | (uint64_t)(j.poly & 0xfffffffu); };
+    auto by_dec  = [&](uint32_t a, uint32_t b) { return dec_key(jobs[a]) < dec_key(jobs[b]); };
+    if (!std::is_sorted(order.begin(), order.end(), by_dec)) {
+      std::stable_sort(order.begin(), order.end(), by_dec);
+    }
     if (!ensure(&h->d_iter, &h->h_iter, &h->iter_cap, n_jobs) || !ensure(&h->d_map, &h->h_map, &h->map_cap, n_jobs) ||
         !ensure(&h->d_cbf, &h->h_cbf, &h->cbf_cap, n_jobs)) {
       return SRSRAN_ERROR;

@@ -314,3 +314,61 @@ def test_transport_block_encode_matches_reference_chain(hiplib):
         assert np.array_equal(got[o:o + e.size], e), k
     assert hiplib.srsran_hip_sch_nr_encode(h, d_pay.ptr, arr, 0, d_e.ptr, None) == 0
     hiplib.srsran_hip_sch_nr_free(h)
+
+
+def test_large_transport_block_vs_oracle(hiplib):
+    """a transport block of 21 code blocks whose rate-matched lengths come in both sizes of sch_nr_get_E (G / (N_L Qm) not a multiple of
+    C), two layers, limited buffer: device encode and decode against the oracle's restatement of the loops"""
+    import ctypes as C
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    tbs, R, mod, Nl, rv = 176208, 0.8, 3, 2, 0  # B = 176232 -> C = 21, K' = 8416, Z = 384, F = 32
+    G = 12 * 19003                                # 19003 = 21 * 904 + 19: the last 19 blocks get one more symbol per layer
+    Nref = 20000
+    cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, Nref)
+    assert (cfg.C, cfg.Z, cfg.F, cfg.L_cb) == (21, 384, 32, 24)
+    Es = [O.sch_nr_get_E(cfg, r) for r in range(cfg.C)]
+    assert len(set(Es)) == 2 and sum(Es) == G
+    rng = np.random.default_rng(11)
+    payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+    e = O.sch_nr_encode_tb(cfg, rv, payload)
+    h = C.c_void_p()
+    capi.check(hiplib.srsran_hip_sch_nr_create(C.byref(h), 0.8, 6, 24), "create")
+    tb = (capi.HipNrTb * 1)(capi.HipNrTb(R, tbs, mod, rv, Nl, G, Nref, 0, 0, 2, 0))
+    d_pay = S.DeviceBuffer.from_numpy(payload)
+    d_e = S.DeviceBuffer.from_numpy(np.zeros(G, np.uint8))
+    capi.check(hiplib.srsran_hip_sch_nr_encode(h, d_pay.ptr, tb, 1, d_e.ptr, None), "encode")
+    capi.check(hiplib.srsran_hip_stream_sync(None), "sync")
+    assert np.array_equal(d_e.to_numpy(np.uint8, (G,)), e)
+    llr = np.clip(np.round(9.0 * (1.0 - 2.0 * e) + 5.0 * rng.standard_normal(G)), -63, 63).astype(np.int8)
+    SB, DS = 66 * 384, 8448 // 8
+    d_llr = S.DeviceBuffer.from_numpy(llr)
+    d_soft = S.DeviceBuffer.from_numpy(np.zeros((24, SB), np.int8))
+    d_data = S.DeviceBuffer.from_numpy(np.zeros((24, DS), np.uint8))
+    d_out = S.DeviceBuffer.from_numpy(np.zeros(tbs // 8, np.uint8))
+    cb_crc = np.zeros(24, np.uint8)
+    res = (capi.HipNrTbResult * 1)()
+    capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, tb, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_out.ptr, res, None), "decode")
+    soft, crc, data = np.zeros((cfg.C, SB), np.int8), np.zeros(cfg.C, np.uint8), np.zeros((cfg.C, DS), np.uint8)
+    out, ok, avg = O.sch_nr_decode_tb(cfg, rv, 0.8, 6, llr, soft, crc, data)
+    assert np.array_equal(cb_crc[2:2 + cfg.C], crc) and (res[0].crc_ok, res[0].all_decoded) == (ok, int(crc.all()))
+    assert abs(res[0].avg_iter - avg) < 1e-6
+    assert np.array_equal(d_soft.to_numpy(np.int8, (24, SB))[2:2 + cfg.C], soft)
+    if crc.all():
+        assert np.array_equal(d_out.to_numpy(np.uint8, (tbs // 8,)), out) and (not ok or np.array_equal(out, payload))
+    assert 0 < crc.sum() < cfg.C  # the operating point leaves some code blocks undecoded ...
+    # ... and a second transmission (rv 2) carries the soft bits of exactly those (sch_nr.c:584-588,665)
+    e2 = O.sch_nr_encode_tb(cfg, 2, payload)
+    off = np.cumsum([0] + Es)
+    keep = np.concatenate([e2[off[r]:off[r + 1]] for r in range(cfg.C) if not crc[r]])
+    llr2 = np.clip(np.round(9.0 * (1.0 - 2.0 * keep) + 3.0 * rng.standard_normal(keep.size)), -63, 63).astype(np.int8)
+    d_llr2 = S.DeviceBuffer.from_numpy(llr2)
+    tb[0].rv = 2
+    capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr2.ptr, tb, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_out.ptr, res, None), "decode 2")
+    out, ok, avg = O.sch_nr_decode_tb(cfg, 2, 0.8, 6, llr2, soft, crc, data)
+    assert np.array_equal(cb_crc[2:2 + cfg.C], crc) and (res[0].crc_ok, res[0].all_decoded) == (ok, int(crc.all())) and abs(res[0].avg_iter - avg) < 1e-6
+    assert np.array_equal(d_soft.to_numpy(np.int8, (24, SB))[2:2 + cfg.C], soft)
+    assert ok == 1 and np.array_equal(d_out.to_numpy(np.uint8, (tbs // 8,)), payload)
+    hiplib.srsran_hip_sch_nr_free(h)

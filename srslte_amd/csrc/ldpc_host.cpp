@@ -243,7 +243,7 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
     const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
     const size_t cpb = (size_t)choose_cpb(ls, (size_t)d.N * ls * (dtype == ldpc::DT_F32 ? 4 : 2));
     size_t       slots = ((size_t)(max_nof_cw ? max_nof_cw : 1) + cpb - 1) / cpb;
-    slots              = slots < 1024 ? slots : 1024; // 256 CUs x at most 4 resident workgroups
+    slots              = slots < 2048 ? slots : 2048; // resident workgroups (256 CUs x at most 4) and, for early stop, as many queued behind them
     h->cpb             = (int)cpb;
     h->slots           = (int)slots;
     PHY_HIP_CHECK(hipMalloc(&h->d_c2v, slots * cpb * d.E * ls * es), SRSRAN_ERROR);

@@ -54,6 +54,10 @@ typedef struct {
   uint32_t data_offset; /* first decoded byte in d_data; tbs/8 + 6 bytes are written */
   uint32_t first_cb;    /* first code-block slot (soft buffer, cb_crc) of this block */
 } srsran_hip_tb_t;
+/* OR-ed into srsran_hip_tb_t.rv: the block is new data (the caller would srsran_softbuffer_rx_reset it before decode_tb): its soft
+ * buffer rows are overwritten by the rate de-matcher instead of accumulated into, so they need not be cleared beforehand; the
+ * cb_crc flags of the block must be 0. */
+#define SRSRAN_HIP_TB_NEW_DATA 0x100u
 
 typedef struct {
   int32_t  crc_ok;         /* SRSRAN_SUCCESS or SRSRAN_ERROR: what decode_tb returns */

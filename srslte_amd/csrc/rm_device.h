@@ -13,6 +13,7 @@ struct RxJob {
   uint32_t out_offset; // start of this code block's soft buffer (elements)
   uint32_t out_len;    // 3K + 12
   uint32_t table;      // offset of the position table of (K, rv, layout) in the table pool (uint16 elements)
+  uint32_t fresh;      // 1: the soft buffer holds nothing yet (new data): overwrite all of it instead of accumulating
 };
 
 struct TbCrcJob {

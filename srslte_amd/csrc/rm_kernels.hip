@@ -180,10 +180,10 @@ __global__ __launch_bounds__(512) void rm_rx_gather_lds_kernel(const T* in, T* o
       for (int i = 0; i < V; i++) {
         any = any || (k[i] != 0xffffu && k[i] < jb.in_len);
       }
-      if (!any) {
+      if (!any && !jb.fresh) {
         continue;
       }
-      uint4 cur = *reinterpret_cast<uint4*>(dst + j0);
+      uint4 cur = jb.fresh ? make_uint4(0u, 0u, 0u, 0u) : *reinterpret_cast<uint4*>(dst + j0);
       T*    e   = reinterpret_cast<T*>(&cur);
 #pragma unroll
       for (int i = 0; i < V; i++) {
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(512) void rm_rx_gather_lds_kernel(const T* in, T* o
       for (uint32_t j = j0; j < j0 + V && j < out_span; j++) {
         const uint32_t k = inv[j];
         if (k != 0xffffu && k < jb.in_len) {
-          dst[j] = (T)(dst[j] + gather(k));
+          dst[j] = (T)((jb.fresh ? (T)0 : dst[j]) + gather(k));
+        } else if (jb.fresh) {
+          dst[j] = (T)0;
         }
       }
     }

@@ -139,7 +139,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
     results[t] = {SRSRAN_ERROR, 0.f, 0};
-    if (srsran_cbsegm(&seg[t], tb.tbs) || tb.Qm == 0 || tb.rv > 3 || (tb.tbs & 7)) {
+    if (srsran_cbsegm(&seg[t], tb.tbs) || tb.Qm == 0 || (tb.rv & ~(uint32_t)SRSRAN_HIP_TB_NEW_DATA) > 3 || (tb.tbs & 7)) {
       set_error("sch decode: transport block %u: invalid tbs / Qm / rv", t);
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
@@ -179,7 +179,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
       w.K      = K;
       w.slot   = tb.first_cb + i;
       w.poly   = cs.C > 1 ? CRC24B : CRC24A; // sch.c:432-438
-      w.job    = {tb.e_offset + rp, n_e2, w.slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 3 * K + 12, 0};
+      w.job    = {tb.e_offset + rp, n_e2, w.slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 3 * K + 12, 0, (tb.rv & SRSRAN_HIP_TB_NEW_DATA) ? 1u : 0u};
       w.desc   = {w.slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, tb.data_offset + i * rlen / 8,
                   (i + 1 == cs.C) ? K / 8 : rlen / 8, 0};
       work.push_back(w);
@@ -205,7 +205,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   // group by (K, rv, generator): one rate de-matching launch and one decoder launch per group
   std::map<uint64_t, std::vector<size_t>> groups;
   for (size_t i = 0; i < n; i++) {
-    groups[((uint64_t)work[i].K << 34) | ((uint64_t)tbs[work[i].tb].rv << 32) | work[i].poly].push_back(i);
+    groups[((uint64_t)work[i].K << 34) | ((uint64_t)(tbs[work[i].tb].rv & 3u) << 32) | work[i].poly].push_back(i);
   }
   std::vector<rm::RxJob>     jobs;
   std::vector<turbo::CbDesc> descs;
@@ -236,6 +236,16 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
     uint32_t max_in = 0;
     for (uint32_t i = 0; i < m; i++) {
       max_in = std::max(max_in, work[g.second[i]].job.in_len);
+    }
+    if ((size_t)max_in * (llr8 ? 1 : 2) > 40 * 1024 - 16) {
+      // (the kernel for inputs beyond its LDS staging area only accumulates: clear the new blocks' rows here)
+      for (uint32_t i = 0; i < m; i++) {
+        const CbWork& w = work[g.second[i]];
+        if (w.job.fresh) {
+          PHY_HIP_CHECK(hipMemsetAsync(static_cast<uint8_t*>(d_softbuf) + (size_t)w.job.out_offset * (llr8 ? 1 : 2), 0,
+                                       (size_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE * (llr8 ? 1 : 2), st), SRSRAN_ERROR);
+        }
+      }
     }
     PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, max_in), SRSRAN_ERROR);
     if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {

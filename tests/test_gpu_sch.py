@@ -77,6 +77,58 @@ def test_batch_of_transport_blocks_vs_oracle(hiplib):
     lib.srsran_hip_sch_free(h)
 
 
+def test_new_data_flag_overwrites_the_soft_buffer(hiplib):
+    """SRSRAN_HIP_TB_NEW_DATA in rv: the rows of a new block need no srsran_softbuffer_rx_reset -- de-matching overwrites whatever they
+    hold (16- and 8-bit), with the result of a cleared buffer"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(21)
+    h = C.c_void_p()
+    assert lib.srsran_hip_sch_create(C.byref(h)) == 0
+    NEW = 0x100
+    for dt in (np.int16, np.int8):
+        cases = [(75376, 6, 100800, 5.5), (4584, 2, 9000, 3.0), (12216, 4, 26000, 3.5)]
+        tb_list, e_parts, first_cb, data_off, segs = [], [], 1, 0, []
+        for i, (tbs, Qm, G, snr) in enumerate(cases):
+            e16, payload = O.make_tb(tbs, Qm, G, 0, snr, rng)
+            e = e16 if dt == np.int16 else np.clip(np.round(e16 * (10.0 / np.mean(np.abs(e16)))), -100, 100).astype(np.int8)
+            s = O.cbsegm(tbs)
+            tb_list.append(capi.HipTb(tbs, Qm, NEW if i != 1 else 0, G, sum(p.size for p in e_parts), data_off, first_cb))
+            e_parts.append(e)
+            segs.append(s)
+            first_cb += s["C"] + 1
+            data_off += tbs // 8 + 8
+        lim = 100 if dt == np.int8 else 20000
+        softbuf = rng.integers(-lim, lim, (first_cb, SB)).astype(dt)  # rubbish everywhere ...
+        for s, tb in zip(segs[1:2], tb_list[1:2]):
+            softbuf[tb.first_cb:tb.first_cb + s["C"]] = 0                # ... except under the block without the flag
+        guard = softbuf.copy()
+        cb_crc = np.zeros(first_cb, np.uint8)
+        tbs_arr = (capi.HipTb * len(tb_list))(*tb_list)
+        res = (capi.HipTbResult * len(tb_list))()
+        d_e = S.DeviceBuffer.from_numpy(np.concatenate(e_parts))
+        d_soft = S.DeviceBuffer.from_numpy(softbuf)
+        d_data = S.DeviceBuffer.from_numpy(np.zeros(data_off, np.uint8))
+        fn = lib.srsran_hip_sch_decode if dt == np.int16 else lib.srsran_hip_sch_decode_8bit
+        capi.check(fn(h, d_e.ptr, tbs_arr, len(tb_list), 8, d_soft.ptr, O.P(cb_crc), d_data.ptr, res, None), "decode")
+        got = d_soft.to_numpy(dt, softbuf.shape)
+        used = np.zeros(first_cb, bool)
+        for i, ((tbs, Qm, G, snr), tb, s) in enumerate(zip(cases, tb_list, segs)):
+            o_soft, o_crc = np.zeros((s["C"], SB), dt), np.zeros(s["C"], np.uint8)
+            ret, o_data, o_avg = O.sch_decode_tb(tbs, Qm, 0, e_parts[i], o_soft, o_crc, 8)
+            assert res[i].crc_ok == ret and (ret == 0 or dt == np.int8) and abs(res[i].avg_iterations - o_avg) < 1e-6, (dt, i, ret)
+            assert np.array_equal(cb_crc[tb.first_cb:tb.first_cb + s["C"]], o_crc), (dt, i)
+            for c in range(s["C"]):
+                K = s["K1"] if c < s["C1"] else s["K2"]
+                n = 3 * (K + 32) + 12
+                assert np.array_equal(_mask_tail_slots(got[tb.first_cb + c][:n], K), _mask_tail_slots(o_soft[c][:n], K)), (dt, i, c)
+                used[tb.first_cb + c] = True
+        assert np.array_equal(got[~used], guard[~used])  # rows of no block are not touched
+    lib.srsran_hip_sch_free(h)
+
+
 def test_batch_of_transport_blocks_8bit_vs_oracle(hiplib):
     """q->llr_is_8bit (sch.c:408-412,426-428): int8 LLRs, srsran_rm_turbo_rx_lut_8bit, the 8-bit window decoders (32 / 16 / 8
     sub-blocks), same loop; incl. a second transmission of a block whose first one fails"""

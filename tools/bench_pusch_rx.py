@@ -42,7 +42,7 @@ def main():
     d_data = torch.zeros((a.tbs, dlen), dtype=torch.uint8, device=dev)
     d_soft = torch.zeros((a.tbs * ncb, capi.SOFTBUFFER_CB_SIZE), dtype=torch.int16, device=dev)
     jobs = (capi.HipDemodJob * a.tbs)(*[capi.HipDemodJob(mod, nsym, i * nsym, i * G, pool[i % pool_n][2], 1) for i in range(a.tbs)])
-    tb_arr = (capi.HipTb * a.tbs)(*[capi.HipTb(tbs, Qm, 0, G, i * G, i * dlen, i * ncb) for i in range(a.tbs)])
+    tb_arr = (capi.HipTb * a.tbs)(*[capi.HipTb(tbs, Qm, 0x100, G, i * G, i * dlen, i * ncb) for i in range(a.tbs)])
     res = (capi.HipTbResult * a.tbs)()
     flags = np.zeros(a.tbs * ncb, np.uint8)
     hd, hs = C.c_void_p(), C.c_void_p()
@@ -54,7 +54,7 @@ def main():
 
     def step():
         flags[:] = 0
-        d_soft.zero_()  # first transmission: srsran_softbuffer_rx_reset
+        # first transmission: the blocks carry SRSRAN_HIP_TB_NEW_DATA (0x100 in rv), which stands for srsran_softbuffer_rx_reset
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev[0].record()

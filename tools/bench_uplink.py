@@ -89,7 +89,7 @@ def main():
     flags = np.zeros(n_tb * ncb, np.uint8)
     res = (capi.HipTbResult * n_tb)()
     jobs = (capi.HipDemodJob * n_tb)(*[capi.HipDemodJob(mod, n_re, i * n_re, i * G, seeds[i % pool_n], 1) for i in range(n_tb)])
-    rxd = (capi.HipTb * n_tb)(*[capi.HipTb(tbs, Qm, 0, G, i * G, i * dlen, i * ncb) for i in range(n_tb)])
+    rxd = (capi.HipTb * n_tb)(*[capi.HipTb(tbs, Qm, 0x100, G, i * G, i * dlen, i * ncb) for i in range(n_tb)])
     dem, sch = C.c_void_p(), C.c_void_p()
     capi.check(lib.srsran_hip_demod_create(C.byref(dem)), "demod")
     capi.check(lib.srsran_hip_sch_create(C.byref(sch)), "sch")
@@ -100,7 +100,7 @@ def main():
 
     def step():
         flags[:] = 0
-        d_soft.zero_()
+        # first transmission: SRSRAN_HIP_TB_NEW_DATA (0x100 in rv) stands for srsran_softbuffer_rx_reset
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -98,6 +98,11 @@ SRSRAN_API void srsran_hip_nr_sch_free(srsran_hip_nr_sch_t* h);
 SRSRAN_API int srsran_hip_ldpc_rm_rx_batch(srsran_hip_nr_sch_t* h, int llr_type, const void* d_in, void* d_softbuf,
                                            const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb, uint32_t F, srsran_basegraph_t bg, uint32_t ls,
                                            uint32_t rv, srsran_mod_t mod_type, uint32_t Nref, void* stream);
+/* the same with a flag per code block (may be NULL): 1 = new data, the block's soft-buffer row is overwritten -- what
+ * srsran_softbuffer_rx_reset followed by the first srsran_ldpc_rm_rx_c leaves there -- instead of accumulated into */
+SRSRAN_API int srsran_hip_ldpc_rm_rx_batch_new(srsran_hip_nr_sch_t* h, int llr_type, const void* d_in, void* d_softbuf,
+                                               const srsran_hip_ldpc_cb_t* cbs, const uint8_t* new_data, uint32_t n_cb, uint32_t F,
+                                               srsran_basegraph_t bg, uint32_t ls, uint32_t rv, srsran_mod_t mod_type, uint32_t Nref, void* stream);
 SRSRAN_API int srsran_hip_ldpc_rm_tx_batch(srsran_hip_nr_sch_t* h, const uint8_t* d_codewords, uint8_t* d_out,
                                            const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb, srsran_basegraph_t bg, uint32_t ls, uint32_t rv,
                                            srsran_mod_t mod_type, uint32_t Nref, void* stream);
@@ -114,7 +119,7 @@ typedef struct {
   double   R;              /* target code rate (base-graph choice, sch_nr.c:35-45) */
   uint32_t tbs;            /* transport block size A in bits */
   uint32_t mod;            /* srsran_mod_t */
-  uint32_t rv;
+  uint32_t rv;             /* 0..3, | SRSRAN_HIP_NR_TB_NEW_DATA: new data, the soft-buffer rows of the block are overwritten (no reset needed) */
   uint32_t N_L;            /* layers */
   uint32_t nof_bits;       /* G */
   uint32_t Nref;           /* limited-buffer rate-matching size (sch_nr.c:119-126 derive it from the carrier); 0: full buffer */
@@ -123,6 +128,8 @@ typedef struct {
   uint32_t first_cb;
   uint32_t reserved;
 } srsran_hip_nr_tb_t;
+
+#define SRSRAN_HIP_NR_TB_NEW_DATA 0x100u
 
 typedef struct {
   int32_t  crc_ok;      /* res->crc (false when not every code block is decoded, where the reference leaves it untouched) */

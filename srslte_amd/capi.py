@@ -436,6 +436,7 @@ def lib():
             "srsran_hip_nr_sch_create": (i32, [C.POINTER(vp)]),
             "srsran_hip_nr_sch_free": (None, [vp]),
             "srsran_hip_ldpc_rm_rx_batch": (i32, [vp, i32, vp, vp, C.POINTER(HipLdpcCb), u32, u32, i32, u32, u32, i32, u32, vp]),
+            "srsran_hip_ldpc_rm_rx_batch_new": (i32, [vp, i32, vp, vp, C.POINTER(HipLdpcCb), vp, u32, u32, i32, u32, u32, i32, u32, vp]),
             "srsran_hip_ldpc_rm_tx_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, u32, i32, u32, vp]),
             "srsran_hip_ldpc_encode_batch": (i32, [vp, vp, vp, C.POINTER(HipLdpcCb), u32, i32, u32, vp]),
             "srsran_predecoding_single": (i32, [vp, vp, vp, vp, i32, C.c_float, C.c_float]),

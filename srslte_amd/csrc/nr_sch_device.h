@@ -13,7 +13,7 @@ struct CbJob { // one code block
   uint32_t in_off;  // elements
   uint32_t out_off; // elements
   uint32_t E;       // rate-matched length
-  uint32_t aux;     // encoder: cdwd_rm_length after clamping / rounding
+  uint32_t aux;     // encoder: cdwd_rm_length after clamping / rounding; de-matcher: bit 0 = new data (overwrite, do not accumulate)
 };
 
 struct RmParams { // init_rm, ldpc_rm.c:113-167
@@ -26,7 +26,8 @@ struct RmParams { // init_rm, ldpc_rm.c:113-167
   int          type;
 };
 
-hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream); // max_E: the largest job.E of the batch
+// max_E: the largest job.E of the batch; min_E_new: the smallest job.E among the jobs flagged as new data (aux bit 0), ~0u if none
+hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream, uint32_t min_E_new = ~0u);
 hipError_t launch_rm_tx(const RmParams& p, hipStream_t stream); // uint8 code words -> uint8 rate-matched bits
 
 #define NRSCH_MAX_CORE_TERMS 4

@@ -190,7 +190,7 @@ struct srsran_hip_nr_sch {
   }
 
   // job list -> device (the previous call's kernel must have consumed the buffer first)
-  int stage(const srsran_hip_ldpc_cb_t* cbs, uint32_t n, const Graph* enc, hipStream_t st)
+  int stage(const srsran_hip_ldpc_cb_t* cbs, uint32_t n, const Graph* enc, hipStream_t st, const uint8_t* new_data = nullptr)
   {
     if (pending) {
       PHY_HIP_CHECK(hipEventSynchronize(done), SRSRAN_ERROR);
@@ -208,7 +208,7 @@ struct srsran_hip_nr_sch {
       cap = c;
     }
     for (uint32_t i = 0; i < n; i++) {
-      h_jobs[i] = nrsch::CbJob{cbs[i].in_offset, cbs[i].out_offset, cbs[i].E, enc ? enc_layers(*enc, cbs[i].E) : 0u};
+      h_jobs[i] = nrsch::CbJob{cbs[i].in_offset, cbs[i].out_offset, cbs[i].E, enc ? enc_layers(*enc, cbs[i].E) : ((new_data && new_data[i]) ? 1u : 0u)};
     }
     PHY_HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, n * sizeof(nrsch::CbJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
     return SRSRAN_SUCCESS;
@@ -258,7 +258,7 @@ extern "C" void srsran_hip_nr_sch_free(srsran_hip_nr_sch_t* h)
 }
 
 static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d_in, void* d_out, const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb,
-                    uint32_t F, int bg, uint32_t ls, uint32_t rv, int mod, uint32_t Nref, hipStream_t st)
+                    uint32_t F, int bg, uint32_t ls, uint32_t rv, int mod, uint32_t Nref, hipStream_t st, const uint8_t* new_data = nullptr)
 {
   if (!h || (n_cb && (!cbs || !d_in || !d_out)) || llr_type < 0 || llr_type > 2 || n_cb > 65535) {
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -277,8 +277,14 @@ static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d
   if (F > c.K - 2 * ls || c.Ncb == 0 || c.Ncb > 65535) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  if (h->stage(cbs, n_cb, nullptr, st) != SRSRAN_SUCCESS) {
+  if (h->stage(cbs, n_cb, nullptr, st, tx ? nullptr : new_data) != SRSRAN_SUCCESS) {
     return SRSRAN_ERROR;
+  }
+  uint32_t min_E_new = ~0u;
+  for (uint32_t i = 0; !tx && new_data && i < n_cb; i++) {
+    if (new_data[i]) {
+      min_E_new = std::min(min_E_new, cbs[i].E);
+    }
   }
   nrsch::RmParams p{};
   p.in     = d_in;
@@ -291,7 +297,7 @@ static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d
   p.ini_ex = p.end_ex - F;
   p.Qm     = c.Qm;
   p.type   = llr_type == SRSRAN_HIP_LLR_BYTE ? nrsch::T_I8 : (llr_type == SRSRAN_HIP_LLR_SHORT ? nrsch::T_I16 : nrsch::T_F32);
-  PHY_HIP_CHECK(tx ? nrsch::launch_rm_tx(p, st) : nrsch::launch_rm_rx(p, max_E, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(tx ? nrsch::launch_rm_tx(p, st) : nrsch::launch_rm_rx(p, max_E, st, min_E_new), SRSRAN_ERROR);
   return h->finish(st);
 }
 
@@ -300,6 +306,15 @@ extern "C" int srsran_hip_ldpc_rm_rx_batch(srsran_hip_nr_sch_t* h, int llr_type,
                                            uint32_t Nref, void* stream)
 {
   return rm_batch(h, false, llr_type, d_in, d_softbuf, cbs, n_cb, F, (int)bg, ls, rv, (int)mod_type, Nref, (hipStream_t)stream);
+}
+
+// the same with a flag per code block: 1 = new data, its soft-buffer row is overwritten (what srsran_softbuffer_rx_reset + the first
+// srsran_ldpc_rm_rx_c leave there) instead of accumulated into
+extern "C" int srsran_hip_ldpc_rm_rx_batch_new(srsran_hip_nr_sch_t* h, int llr_type, const void* d_in, void* d_softbuf, const srsran_hip_ldpc_cb_t* cbs,
+                                               const uint8_t* new_data, uint32_t n_cb, uint32_t F, srsran_basegraph_t bg, uint32_t ls, uint32_t rv,
+                                               srsran_mod_t mod_type, uint32_t Nref, void* stream)
+{
+  return rm_batch(h, false, llr_type, d_in, d_softbuf, cbs, n_cb, F, (int)bg, ls, rv, (int)mod_type, Nref, (hipStream_t)stream, new_data);
 }
 
 extern "C" int srsran_hip_ldpc_rm_tx_batch(srsran_hip_nr_sch_t* h, const uint8_t* d_codewords, uint8_t* d_out, const srsran_hip_ldpc_cb_t* cbs,

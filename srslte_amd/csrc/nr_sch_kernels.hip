@@ -91,10 +91,22 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const RmParams p, uint32_t l
   const uint32_t A = (p.Ncb - p.k0) - (fe - min(max(p.k0, fi), fe)); // non-filler positions in [k0, Ncb)
   const uint32_t spl = p.Qm >= 8 ? 1u : 8u / p.Qm; // symbols per lane: about 8 soft bits whatever the modulation
   const uint32_t sym_tiles = (cols + 256u * spl - 1) / (256u * spl);
+  const bool fresh = lap == 0 && (job.aux & 1u); // new data: nothing to accumulate into, every position of the lap is written
   if (blockIdx.x >= sym_tiles) {
-    const uint32_t i = p.ini_ex + (blockIdx.x - sym_tiles) * 256u + threadIdx.x;
-    if (lap == 0 && i < p.end_ex) {
-      out[i] = Acc<T>::inf(); // ldpc_rm.c:226-229,266-269,318-321
+    const uint32_t t = blockIdx.x - sym_tiles, fill_tiles = (p.end_ex - p.ini_ex + 255u) / 256u;
+    if (t < fill_tiles) {
+      const uint32_t i = p.ini_ex + t * 256u + threadIdx.x;
+      if (lap == 0 && i < p.end_ex) {
+        out[i] = Acc<T>::inf(); // ldpc_rm.c:226-229,266-269,318-321
+      }
+    } else if (fresh && P) {
+      // the ranks this transmission does not reach: what a cleared soft buffer holds there
+      for (uint32_t u = 0; u < 8; u++) { // 2048 ranks per tile
+        const uint32_t k = min(E, P) + ((t - fill_tiles) * 8u + u) * 256u + threadIdx.x;
+        if (k < P) {
+          out[rx_position(p, fi, fe, A, k)] = (T)0;
+        }
+      }
     }
     return;
   }
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const RmParams p, uint32_t l
       const uint32_t k = i * cols + j;
       if (k >= lo && k < hi) {
         const uint32_t pos = rx_position(p, fi, fe, A, k - lo);
-        out[pos]           = Acc<T>::add(out[pos], in[j * p.Qm + i]);
+        out[pos]           = Acc<T>::add(fresh ? (T)0 : out[pos], in[j * p.Qm + i]);
       }
     }
   }
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p)
 
 } // namespace
 
-hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream)
+hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream, uint32_t min_E_new)
 {
   if (p.n_cb == 0) {
     return hipSuccess;
@@ -256,7 +268,9 @@ hipError_t launch_rm_rx(const RmParams& p, uint32_t max_E, hipStream_t stream)
   const uint32_t P  = p.Ncb - (fe - fi);
   const uint32_t laps = P ? ceil_div(max_E ? max_E : 1u, P) : 1u;
   const uint32_t spl = p.Qm >= 8 ? 1u : 8u / p.Qm;
-  dim3           grid(ceil_div(ceil_div(max_E, p.Qm), 256u * spl) + ceil_div(p.end_ex - p.ini_ex, 256u), p.n_cb);
+  // + tiles that clear the ranks a new block's first transmission does not reach (min_E_new: its shortest length, ~0u: no new block)
+  const uint32_t zero_tiles = (min_E_new != ~0u && min_E_new < P) ? ceil_div(P - min_E_new, 2048u) : 0u;
+  dim3           grid(ceil_div(ceil_div(max_E, p.Qm), 256u * spl) + ceil_div(p.end_ex - p.ini_ex, 256u) + zero_tiles, p.n_cb);
   for (uint32_t lap = 0; lap < laps; lap++) {
     switch (p.type) {
       case T_I8:

@@ -33,7 +33,7 @@ struct TbCfg { // srsran_sch_nr_tb_info_t
 bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
 {
   static const uint32_t qm[5] = {1, 2, 4, 6, 8};
-  if (tb.tbs == 0 || tb.mod > 4 || tb.N_L == 0 || tb.rv > 3) {
+  if (tb.tbs == 0 || tb.mod > 4 || tb.N_L == 0 || (tb.rv & ~SRSRAN_HIP_NR_TB_NEW_DATA) > 3) {
     return false;
   }
   c->bg = ((tb.tbs <= 292) || (tb.tbs <= 3824 && tb.R <= 0.67) || (tb.R <= 0.25)) ? 1 : 0; // sch_nr.c:35-45
@@ -86,7 +86,7 @@ uint32_t get_E(const TbCfg& c, uint32_t j) // sch_nr_get_E, sch_nr.c:146-157 (al
 }
 
 struct Job {
-  uint32_t tb, cb, E, in_off, n_llr, cb_len;
+  uint32_t tb, cb, E, in_off, n_llr, cb_len, fresh;
   int      bg;
   uint32_t Z, rv, mod, Nref, F, poly, order;
 };
@@ -220,10 +220,11 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
       // n_llr of srsran_ldpc_rm_rx_c (ldpc_rm.c:704-705)
       static const uint32_t basek0[4][2] = {{0, 0}, {17, 13}, {33, 25}, {56, 43}};
       const uint32_t        Ncb = c.N <= c.Nref ? c.N : c.Nref;
-      const uint32_t        k0  = c.N <= c.Nref ? c.Z * basek0[tbs[t].rv][c.bg] : c.Z * ((basek0[tbs[t].rv][c.bg] * c.Nref) / c.N);
+      const uint32_t        k0  = c.N <= c.Nref ? c.Z * basek0[tbs[t].rv & 3u][c.bg] : c.Z * ((basek0[tbs[t].rv & 3u][c.bg] * c.Nref) / c.N);
       Job                   j;
       j.tb = t, j.cb = cb, j.E = E, j.in_off = in, j.n_llr = std::min(k0 + E, Ncb), j.cb_len = c.Kp - c.L_cb;
-      j.bg = c.bg, j.Z = c.Z, j.rv = tbs[t].rv, j.mod = tbs[t].mod, j.Nref = c.Nref, j.F = c.F;
+      j.bg = c.bg, j.Z = c.Z, j.rv = tbs[t].rv & 3u, j.mod = tbs[t].mod, j.Nref = c.Nref, j.F = c.F;
+      j.fresh = (tbs[t].rv & SRSRAN_HIP_NR_TB_NEW_DATA) ? 1u : 0u;
       j.poly  = c.L_cb ? 0x1800063u : (c.L_tb == 24 ? 0x1864CFBu : 0x11021u); // :611-615
       j.order = c.L_cb ? 24 : c.L_tb;
       jobs.push_back(j);
@@ -257,17 +258,20 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
       std::stable_sort(order.begin(), order.end(), by_rm);
     }
     std::vector<srsran_hip_ldpc_cb_t> cbs;
+    std::vector<uint8_t>              fresh;
     for (uint32_t i = 0; i < n_jobs;) {
       uint32_t e = i;
       cbs.clear();
+      fresh.clear();
       while (e < n_jobs && rm_key(jobs[order[e]]) == rm_key(jobs[order[i]])) {
         const Job& j = jobs[order[e]];
         cbs.push_back(srsran_hip_ldpc_cb_t{j.in_off, j.cb * sb_stride, j.E});
+        fresh.push_back((uint8_t)j.fresh);
         e++;
       }
       const Job& j = jobs[order[i]];
-      if (srsran_hip_ldpc_rm_rx_batch(h->rm, SRSRAN_HIP_LLR_BYTE, d_e_bits, d_softbuffer, cbs.data(), (uint32_t)cbs.size(), j.F, (srsran_basegraph_t)j.bg,
-                                      j.Z, j.rv, (srsran_mod_t)j.mod, j.Nref, st) != SRSRAN_SUCCESS) {
+      if (srsran_hip_ldpc_rm_rx_batch_new(h->rm, SRSRAN_HIP_LLR_BYTE, d_e_bits, d_softbuffer, cbs.data(), fresh.data(), (uint32_t)cbs.size(), j.F,
+                                          (srsran_basegraph_t)j.bg, j.Z, j.rv, (srsran_mod_t)j.mod, j.Nref, st) != SRSRAN_SUCCESS) {
         set_error("sch_nr: rate de-matching refused (E=%u, Z=%u)", j.E, j.Z);
         return SRSRAN_ERROR;
       }
@@ -418,7 +422,7 @@ extern "C" int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d
       h->h_cbe[row]         = nrsch::CbEnc{t, bit, cb_len, c.Kp, c.Kr, c.L_cb, last ? 1u : 0u, row};
       bit += (cb_len / 8) * 8; // input_ptr += cb_len / 8 (:448)
       const uint32_t E = get_E(c, r);
-      jobs.push_back(EJob{c.bg, c.Z, tbs[t].rv, tbs[t].mod, c.Nref, E, out, row});
+      jobs.push_back(EJob{c.bg, c.Z, tbs[t].rv & 3u, tbs[t].mod, c.Nref, E, out, row});
       out += E;
       row++;
     }

@@ -199,7 +199,10 @@ def test_transport_block_loop_matches_reference_chain(hiplib):
         tbs, R1000, mod, rv, Nl, Gb, Nref, max_iter, Cn, Z, Kr, Kp, F, L_tb, L_cb, bg, n_tx = pars[key]
         capi.check(hiplib.srsran_hip_sch_nr_create(C.byref(h), 0.8, max_iter, 16), "create")
         N = Z * (66 if bg == 0 else 50)
-        d_soft = S.DeviceBuffer.from_numpy(np.zeros((16, SB), np.int8))
+        # the first transmission carries SRSRAN_HIP_NR_TB_NEW_DATA for every second case: rubbish in the soft buffer must not matter
+        new_data = (list(d["cases"]).index(key) % 2) == 1
+        soft0 = np.random.default_rng(5).integers(-60, 60, (16, SB)).astype(np.int8) if new_data else np.zeros((16, SB), np.int8)
+        d_soft = S.DeviceBuffer.from_numpy(soft0)
         d_data = S.DeviceBuffer.from_numpy(np.zeros((16, DS), np.uint8))
         d_pay = S.DeviceBuffer.from_numpy(np.zeros(tbs // 8 + 64, np.uint8))
         cb_crc = np.zeros(16, np.uint8)
@@ -209,7 +212,7 @@ def test_transport_block_loop_matches_reference_chain(hiplib):
             llr = np.concatenate([np.zeros(5, np.int8), d[k + "_llr"]])
             d_llr = S.DeviceBuffer.from_numpy(llr if llr.size else np.zeros(1, np.int8))
             assert np.array_equal(cb_crc[first:first + Cn], d[k + "_crc_in"])
-            tb = (capi.HipNrTb * 1)(capi.HipNrTb(R1000 / 1000.0, tbs, mod, rv if t == 0 else 2, Nl, Gb, Nref, 5, 7, first, 0))
+            tb = (capi.HipNrTb * 1)(capi.HipNrTb(R1000 / 1000.0, tbs, mod, (rv | (0x100 if new_data else 0)) if t == 0 else 2, Nl, Gb, Nref, 5, 7, first, 0))
             res = (capi.HipNrTbResult * 1)()
             capi.check(hiplib.srsran_hip_sch_nr_decode(h, d_llr.ptr, tb, 1, d_soft.ptr, SB, cb_crc.ctypes.data, d_data.ptr, DS, d_pay.ptr, res, None), k)
             assert np.array_equal(cb_crc[first:first + Cn], d[k + "_crc_out"]), k
@@ -218,7 +221,8 @@ def test_transport_block_loop_matches_reference_chain(hiplib):
             assert (res[0].crc_ok, res[0].nof_cb, round(res[0].avg_iter * Cn)) == (ok_ref, Cn, it_sum), k
             assert res[0].all_decoded == int(d[k + "_crc_out"].all())
             soft = d_soft.to_numpy(np.int8, (16, SB))[first:first + Cn, :N]
-            assert zlib.crc32(np.ascontiguousarray(soft).tobytes()) == int(d[k + "_soft_crc"][0]), k
+            if not new_data or Nref >= N:  # (with a limited buffer the positions behind Ncb are never written nor read)
+                assert zlib.crc32(np.ascontiguousarray(soft).tobytes()) == int(d[k + "_soft_crc"][0]), k
             if res[0].all_decoded:
                 pay = d_pay.to_numpy(np.uint8, (tbs // 8 + 64,))
                 assert np.array_equal(pay[7:7 + tbs // 8], d[k + "_out"]), k

@@ -63,6 +63,7 @@ def main():
     d_nit = torch.zeros(n_cb, dtype=torch.int32, device=dev)
     dj = (capi.HipDemodJob * a.tbs)(*[capi.HipDemodJob(mod, nsym_tb, i * nsym_tb, i * ncb_tb * E, seeds[i % pool_tb], 3) for i in range(a.tbs)])
     rxj = (capi.HipLdpcCb * n_cb)(*[capi.HipLdpcCb(i * E, i * N, E) for i in range(n_cb)])
+    new_flags = np.ones(n_cb, np.uint8)
     hd = C.c_void_p()
     capi.check(lib.srsran_hip_demod_create(C.byref(hd)), "demod_create")
     dec = S.LdpcBatch(bg, Z, 0.8, a.iters, n_cb)
@@ -70,13 +71,13 @@ def main():
     parts = []
 
     def step():
-        d_soft.zero_()  # first transmission
+        # first transmission: the de-matcher gets the new-data flag of every block instead of a cleared soft buffer
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev[0].record()
         capi.check(lib.srsran_hip_demod_run(hd, d_sym.data_ptr(), d_llr.data_ptr(), capi.LLR_BYTE, dj, a.tbs, st), "demod")
         ev[1].record()
-        capi.check(lib.srsran_hip_ldpc_rm_rx_batch(h, capi.LLR_BYTE, d_llr.data_ptr(), d_soft.data_ptr(), rxj, n_cb, F, bg, Z, 0, mod, N, st), "rm_rx")
+        capi.check(lib.srsran_hip_ldpc_rm_rx_batch_new(h, capi.LLR_BYTE, d_llr.data_ptr(), d_soft.data_ptr(), rxj, new_flags.ctypes.data, n_cb, F, bg, Z, 0, mod, N, st), "rm_rx")
         ev[2].record()
         capi.check(lib.srsran_hip_ldpc_batch_run_crc(dec._h, d_soft.data_ptr(), N, d_out.data_ptr(), K, n_cb, min(E, N), poly, order,
                                                      d_nit.data_ptr(), st), "ldpc_run_crc")

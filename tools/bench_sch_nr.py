@@ -48,7 +48,7 @@ def main():
     d_pay = torch.zeros((a.tbs, tbs // 8), dtype=torch.uint8, device=dev)
     cb_crc = np.zeros(n_cb, np.uint8)
     dj = (capi.HipDemodJob * a.tbs)(*[capi.HipDemodJob(mod, nsym, i * nsym, i * G, seeds[i % pool_tb], 3) for i in range(a.tbs)])
-    tb = (capi.HipNrTb * a.tbs)(*[capi.HipNrTb(R, tbs, mod, 0, Nl, G, 0, i * G, i * (tbs // 8), i * ncb, 0) for i in range(a.tbs)])
+    tb = (capi.HipNrTb * a.tbs)(*[capi.HipNrTb(R, tbs, mod, 0x100, Nl, G, 0, i * G, i * (tbs // 8), i * ncb, 0) for i in range(a.tbs)])
     res = (capi.HipNrTbResult * a.tbs)()
     hd, hn = C.c_void_p(), C.c_void_p()
     capi.check(lib.srsran_hip_demod_create(C.byref(hd)), "demod_create")
@@ -57,7 +57,7 @@ def main():
     t_demod = []
 
     def step():
-        d_soft.zero_()  # first transmission: srsran_softbuffer_rx_reset
+        # first transmission: SRSRAN_HIP_NR_TB_NEW_DATA (0x100 in rv) stands for srsran_softbuffer_rx_reset
         cb_crc[:] = 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -520,7 +520,6 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   }
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
-  const uint32_t msg_bytes = (liftK + 7) / 8;
   memcpy(c->h_llr, llrs, n_llr * c->esz);
   PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr * c->esz, hipMemcpyHostToDevice, c->stream), -1);
   if (crc) {

@@ -5,7 +5,7 @@
  * meaning, return codes and -- because the handles are caller-allocated and embedded by value in
  * srsran_ue_dl_t / srsran_enb_ul_t / srsran_sch_t / srsran_sch_nr_t -- struct sizes and field
  * offsets are those of the reference headers cited at each block (paths relative to the
- * reference tree).  tests/test_abi_layout.py checks sizes/offsets against the reference headers.
+ * reference tree).  tests/test_host_cpu.py (test_struct_layout_matches_reference / _recorded_reference) checks sizes/offsets against the reference headers.
  *
  * Handles keep their device state behind the pointer fields the reference already has
  * (srsran_dft_plan_t.p, srsran_tdec_t.dec16_hdlr[0], srsran_ldpc_decoder_t.ptr, srsran_ofdm_t.tmp):

@@ -185,6 +185,10 @@ int  orc_sss_generate(float* sf0, float* sf5, uint32_t cell_id);
  * peak value and PSR (pss.c:408-437) */
 int  orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, uint32_t N_id_2,
                   float* corr_out, float* peak_value, float* psr);
+/* pieces of orc_pss_find for an FFT-based port: the time-domain replica (fft_size complex) and the PSR rule on a power vector
+ * that holds conv_output_len + 2 entries (zero behind the computed ones) */
+int   orc_pss_time_replica(float* out, uint32_t N_id_2, uint32_t fft_size);
+float orc_peak_sidelobe(const float* avg, uint32_t corr_peak_pos, uint32_t conv_output_len);
 /* find_sss.c:99-192 partial + sss.c:128-156; input points at the start of the SSS symbol (N samples) */
 int  orc_sss_m0m1_partial(const float* sss_symbol, uint32_t fft_size, uint32_t N_id_2, uint32_t* m0,
                           uint32_t* m1, int* n_id_1, int* sf_idx);

@@ -210,7 +210,8 @@ int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bit
     }
     int16_t* sb  = softbuf + (size_t)i * 18600;
     uint32_t nsb = orc_tdec_autoimp_subblocks(K);
-    if (!nsb || orc_rm_turbo_rx(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
+    /* nsb == 0 (K <= 400): natural soft-buffer layout (rm_turbo.c:412-421) and the scalar decoder (turbodecoder.c:381-408) */
+    if (orc_rm_turbo_rx(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
       return -2;
     }
     uint8_t* out = &data[i * rlen / 8];
@@ -219,7 +220,7 @@ int orc_sch_decode_tb(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_e_bit
     do {
       noi++;
       /* srsran_tdec_iteration noi times from the start = the state after noi half iterations */
-      if (orc_tdec_run_all(sb, out, noi, K, ORC_TDEC_AUTO, 1, NULL, NULL)) {
+      if (orc_tdec_run_all(sb, out, noi, K, ORC_TDEC_AUTO, nsb ? 1 : 0, NULL, NULL)) {
         return -2;
       }
       it += 1;
@@ -272,7 +273,8 @@ int orc_sch_decode_tb_8bit(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_
     }
     int8_t*  sb  = softbuf + (size_t)i * 18600;
     uint32_t nsb = orc_tdec_autoimp_subblocks_8bit(K);
-    if (!nsb || orc_rm_turbo_rx_8bit(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
+    /* nsb == 0 (K <= 400): natural layout; the 8-bit API widens to int16 and runs the scalar decoder (turbodecoder.c:455-478) */
+    if (orc_rm_turbo_rx_8bit(&e_bits[rp], sb, n_e2, K, rv, nsb)) {
       return -2;
     }
     uint8_t* out = &data[i * rlen / 8];
@@ -281,7 +283,7 @@ int orc_sch_decode_tb_8bit(uint32_t tbs, uint32_t Qm, uint32_t rv, uint32_t nof_
     do {
       noi++;
       /* srsran_tdec_iteration noi times from the start = the state after noi half iterations */
-      if (orc_tdec_run_all_8bit(sb, out, noi, K, ORC_TDEC_AUTO, 1, NULL)) {
+      if (orc_tdec_run_all_8bit(sb, out, noi, K, ORC_TDEC_AUTO, nsb ? 1 : 0, NULL)) {
         return -2;
       }
       it += 1;

@@ -173,6 +173,17 @@ int orc_pss_find(const float* input, uint32_t frame_size, uint32_t fft_size, uin
   return (int)peak;
 }
 
+/* the two pieces above for the FFT-convolution port of the search (tests/oracle_api.py::pss_find_fft times the reference's
+ * algorithm shape -- ONE convolution of length frame + fft per hypothesis, convolution.c:113-120 -- on a library FFT) */
+int orc_pss_time_replica(float* out, uint32_t N_id_2, uint32_t fft_size)
+{
+  return pss_time_replica(out, N_id_2, fft_size, 0);
+}
+float orc_peak_sidelobe(const float* avg, uint32_t corr_peak_pos, uint32_t conv_output_len)
+{
+  return peak_sidelobe(avg, corr_peak_pos, conv_output_len);
+}
+
 /* ------------------------------------------------------------------ SSS */
 
 static void zsc_tilde(int* z_tilde, int* s_tilde, int* c_tilde) /* gen_sss.c:31-53 */

@@ -168,11 +168,6 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
         n_e2 = n_e + tb.Qm;
         rp   = (cs.C - gamma) * n_e + (i - (cs.C - gamma)) * n_e2;
       }
-      if ((llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K)) == 0) {
-        set_error("sch decode: code blocks of %u bits go to the scalar decoder, which has no device early stop; "
-                  "use the srsran_tdec_* / srsran_rm_turbo_* entry points for them", K);
-        return SRSRAN_ERROR_INVALID_INPUTS;
-      }
       CbWork w;
       w.tb     = t;
       w.cb_idx = i;
@@ -247,8 +242,9 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
         }
       }
     }
-    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, 3 * (K + 32) + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, max_in), SRSRAN_ERROR);
-    if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, 1, poly, d_noi + at, d_ok + at, st)) {
+    // (blocks of K <= 400 have no sub-block layout: nsb = 0, natural soft buffer, scalar decoder -- turbodecoder.c:381-408, rm_turbo.c:412-421)
+    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, nsb ? 3 * (K + 32) + 12 : 3 * K + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, max_in), SRSRAN_ERROR);
+    if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, nsb ? 1 : 0, poly, d_noi + at, d_ok + at, st)) {
       return SRSRAN_ERROR;
     }
     at += m;

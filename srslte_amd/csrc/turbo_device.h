@@ -54,6 +54,11 @@ struct GenParams {
   uint32_t        n_end;
   int             n_cb;
   int             in_is8;
+  // transport-block decoding (as WinParams): per-block placement and CRC early stop, 0 / null = off
+  const CbDesc*   desc;
+  uint32_t        crc_poly;
+  int*            noi;
+  uint8_t*        crc_ok;
 };
 
 // dwords of workspace per code block for the window decoder with nb sub-blocks

@@ -441,14 +441,35 @@ static uint32_t xpow_mod(uint64_t e, uint32_t poly)
 }
 
 // Transport-block decoding (sch_host.cpp): all half iterations up to max_iterations with the per-block CRC early
-// stop of decode_tb_cb (sch.c:420-454).  Window decoders only; d_desc places every block's input / output.
+// stop of decode_tb_cb (sch.c:420-454); d_desc places every block's input / output.
 int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* d_input, bool in_is8, const turbo::CbDesc* d_desc,
                                         uint8_t* d_output, uint32_t n_cb, uint32_t max_iterations, int sb_layout, uint32_t crc_poly,
                                         int* d_noi, uint8_t* d_crc_ok, hipStream_t stream)
 {
-  if (!h || !h->nb || !d_input || !d_output || !d_desc || n_cb == 0 || n_cb > h->max_cb || max_iterations == 0 || !crc_poly) {
-    set_error("tdec early stop: invalid arguments (window decoders only)");
+  if (!h || !d_input || !d_output || !d_desc || n_cb == 0 || n_cb > h->max_cb || max_iterations == 0 || !crc_poly || (sb_layout && !h->nb)) {
+    set_error("tdec early stop: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!h->nb) {
+    // K <= 400: the scalar decoder (turbodecoder.c:381-408 sends these blocks to gen_impl), one lane per code block
+    turbo::GenParams g = {};
+    g.input     = static_cast<const short*>(d_input);
+    g.output    = d_output;
+    g.ws        = h->d_ws_gen;
+    g.inter     = h->d_inter16;
+    g.deinter   = h->d_deinter16;
+    g.ws_stride = turbo::gen_ws_shorts(h->K);
+    g.K         = h->K;
+    g.n_begin   = 0;
+    g.n_end     = max_iterations;
+    g.n_cb      = (int)n_cb;
+    g.in_is8    = in_is8 ? 1 : 0;
+    g.desc      = d_desc;
+    g.crc_poly  = crc_poly;
+    g.noi       = d_noi;
+    g.crc_ok    = d_crc_ok;
+    PHY_HIP_CHECK(turbo::launch_gen(g, stream), SRSRAN_ERROR);
+    return SRSRAN_SUCCESS;
   }
   uint32_t*& d_mult = h->crc_mult[crc_poly];
   if (!d_mult) {

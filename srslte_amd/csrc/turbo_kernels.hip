@@ -1135,8 +1135,9 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
 
   if (p.n_begin == 0) {
     // int8 input: the 8-bit API widens to int16 when no 8-bit decoder takes this K (turbodecoder.c:455-478)
-    const short*       in16 = p.input + (size_t)cb * p.in_stride;
-    const signed char* in8  = reinterpret_cast<const signed char*>(p.input) + (size_t)cb * p.in_stride;
+    const size_t       in_off = p.desc ? (size_t)p.desc[cb].in_off : (size_t)cb * p.in_stride;
+    const short*       in16 = p.input + in_off;
+    const signed char* in8  = reinterpret_cast<const signed char*>(p.input) + in_off;
     auto               in   = [&](uint32_t i) -> short { return p.in_is8 ? (short)in8[i] : in16[i]; };
     for (uint32_t i = 0; i < K; i++) { // turbodecoder_gen.c:238-258
       GV(oS, i)  = in(3 * i);
@@ -1152,6 +1153,8 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
   }
   const uint16_t* inter   = p.inter;
   const uint16_t* deinter = p.deinter;
+  uint32_t        n_run    = p.n_end; // half iterations completed when the loop is left
+  bool            crc_good = false;
 
   for (uint32_t n = p.n_begin; n < p.n_end; n++) {
     const bool     dec1    = !(n & 1);
@@ -1261,11 +1264,34 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
         GV(oA1, inter[i]) = GV(oE2, i);
       }
     }
+    n_run = n + 1;
+    if (p.crc_poly) {
+      // decode_tb_cb (sch.c:420-454): the checksum of the K hard bits after every half iteration (crc.c:92-140: MSB first,
+      // zero initial state; zero = the block is good); this lane's block stops at its first match
+      const uint32_t oC = (n_run & 1) ? oE1 : oA1;
+      const uint32_t g  = p.crc_poly & 0xffffffu;
+      uint32_t       c  = 0;
+      for (uint32_t i = 0; i < K; i++) {
+        const uint32_t x = GV(oC, i) > 0 ? 1u : 0u;
+        c = ((c << 1) & 0xffffffu) ^ ((((c >> 23) ^ x) & 1u) ? g : 0u);
+      }
+      if (c == 0) {
+        crc_good = true;
+        break;
+      }
+    }
+  }
+  if (p.noi) {
+    p.noi[cb] = (int)(n_run - p.n_begin);
+  }
+  if (p.crc_ok) {
+    p.crc_ok[cb] = crc_good ? 1 : 0;
   }
   // decision (turbodecoder.c:370-378, turbodecoder_gen.c:260-277)
-  const uint32_t oD  = (p.n_end & 1) ? oE1 : oA1;
-  uint8_t*       out = p.output + (size_t)cb * p.out_stride;
-  for (uint32_t jb = 0; jb < K / 8; jb++) {
+  const uint32_t oD        = (n_run & 1) ? oE1 : oA1;
+  uint8_t*       out       = p.output + (p.desc ? (size_t)p.desc[cb].out_off : (size_t)cb * p.out_stride);
+  const uint32_t out_bytes = p.desc ? p.desc[cb].out_bytes : K / 8;
+  for (uint32_t jb = 0; jb < out_bytes; jb++) {
     uint32_t byte = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {

@@ -422,6 +422,73 @@ def sss_detect(symbol, fft_size, N_id_2, M):
     return m0.value, m1.value, v0.value, v1.value, nid.value, sf.value
 
 
+def pss_find_fft(frame, fft_size, N_id_2):
+    """srsran_pss_find_pss in the reference's algorithmic shape: ONE FFT convolution of length frame + fft per hypothesis
+    (pss.c:446-534 -> srsran_conv_fft_cc_run, convolution.c:113-120), |.|^2, first maximum over conv_output_len - 1 entries, PSR --
+    on scipy's pocketfft in complex64, one thread.  A CPU-baseline port (the reference's own FFT backend, FFTW, is absent);
+    pinned to the direct-sum oracle by test_fft_ports_match_the_oracle.  Returns (peak_pos, peak_value, psr)."""
+    import scipy.fft as F
+
+    orc().orc_peak_sidelobe.restype = C.c_float
+    orc().orc_peak_sidelobe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    x = np.ascontiguousarray(frame, np.complex64)
+    n = x.size
+    assert n >= fft_size
+    h = np.zeros(fft_size, np.complex64)
+    assert orc().orc_pss_time_replica(P(h), N_id_2, fft_size) == 0
+    L = n + fft_size
+    X = F.fft(x, L, workers=1)
+    H = F.fft(h, L, workers=1)
+    y = F.ifft(X * H, workers=1)
+    avg = np.zeros(L + 2, np.float32)
+    avg[:L - 2] = (y.real * y.real + y.imag * y.imag)[:L - 2]
+    pk = int(np.argmax(avg[:L - 2]))
+    psr = orc().orc_peak_sidelobe(P(avg), pk, L - 1)
+    return pk, float(avg[pk]), float(psr)
+
+
+def ofdm_rx_fft(cfg, x):
+    """srsran_ofdm_rx_sf (ofdm.c:395-475) for the plain configuration (normal CP, no frequency shift / window offset / MBSFN) on
+    scipy's pocketfft, complex64, one thread: a CPU-baseline port pinned to orc_ofdm_rx by test_fft_ports_match_the_oracle"""
+    import scipy.fft as F
+
+    assert cfg.cp_ext == 0 and cfg.freq_shift_f == 0.0 and cfg.rx_window_offset == 0.0 and cfg.mbsfn_region == 0
+    N, nsym, sf_sz, sf_re = ofdm_geometry(cfg)
+    x = np.ascontiguousarray(x, np.complex64)
+    n_sf = x.shape[0]
+    nre = sf_re // nsym
+    cp0, cp1 = orc().orc_cp_len(N, 160), orc().orc_cp_len(N, 144)
+    out = np.empty((n_sf, nsym, nre), np.complex64)
+    slot = sf_sz // 2
+    starts = [s * slot + cp0 + i * (N + cp1) for s in range(2) for i in range(nsym // 2)]
+    sym = np.stack([x[:, st:st + N] for st in starts], axis=1)  # [n_sf, nsym, N]
+    Y = F.fft(sym, axis=2, workers=1)
+    if cfg.normalize:
+        Y = Y * np.float32(1.0 / np.sqrt(N))
+    half = nre // 2
+    out[:, :, :half] = Y[:, :, N - half:]
+    if cfg.keep_dc:
+        out[:, :, half:] = Y[:, :, :nre - half]
+    else:
+        out[:, :, half:] = Y[:, :, 1:nre - half + 1]
+    return out.reshape(n_sf, sf_re)
+
+
+def capture_cell_search(x, fft_size, M=1):
+    """PSS over the three hypotheses (pss.c:446-534), SSS on the symbol before the strongest peak (find_sss.c):
+    returns (N_id_2, peak_pos, psr, N_id_1, sf_idx) -- what pbch_file_test / cell_search do with a recorded capture"""
+    best = None
+    for n2 in range(3):
+        pk, pv, psr = pss_find(x, fft_size, n2)
+        if best is None or pv > best[2]:
+            best = (n2, pk, pv, psr)
+    n2, pk, pv, psr = best
+    cp = orc().orc_cp_len(fft_size, 144)
+    pos = pk - 2 * fft_size - cp
+    m0, m1, v0, v1, nid, sf = sss_detect(x[pos:pos + fft_size], fft_size, n2, M)
+    return n2, pk, psr, nid, sf
+
+
 # ------------------------------------------------------------------ soft demodulation / descrambling (orc_modem.c)
 LLR_DTYPES = {"s": np.int16, "b": np.int8, "f": np.float32}
 QM = {0: 1, 1: 2, 2: 4, 3: 6, 4: 8}

@@ -197,6 +197,69 @@ def test_batch_of_transport_blocks_8bit_vs_oracle(hiplib):
     lib.srsran_hip_sch_free(h)
 
 
+@pytest.mark.parametrize("llr8", [False, True])
+def test_mixed_small_and_large_transport_blocks(hiplib, llr8):
+    """one call with TBS 16 ... 75,376: blocks of K <= 400 (RAR, paging, SIB, VoLTE sizes) go to the scalar decoder with the natural
+    soft-buffer layout exactly as decode_tb_cb does through srsran_tdec_iteration (turbodecoder.c:381-408: gen_impl; the 8-bit API
+    widens them to int16, :455-478), side by side with the window decoders -- one small block must not fail the batch"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(21 + llr8)
+    h = C.c_void_p()
+    assert lib.srsran_hip_sch_create(C.byref(h)) == 0
+    # K = tbs + 24: 40, 48, 80, 160, 232, 280, 400 (scalar) | 416, 512 (8 windows) | 4608, 13 x 5824, 2 x 6144; one hopeless small block
+    cases = [(16, 2, 120, 4.0), (24, 2, 200, 2.0), (56, 2, 300, 1.0), (75376, 6, 100800, 5.0), (136, 2, 500, 0.0), (208, 4, 640, 1.0),
+             (256, 2, 560, 0.5), (376, 2, 900, 0.0), (392, 2, 1000, 1.0), (488, 6, 1200, 1.0), (4584, 2, 9000, 3.0), (12216, 4, 26000, 3.0),
+             (328, 2, 720, -8.0), (144, 2, 1800, -4.0)]
+    tb_list, e_parts, first_cb, data_off, truth = [], [], 0, 0, []
+    for tbs, Qm, G, snr in cases:
+        e, payload = O.make_tb(tbs, Qm, G, 0, snr, rng)
+        if llr8:
+            e = np.clip(np.round(e * (10.0 / np.mean(np.abs(e)))), -100, 100).astype(np.int8)
+        s = O.cbsegm(tbs)
+        tb_list.append(capi.HipTb(tbs, Qm, 0, G, sum(p.size for p in e_parts), data_off, first_cb))
+        e_parts.append(e)
+        truth.append((payload, s))
+        first_cb += s["C"]
+        data_off += tbs // 8 + 6 + 1
+    dt = np.int8 if llr8 else np.int16
+    softbuf = np.zeros((first_cb, SB), dt)
+    cb_crc = np.zeros(first_cb, np.uint8)
+    tbs_arr = (capi.HipTb * len(tb_list))(*tb_list)
+    res = (capi.HipTbResult * len(tb_list))()
+    d_e = S.DeviceBuffer.from_numpy(np.concatenate(e_parts))
+    d_soft = S.DeviceBuffer.from_numpy(softbuf)
+    d_data = S.DeviceBuffer.from_numpy(np.zeros(data_off, np.uint8))
+    f = lib.srsran_hip_sch_decode_8bit if llr8 else lib.srsran_hip_sch_decode
+    capi.check(f(h, d_e.ptr, tbs_arr, len(tb_list), 8, d_soft.ptr, O.P(cb_crc), d_data.ptr, res, None), "sch_decode")
+    softbuf[:] = d_soft.to_numpy(dt, softbuf.shape)
+    data = d_data.to_numpy(np.uint8, (data_off,))
+    n_ok = n_small_ok = 0
+    for i, ((tbs, Qm, G, snr), tb, (payload, s)) in enumerate(zip(cases, tb_list, truth)):
+        o_soft, o_crc = np.zeros((s["C"], SB), dt), np.zeros(s["C"], np.uint8)
+        ret, o_data, o_avg = O.sch_decode_tb(tbs, Qm, 0, e_parts[i], o_soft, o_crc, 8)
+        assert ret in (0, -1), (i, ret)
+        assert res[i].crc_ok == ret, (i, tbs, res[i].crc_ok, ret)
+        assert res[i].nof_cb == s["C"] and abs(res[i].avg_iterations - o_avg) < 1e-6, (i, tbs, res[i].avg_iterations, o_avg)
+        assert np.array_equal(cb_crc[tb.first_cb:tb.first_cb + s["C"]], o_crc), i
+        assert np.array_equal(data[tb.data_offset:tb.data_offset + tbs // 8 + 6], o_data), (i, tbs)
+        for c in range(s["C"]):
+            K = s["K1"] if c < s["C1"] else s["K2"]
+            if K <= 400:  # natural layout: every position is a rate-matching position, nothing is parked in the buffer
+                assert np.array_equal(softbuf[tb.first_cb + c], o_soft[c]), (i, c)
+            else:
+                assert np.array_equal(_mask_tail_slots(softbuf[tb.first_cb + c], K), _mask_tail_slots(o_soft[c], K)), (i, c)
+        if ret == 0:
+            n_ok += 1
+            n_small_ok += tbs <= 376
+            assert np.array_equal(data[tb.data_offset:tb.data_offset + tbs // 8 + 3], payload)
+    assert n_ok >= 9 and n_small_ok >= 5 and res[12].crc_ok == capi.SRSRAN_ERROR
+    assert any(0 < res[i].avg_iterations < 8 for i in range(len(cases)) if cases[i][0] <= 376)  # the scalar decoder stops early too
+    lib.srsran_hip_sch_free(h)
+
+
 def test_harq_retransmission_and_errors(hiplib):
     """first transmission too noisy, the retransmission (rv 2) combines in the soft buffers; code blocks already decoded
     are skipped (their flag is set, their bytes stay in d_data)"""
@@ -232,12 +295,11 @@ def test_harq_retransmission_and_errors(hiplib):
     assert res[0].crc_ok == capi.SRSRAN_SUCCESS and np.all(cb_crc == 1)
     assert np.array_equal(data[:tbs // 8 + 3], payload)
     assert abs(res[0].avg_iterations - o_avg2) < 1e-6
-    # errors: filler bits (non-standard TBS), scalar-decoder block sizes, bad arguments
+    # errors: filler bits (non-standard TBS), bad arguments
     d = S.DeviceBuffer(1 << 20)
     r = (capi.HipTbResult * 1)()
     flags = np.zeros(4, np.uint8)
-    for bad in (capi.HipTb(6208, 2, 0, 20000, 0, 0, 0), capi.HipTb(256, 2, 0, 1000, 0, 0, 0), capi.HipTb(4584, 0, 0, 9000, 0, 0, 0),
-                capi.HipTb(4584, 2, 4, 9000, 0, 0, 0)):
+    for bad in (capi.HipTb(6208, 2, 0, 20000, 0, 0, 0), capi.HipTb(4584, 0, 0, 9000, 0, 0, 0), capi.HipTb(4584, 2, 4, 9000, 0, 0, 0)):
         flags[:] = 0
         assert lib.srsran_hip_sch_decode(h, d.ptr, (capi.HipTb * 1)(bad), 1, 8, d.ptr, O.P(flags), d.ptr, r, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
     lib.srsran_hip_sch_free(h)

@@ -138,7 +138,12 @@ def test_pss_sss_handle_api(hiplib):
     assert lib.srsran_pss_resize(C.byref(q), 4800, 128, 0) == 0 and lib.srsran_pss_resize(C.byref(q), 9601, 128, 0) == -1
     lib.srsran_pss_free(C.byref(q))
     assert q.max_frame_size == 0
-    assert lib.srsran_pss_init_fft_offset_decim(C.byref(q), frame, N, 0, 4) == -1  # decimation: refused loudly
+    # 128 / 4 = 32 points cannot hold the 62 PSS carriers (the reference would index before its buffers): refused loudly;
+    # a decimation that leaves >= 64 points is accepted (searches: test_gpu_syncfind.py::test_pss_decimated_search)
+    assert lib.srsran_pss_init_fft_offset_decim(C.byref(q), frame, N, 0, 4) == -1
+    assert lib.srsran_pss_init_fft_offset_decim(C.byref(q), frame, N, 0, 5) == -1  # factor outside 1..4
+    assert lib.srsran_pss_init_fft_offset_decim(C.byref(q), frame, N, 0, 2) == 0 and (q.fft_size, q.frame_size, q.decimate) == (64, 4800, 2)
+    lib.srsran_pss_free(C.byref(q))
     # SSS
     s = capi.Sss()
     assert lib.srsran_sss_init(C.byref(s), N) == 0
@@ -162,3 +167,76 @@ def test_pss_sss_handle_api(hiplib):
             assert lib.srsran_sss_subframe(m0.value, m1.value) == sf == 5
     lib.srsran_sss_free(C.byref(s))
     assert s.fft_size == 0
+
+
+def test_reference_captures_known_cells(hiplib):
+    """The recorded air captures of the reference's own tests (tests/golden/sync_captures.npz, see tools/gen_golden.py) through
+    every entry point of the PSS / SSS path: the cell ids must be the ones the reference's test lines state
+    (phch/test/CMakeLists.txt:433,439-442: 150, 1, 150), and every integer the oracle's."""
+    import os
+
+    import srslte_amd as S
+    from srslte_amd import capi
+    from test_oracle_golden import SYNC_CAPTURE_ANSWERS
+
+    lib = hiplib
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sync_captures.npz"))
+    for key in d["cases"]:
+        key = str(key)
+        N, n_use, cell = [int(v) for v in d[key + "_par"]]
+        x = np.ascontiguousarray(d[key + "_x"][:n_use])
+        want_n2, want_pk, want_nid = SYNC_CAPTURE_ANSWERS[key]
+        # (1) batched cell search
+        h, got = _run_batch(S, x[None], n_use, N, 1)
+        best = max(range(3), key=lambda n2: got[n2].peak_value)
+        g = got[best]
+        assert (best, g.peak_pos, g.N_id_1, g.sf_idx, g.sss_available) == (want_n2, want_pk, want_nid, 0, 1), key
+        assert 3 * g.N_id_1 + best == cell
+        for n2 in range(3):
+            pk, pv, psr = O.pss_find(x, N, n2)
+            assert got[n2].peak_pos == pk and abs(got[n2].peak_value - pv) <= 1e-4 * pv and abs(got[n2].psr - psr) <= 1e-3 * psr
+        S.lib().srsran_hip_cellsearch_free(h)
+        # (2) handle API: srsran_pss_find_pss + srsran_sss_m0m1_partial + srsran_sss_N_id_1
+        q = capi.Pss()
+        assert lib.srsran_pss_init_fft(C.byref(q), n_use, N) == 0
+        lib.srsran_pss_set_ema_alpha(C.byref(q), 1.0)
+        peaks = []
+        for n2 in range(3):
+            assert lib.srsran_pss_set_N_id_2(C.byref(q), n2) == 0
+            psr = C.c_float()
+            pk = lib.srsran_pss_find_pss(C.byref(q), O.P(x), C.byref(psr))
+            peaks.append((q.peak_value, pk, psr.value))
+        lib.srsran_pss_free(C.byref(q))
+        n2 = max(range(3), key=lambda i: peaks[i][0])
+        assert (n2, peaks[n2][1]) == (want_n2, want_pk) and peaks[n2][2] > 4.0
+        s = capi.Sss()
+        assert lib.srsran_sss_init(C.byref(s), N) == 0 and lib.srsran_sss_set_N_id_2(C.byref(s), n2) == 0
+        pos = want_pk - 2 * N - O.orc().orc_cp_len(N, 144)
+        sym = x[pos:pos + N].copy()
+        m0, m1, v0, v1 = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_float()
+        assert lib.srsran_sss_m0m1_partial(C.byref(s), O.P(sym), 1, None, C.byref(m0), C.byref(v0), C.byref(m1), C.byref(v1)) == 0
+        om0, om1, ov0, ov1, nid, sf = O.sss_detect(sym, N, n2, 1)
+        assert (m0.value, m1.value) == (om0, om1)
+        assert lib.srsran_sss_N_id_1(C.byref(s), m0.value, m1.value, v0.value + v1.value) == want_nid
+        assert lib.srsran_sss_subframe(m0.value, m1.value) == 0
+        lib.srsran_sss_free(C.byref(s))
+        # (3) srsran_sync_find, as ue_sync / cell search drive it (the buffer holds frame + offset samples)
+        sq = capi.Sync()
+        assert lib.srsran_sync_init(C.byref(sq), n_use, n_use, N) == 0
+        lib.srsran_sync_set_threshold(C.byref(sq), 2.0)
+        lib.srsran_sync_set_em_alpha(C.byref(sq), 1.0)
+        lib.srsran_sync_set_sss_algorithm(C.byref(sq), capi.SSS_PARTIAL_3)
+        lib.srsran_sync_set_N_id_2(C.byref(sq), want_n2)
+        buf = np.zeros(2 * n_use, np.complex64)
+        buf[:n_use] = x
+        pk = C.c_uint32()
+        assert lib.srsran_sync_find(C.byref(sq), O.P(buf), 0, C.byref(pk)) == capi.SYNC_FOUND
+        assert pk.value == want_pk
+        assert lib.srsran_sync_get_cell_id(C.byref(sq)) == cell and lib.srsran_sync_get_sf_idx(C.byref(sq)) == 0
+        assert lib.srsran_sync_get_cp(C.byref(sq)) == capi.CP_NORM
+        lib.srsran_sync_free(C.byref(sq))
+    # the 10 ms capture as a whole: both halves carry cell 1 (subframes 0 and 5)
+    x = np.ascontiguousarray(d["amar_1_92M_sf0_x"][9600:19200])
+    h, got = _run_batch(S, x[None], 9600, 128, 1)
+    assert (got[1].peak_pos, got[1].N_id_1, got[1].sf_idx) == (960, 0, 5)
+    S.lib().srsran_hip_cellsearch_free(h)

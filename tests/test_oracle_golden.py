@@ -148,6 +148,50 @@ def test_sync_glue_reference_outputs():
     assert np.abs(corr - d["cp_corr"]).max() < 1e-4 * np.abs(d["cp_corr"]).max()
 
 
+# (N_id_2, PSS peak, N_id_1) the recorded captures of the reference's own tests must give: the cell ids are what
+# phch/test/CMakeLists.txt:433,439-442 hand to pbch_file_test (default 150, pbch_file_test.c:32-36), pdcch_file_test -c 1
+# and pcfich_file_test -c 150; the peak is the end of slot 0 (7.5 symbols: 960 at 1.92 Msps; the 15.36 Msps capture
+# starts 4 samples late)
+SYNC_CAPTURE_ANSWERS = {"pbch_1_92M": (0, 960, 50), "amar_1_92M_sf0": (1, 960, 0), "pcfich_10M": (0, 7676, 50)}
+
+
+def test_sync_oracle_on_reference_captures():
+    """pins orc_sync.c (PSS correlation + SSS m0/m1) to the only known answers the reference holds for this path"""
+    d = np.load(os.path.join(G, "sync_captures.npz"))
+    assert sorted(str(k) for k in d["cases"]) == sorted(SYNC_CAPTURE_ANSWERS)
+    for key in d["cases"]:
+        key = str(key)
+        N, n_use, cell = [int(v) for v in d[key + "_par"]]
+        x = d[key + "_x"][:n_use]
+        n2, pk, psr, nid, sf = O.capture_cell_search(x, N)
+        assert (n2, pk, nid) == SYNC_CAPTURE_ANSWERS[key], (key, n2, pk, nid)
+        assert 3 * nid + n2 == cell and sf == 0 and psr > 4.0, (key, psr, sf)
+        # the other two hypotheses must not produce a comparable peak
+        for o in range(3):
+            if o != n2:
+                assert O.pss_find(x, N, o)[2] < 2.0
+    # second half of the 10 ms capture: the same cell in subframe 5
+    x = d["amar_1_92M_sf0_x"]
+    n2, pk, psr, nid, sf = O.capture_cell_search(x[9600:19200], 128)
+    assert (n2, pk, nid, sf) == (1, 960, 0, 5)
+
+
+def test_fft_ports_match_the_oracle():
+    """the scipy-FFT restatements bench.py times as CPU baselines (`kind: "port"`) for OFDM and the PSS search give what the C oracle gives"""
+    rng = np.random.default_rng(4)
+    for prb, N, keep_dc in ((6, 128, 0), (100, 2048, 0), (25, 512, 1)):
+        cfg = O.ofdm_cfg(prb, N, 0, 1, keep_dc=keep_dc)
+        n, nsym, sf_sz, sf_re = O.ofdm_geometry(cfg)
+        x = (rng.standard_normal((2, sf_sz)) + 1j * rng.standard_normal((2, sf_sz))).astype(np.complex64)
+        assert np.abs(O.ofdm_rx_fft(cfg, x) - O.ofdm_rx(cfg, x)).max() < 1e-4
+    d = np.load(os.path.join(G, "sync_captures.npz"))
+    x = d["pbch_1_92M_x"][:9600]
+    for n2 in range(3):
+        pk, pv, psr = O.pss_find(x, 128, n2)
+        fpk, fpv, fpsr = O.pss_find_fft(x, 128, n2)
+        assert fpk == pk and abs(fpv - pv) <= 1e-4 * pv and abs(fpsr - psr) <= 1e-3 * psr
+
+
 def test_turbo_known_answer_block():
     """turbodecoder_test.h:69-125: K=504 message and its 1524 coded bits"""
     d = np.load(os.path.join(G, "turbo_ref.npz"))

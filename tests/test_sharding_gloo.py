@@ -46,3 +46,38 @@ def test_shard_range_partitions_exactly():
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+def test_bench_launcher_world_size_2_end_to_end():
+    """`python bench.py --gpus 2` from a plain interpreter: the parent spawns the two ranks itself (no torchrun), they rendezvous
+    on 127.0.0.1 (gloo in this GPU-less rehearsal), broadcast the configuration, take their shard, and rank 0 prints ONE JSON line
+    with n_gpus 2.  --plumbing-only runs no kernels: on the GPU box the same launcher starts the real workers."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--sf", "101",
+                        "--plumbing-only"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["plumbing_only"] is True
+    assert r["config"] == {"n_prb": 100, "n_fft": 2048, "k_cb": 6144, "nit": 8, "cb_per_sf": 13, "sf": 101}
+    assert [tuple(s) for s in r["shards"]] == [(0, 101), (101, 202)]  # weak scaling: the unit list grows with the world size
+    assert r["max_step_time_s"] >= 0.02  # the slowest rank (rank 1 sleeps 20 ms) sets the time
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """a rank that dies must fail the whole run (non-zero exit, no JSON line), not leave the others waiting in a barrier"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # --gpus 2 without --plumbing-only on a box without GPUs: every worker exits with "needs a HIP device"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    import torch
+
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    # a worker launched with a world size that contradicts --gpus refuses to run
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                       env=dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr

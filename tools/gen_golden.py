@@ -26,6 +26,9 @@ No reference source text is stored.
   tests/golden/sch_nr_ref.npz  NR transport blocks through the reference's blocks in the order of sch_nr.c (segmentation, CRCs, LDPC encoder,
                                rate matcher both ways, decoder with CRC early stop): LLRs in, verdicts / iterations / payload out
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
+  tests/golden/sync_captures.npz  the recorded air captures the reference's own tests hold for the PSS / SSS path
+                               (phch/test/signal.1.92M.dat: pbch_file_test, cell 150; signal.1.92M.amar.dat: pdcch_file_test -c 1;
+                               signal.10M.dat: pcfich_file_test -c 150 -n 50) with the cell ids those tests are given
 """
 import ctypes as C
 import os
@@ -226,6 +229,23 @@ def syncglue():
 
 class Args(C.Structure):
     _fields_ = [("type", C.c_int), ("bg", C.c_int), ("ls", C.c_uint16), ("scaling_fctr", C.c_float), ("max_nof_iter", C.c_uint32)]
+
+
+def sync_captures():
+    """data files of the reference's tests + the answers its CMake test lines state (phch/test/CMakeLists.txt:433,439-442;
+    pbch_file_test.c:32-36 default cell id 150).  Samples are stored as they are (complex float32)."""
+    d = {}
+    base = os.path.join(REF, "src/phy/phch/test")
+    # name, file, fft size the capture's sampling rate corresponds to, samples used, cell id of the test line
+    for name, fn, N, n_use, cell in (("pbch_1_92M", "signal.1.92M.dat", 128, 9600, 150),
+                                     ("amar_1_92M_sf0", "signal.1.92M.amar.dat", 128, 9600, 1),
+                                     ("pcfich_10M", "signal.10M.dat", 1024, 7680, 150)):
+        x = np.fromfile(os.path.join(base, fn), dtype=np.complex64)
+        d[name + "_x"] = x
+        d[name + "_par"] = np.array([N, n_use, cell], dtype=np.int32)
+    d["cases"] = np.array(["pbch_1_92M", "amar_1_92M_sf0", "pcfich_10M"])
+    np.savez_compressed(os.path.join(OUT, "sync_captures.npz"), **d)
+    print("sync_captures.npz", os.path.getsize(os.path.join(OUT, "sync_captures.npz")))
 
 
 def ldpc():
@@ -662,6 +682,6 @@ def sch_nr():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr", "sync_captures"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr, "sync_captures": sync_captures}[name]()

@@ -1,6 +1,8 @@
 // common.cpp -- device plumbing shared by every entry point of libsrsran_phy_hip.so
+#include "coalesce.h"
 #include "hip_common.h"
 
+#include <atomic>
 #include <mutex>
 
 namespace phyhip {
@@ -40,9 +42,77 @@ bool device_available()
   return ok;
 }
 
+// ---- submission queues under the handle API (coalesce.h)
+namespace {
+struct Registry {
+  std::mutex                        mu;
+  std::map<std::string, Coalescer*> byKey;
+};
+Registry& registry()
+{
+  static Registry* r = new Registry; // never destroyed: the queues own HIP resources and outlive static destruction order
+  return *r;
+}
+std::atomic<int> g_coalesce{-1}; // -1: not decided yet (environment), 0 / 1
+} // namespace
+
+bool coalescing_enabled()
+{
+  int v = g_coalesce.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("SRSRAN_HIP_COALESCE");
+    v             = (e && e[0] == '0') ? 0 : 1;
+    g_coalesce.store(v, std::memory_order_relaxed);
+  }
+  return v == 1;
+}
+
+Coalescer* coalescer_for(const std::string& key, const std::function<Coalescer*()>& make)
+{
+  Registry&                   r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  auto                        it = r.byKey.find(key);
+  if (it != r.byKey.end()) {
+    return it->second; // may be nullptr: creation failed before, callers fall back to their private path
+  }
+  Coalescer* c = make();
+  if (c && !c->ok()) {
+    delete c;
+    c = nullptr;
+  }
+  r.byKey[key] = c;
+  return c;
+}
+
 } // namespace phyhip
 
 using namespace phyhip;
+
+extern "C" void srsran_hip_set_coalescing(int enable)
+{
+  g_coalesce.store(enable ? 1 : 0, std::memory_order_relaxed);
+}
+
+extern "C" void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_units)
+{
+  uint64_t  b = 0, u = 0;
+  Registry& r = registry();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (auto& kv : r.byKey) {
+    if (kv.second) {
+      uint64_t bb = 0, uu = 0;
+      kv.second->stats(&bb, &uu);
+      b += bb;
+      u += uu;
+    }
+  }
+  if (nof_batches) {
+    *nof_batches = b;
+  }
+  if (nof_units) {
+    *nof_units = u;
+  }
+}
 
 extern "C" int srsran_hip_device_count(void)
 {

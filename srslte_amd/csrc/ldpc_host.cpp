@@ -2,11 +2,13 @@
 //
 // Mirrors (interface + behaviour) lib/src/phy/fec/ldpc/ldpc_decoder.c:540-685 and
 // lib/src/phy/fec/ldpc/base_graph.c:50,4467-4503 of the reference.
+#include "coalesce.h"
 #include "hip_common.h"
 #include "ldpc_device.h"
 #include "tables/nr_ldpc_bg_table.h"
 #include "tables/nr_ldpc_lsindex.h"
 
+#include <map>
 #include <vector>
 
 using namespace phyhip;
@@ -123,9 +125,9 @@ struct srsran_hip_ldpc_batch {
   int      slots    = 1;           // c2v slabs allocated = most workgroups a launch may use
   int*     d_col_start = nullptr;
   int*     d_col_edges = nullptr;
-  uint32_t* d_crc_mult = nullptr; // x^((Z-1-c) bgK) mod g for the generator below (CRC early stop)
-  uint32_t crc_poly = 0;
-  int      crc_order = 0;
+  // x^((Z-1-c) bgK) mod g per generator used with this object (CRC early stop): one device table each, filled on first use and kept --
+  // a batch that alternates CRC24A / CRC24B / CRC16 code words (sch_nr.c:606-619) never re-uploads or synchronises
+  std::map<uint64_t, uint32_t*> crc_mult;
   void*    d_c2v    = nullptr;     // int16 / float: check-to-variable messages, max_cw x E x Z
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
@@ -261,7 +263,9 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
   hipFree(h->d_edges);
   hipFree(h->d_col_start);
   hipFree(h->d_col_edges);
-  hipFree(h->d_crc_mult);
+  for (auto& kv : h->crc_mult) {
+    hipFree(kv.second);
+  }
   hipFree(h->d_c2v);
   delete h;
 }
@@ -353,7 +357,8 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
       set_error("ldpc batch: CRC early stop needs the int8 decoder, a generator of order 8..24 and an iteration array");
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
-    if (!h->d_crc_mult || h->crc_poly != crc_poly || h->crc_order != crc_order) {
+    uint32_t*& d_mult = h->crc_mult[((uint64_t)crc_order << 32) | crc_poly];
+    if (!d_mult) {
       // x^n mod g by repeated multiplication with x; lane c needs n = (Z - 1 - c) * bgK
       const uint32_t mask = (1u << crc_order) - 1u, g = crc_poly & mask;
       std::vector<uint32_t> m(Z);
@@ -364,17 +369,13 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
           r = ((r << 1) & mask) ^ (((r >> (crc_order - 1)) & 1u) ? g : 0u);
         }
       }
-      if (!h->d_crc_mult) {
-        PHY_HIP_CHECK(hipMalloc(&h->d_crc_mult, 384 * sizeof(uint32_t)), SRSRAN_ERROR);
-      }
-      PHY_HIP_CHECK(hipMemcpyAsync(h->d_crc_mult, m.data(), Z * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t)stream), SRSRAN_ERROR);
-      PHY_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream), SRSRAN_ERROR); // m goes out of scope
-      h->crc_poly  = crc_poly;
-      h->crc_order = crc_order;
+      PHY_HIP_CHECK(hipMalloc(&d_mult, Z * sizeof(uint32_t)), SRSRAN_ERROR);
+      // once per (object, generator); hipMemcpy (not Async) orders itself against the caller's stream work that follows
+      PHY_HIP_CHECK(hipMemcpy(d_mult, m.data(), Z * sizeof(uint32_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
     }
     p.crc_poly   = crc_poly;
     p.crc_order  = crc_order;
-    p.crc_mult   = h->d_crc_mult;
+    p.crc_mult   = d_mult;
     p.n_iter_out = d_n_iter;
   }
   p.flood      = h->flood ? 1 : 0;
@@ -451,6 +452,8 @@ struct LdpcCtx {
   int8_t*                  h_llr  = nullptr; // pinned
   uint8_t*                 h_msg  = nullptr; // pinned
   uint8_t*                 h_iter = nullptr; // pinned
+  int                      dec_type = 0;     // srsran_ldpc_decoder_type_t given at init
+  std::vector<uint8_t>     rec;              // one output record of the shared submission queue (message + iteration count)
 };
 
 uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int len)
@@ -520,6 +523,52 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   }
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
+  if (coalescing_enabled()) {
+    // decodes of the same shape that are in flight on different handles share one batch launch (coalesce.h); a record of the
+    // output staging area is the message followed by the iteration count of the CRC early stop
+    const uint32_t nit_off = (liftK + 3u) & ~3u;
+    const uint32_t poly = crc ? (uint32_t)crc->polynom : 0u, order = crc ? (uint32_t)crc->order : 0u;
+    char           key[160];
+    snprintf(key, sizeof(key), "ldpc:t%d:bg%d:z%u:sf%a:it%u:rm%u:crc%x,%u", c->dec_type, (int)q->bg, (unsigned)q->ls, (double)q->scaling_fctr,
+             q->max_nof_iter, cdwd_rm_length, poly, order);
+    const size_t esz  = c->esz;
+    Coalescer*   co   = coalescer_for(key, [&]() -> Coalescer* {
+      const uint32_t           cap = 32;
+      srsran_hip_ldpc_batch_t* b   = nullptr;
+      int*                     d_nit = nullptr;
+      if (srsran_hip_ldpc_batch_create_typed(&b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, cap, (srsran_ldpc_decoder_type_t)c->dec_type) != SRSRAN_SUCCESS ||
+          hipMalloc(&d_nit, cap * sizeof(int)) != hipSuccess) {
+        return nullptr;
+      }
+      const uint32_t in_stride = (uint32_t)(Coalescer::stride_of(n_llr * esz) / esz), out_stride = (uint32_t)Coalescer::stride_of(nit_off + 4);
+      return new Coalescer(n_llr * esz, nit_off + 4, cap, [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) -> int {
+        if (order) {
+          if (srsran_hip_ldpc_batch_run_crc(b, static_cast<const int8_t*>(d_in), in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, poly,
+                                            order, d_nit, st)) {
+            return SRSRAN_ERROR;
+          }
+          PHY_HIP_CHECK(hipMemcpy2DAsync(static_cast<uint8_t*>(d_out) + nit_off, out_stride, d_nit, sizeof(int), sizeof(int), n, hipMemcpyDeviceToDevice, st),
+                        SRSRAN_ERROR);
+          return SRSRAN_SUCCESS;
+        }
+        return srsran_hip_ldpc_batch_run_typed(b, d_in, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, nullptr, st);
+      });
+    });
+    if (co) {
+      std::vector<uint8_t>& rec = c->rec;
+      rec.resize(nit_off + 4);
+      if (co->submit(llrs, rec.data()) != SRSRAN_SUCCESS) {
+        fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
+        return -1;
+      }
+      memcpy(message, rec.data(), liftK);
+      int nit = (int)q->max_nof_iter;
+      if (crc) {
+        memcpy(&nit, rec.data() + nit_off, sizeof(int));
+      }
+      return nit;
+    }
+  }
   memcpy(c->h_llr, llrs, n_llr * c->esz);
   PHY_HIP_CHECK(hipMemcpyAsync(c->d_llr, c->h_llr, n_llr * c->esz, hipMemcpyHostToDevice, c->stream), -1);
   if (crc) {
@@ -616,6 +665,7 @@ extern "C" int srsran_ldpc_decoder_init(srsran_ldpc_decoder_t* q, const srsran_l
   q->ptr  = c;
   q->free = ldpc_ctx_free;
   c->esz  = esz;
+  c->dec_type = (int)args->type;
   c->n_iter = (flood ? 2u : 1u) * q->max_nof_iter;
   // one decode entry point per object, as init_f / init_s / init_c register them (ldpc_decoder.c:170-260)
   if (esz == 4) {

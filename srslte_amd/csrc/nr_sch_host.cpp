@@ -260,10 +260,20 @@ extern "C" void srsran_hip_nr_sch_free(srsran_hip_nr_sch_t* h)
 static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d_in, void* d_out, const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb,
                     uint32_t F, int bg, uint32_t ls, uint32_t rv, int mod, uint32_t Nref, hipStream_t st, const uint8_t* new_data = nullptr)
 {
-  if (!h || (n_cb && (!cbs || !d_in || !d_out)) || llr_type < 0 || llr_type > 2 || n_cb > 65535) {
+  if (!h || (n_cb && (!cbs || !d_in || !d_out)) || llr_type < 0 || llr_type > 2) {
+    set_error("ldpc rate matching: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
   if (n_cb == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  if (n_cb > 65535) { // one launch addresses its code blocks through grid.y: larger batches go in pieces, in stream order
+    for (uint32_t i = 0; i < n_cb; i += 65535) {
+      const int rc = rm_batch(h, tx, llr_type, d_in, d_out, cbs + i, std::min(65535u, n_cb - i), F, bg, ls, rv, mod, Nref, st, new_data ? new_data + i : nullptr);
+      if (rc != SRSRAN_SUCCESS) {
+        return rc;
+      }
+    }
     return SRSRAN_SUCCESS;
   }
   RmCfg    c;

@@ -153,6 +153,12 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
       fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // sch.c:521-524
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
+    // element / byte offsets travel as 32-bit values (rm::RxJob, turbo::CbDesc): refuse what would wrap instead of writing into other rows
+    if ((uint64_t)(tb.first_cb + cs.C) * SRSRAN_HIP_SOFTBUFFER_CB_SIZE > 0xffffffffull || (uint64_t)tb.e_offset + tb.nof_e_bits > 0xffffffffull ||
+        (uint64_t)tb.data_offset + tb.tbs / 8 + 3 > 0xffffffffull) {
+      set_error("sch decode: transport block %u: input, soft-buffer or data offsets beyond 2^32", t);
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
     for (uint32_t i = 0; i < cs.C; i++) {
       if (cb_crc[tb.first_cb + i]) {
         continue; // decoded in an earlier HARQ round: its bytes stay in d_data (sch.c:466-471)

@@ -210,6 +210,15 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
       set_error("sch_nr: transport block %u does not fit the soft buffer (%u code blocks of %u soft bits)", t, c.C, c.N);
       return SRSRAN_ERROR;
     }
+    // element offsets travel as 32-bit values (job lists, code-word map): refuse what would wrap instead of writing into other rows
+    uint64_t e_total = tbs[t].e_offset;
+    for (uint32_t r = 0; r < c.C; r++) {
+      e_total += get_E(c, r);
+    }
+    if (e_total > 0xffffffffull || (uint64_t)(tbs[t].first_cb + c.C) * sb_stride > 0xffffffffull) {
+      set_error("sch_nr: transport block %u: input or soft-buffer offsets beyond 2^32 elements", t);
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
     uint32_t in = tbs[t].e_offset;
     for (uint32_t r = 0; r < c.C; r++) {
       const uint32_t cb = tbs[t].first_cb + r;

@@ -2,6 +2,7 @@
 //
 // Mirrors (interface + behaviour, not code) lib/src/phy/fec/turbo/turbodecoder.c, tc_interl_lte.c,
 // tc_interl_umts.c:51-90 (init/free) and lib/src/phy/fec/cbsegm.c:119-140 of the reference.
+#include "coalesce.h"
 #include "hip_common.h"
 #include "tables/lte_qpp_table.h"
 #include "turbo_device.h"
@@ -515,6 +516,7 @@ struct TdecCtx {
   int16_t* h_in  = nullptr; // pinned
   uint8_t* h_out = nullptr; // pinned
   size_t   in_cap = 0;
+  bool     dev_state_valid = false; // the handle's own batch object holds the decoder state of the current code block
 };
 
 TdecCtx* ctx_of(srsran_tdec_t* h)
@@ -606,6 +608,9 @@ extern "C" int srsran_tdec_new_cb(srsran_tdec_t* h, uint32_t long_cb)
     fprintf(stderr, "TDEC was initialized for max_long_cb=%d\n", h->max_long_cb);
     return -1;
   }
+  if (TdecCtx* c = ctx_of(h)) {
+    c->dev_state_valid = false;
+  }
   h->n_iter          = 0;
   h->current_long_cb = long_cb;
   h->current_cbidx   = srsran_cbsegm_cbindex(long_cb);
@@ -664,7 +669,9 @@ static void tdec_handle_iterate(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
     }
     it = c->dec.emplace(key, b).first;
   }
-  const uint32_t n_begin = (uint32_t)h->n_iter;
+  // a run that went through the shared submission queue left no decoder state in this handle's private object: a caller that
+  // resumes it with srsran_tdec_iteration gets the earlier half iterations re-run from its input first
+  const uint32_t n_begin = c->dev_state_valid ? (uint32_t)h->n_iter : 0u;
   const size_t   in_len  = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
   if (n_begin == 0) {
     // The reference converts between LLR widths on the host when API and decoder differ (convert_8_to_16 /
@@ -689,7 +696,70 @@ static void tdec_handle_iterate(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
   PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, K / 8, hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   memcpy(output, c->h_out, K / 8);
-  h->n_iter = (int)n_end;
+  h->n_iter          = (int)n_end;
+  c->dev_state_valid = true;
+}
+
+// srsran_tdec_run_all{,_8bit}: a whole run from the input is stateless, so runs of the same shape that are in flight on
+// different handles (one worker thread per subframe, cc_worker.cc:212-231) share one batch launch (coalesce.h)
+template <typename ELEM>
+static bool tdec_run_all_queued(srsran_tdec_t* h, ELEM* input, uint8_t* output, uint32_t nit)
+{
+  constexpr bool in8 = sizeof(ELEM) == 1;
+  TdecCtx*       c   = ctx_of(h);
+  const uint32_t K   = h->current_long_cb;
+  if (!c || !coalescing_enabled() || (uint32_t)srsran_cbsegm_cbsize(h->current_cbidx) != K) {
+    return false;
+  }
+  int  nb     = 0;
+  bool arith8 = false;
+  if (impl_to_cfg(h->dec_type, in8, K, &nb, &arith8) || (nb && (K % nb || K / nb <= 40))) {
+    return false; // the private path reports the error
+  }
+  const bool   auto_mode = h->dec_type == SRSRAN_TDEC_AUTO;
+  const int    sb_layout = (!h->force_not_sb && (arith8 || (auto_mode && nb > 0))) ? 1 : 0;
+  const size_t in_len    = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
+  char         key[96];
+  snprintf(key, sizeof(key), "tdec:K%u:nb%d:a%d:sb%d:e%d:it%u", K, nb, arith8 ? 1 : 0, sb_layout, in8 ? 1 : 0, nit);
+  Coalescer* q = coalescer_for(key, [&]() -> Coalescer* {
+    const uint32_t           cap = 64;
+    srsran_hip_tdec_batch_t* b   = nullptr;
+    const int impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)
+                            : (nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC));
+    if (srsran_hip_tdec_batch_create(&b, K, cap, impl)) {
+      return nullptr;
+    }
+    const uint32_t in_stride  = (uint32_t)(Coalescer::stride_of(in_len * sizeof(ELEM)) / sizeof(ELEM));
+    const uint32_t out_stride = (uint32_t)Coalescer::stride_of(K / 8);
+    return new Coalescer(in_len * sizeof(ELEM), K / 8, cap, [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) {
+      return tdec_batch_run_range(b, d_in, in8, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, 0, nit, sb_layout, false, st);
+    });
+  });
+  if (!q) {
+    return false;
+  }
+  if (auto_mode) {
+    h->current_llr_type = arith8 ? SRSRAN_TDEC_8 : SRSRAN_TDEC_16;
+    h->current_dec      = arith8 ? (nb == 32 ? 1 : 0) : (nb == 16 ? 2 : (nb == 8 ? 1 : 0));
+  } else {
+    h->current_dec = 0;
+  }
+  h->current_inter_idx = nb == 32 ? 3 : (nb == 16 ? 2 : (nb == 8 ? 1 : 0));
+  if (q->submit(input, output) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_tdec_run_all: %s\n", get_error());
+    return false;
+  }
+  if (sb_layout && in8 == arith8) {
+    // the reference writes the tail into the caller's buffer (turbodecoder_iter.h:58-70,92-96)
+    for (uint32_t i = K; i < K + 3; i++) {
+      input[i]                = input[3 * (K + 32) + 2 * (i - K)];
+      input[K + 32 + i]       = input[3 * (K + 32) + 2 * (i - K) + 1];
+      input[2 * (K + 32) + i] = input[3 * (K + 32) + 6 + 2 * (i - K) + 1];
+    }
+  }
+  h->n_iter          = (int)nit;
+  c->dev_state_valid = false;
+  return true;
 }
 
 extern "C" void srsran_tdec_iteration(srsran_tdec_t* h, int16_t* input, uint8_t* output)
@@ -703,6 +773,9 @@ extern "C" int srsran_tdec_run_all(srsran_tdec_t* h, int16_t* input, uint8_t* ou
 {
   if (srsran_tdec_new_cb(h, long_cb)) {
     return SRSRAN_ERROR;
+  }
+  if (tdec_run_all_queued(h, input, output, nof_iterations ? nof_iterations : 1)) {
+    return SRSRAN_SUCCESS;
   }
   tdec_handle_iterate(h, input, output, nof_iterations ? nof_iterations : 1);
   return h->n_iter ? SRSRAN_SUCCESS : SRSRAN_ERROR;
@@ -719,6 +792,9 @@ extern "C" int srsran_tdec_run_all_8bit(srsran_tdec_t* h, int8_t* input, uint8_t
 {
   if (srsran_tdec_new_cb(h, long_cb)) {
     return SRSRAN_ERROR;
+  }
+  if (tdec_run_all_queued(h, input, output, nof_iterations ? nof_iterations : 1)) {
+    return SRSRAN_SUCCESS;
   }
   tdec_handle_iterate(h, input, output, nof_iterations ? nof_iterations : 1);
   return h->n_iter ? SRSRAN_SUCCESS : SRSRAN_ERROR;

@@ -26,6 +26,33 @@ def test_all_lifting_sizes(hiplib, bg):
         assert np.array_equal(ref, out), "BG%d Z=%d: %d words differ" % (bg + 1, Z, np.any(ref != out, axis=1).sum())
 
 
+@pytest.mark.parametrize("sf", [0.8, 0.75])
+@pytest.mark.parametrize("snr", [0.5, 2.0])
+@pytest.mark.parametrize("bg", [0, 1])
+def test_z384_at_20_iterations_noisy(hiplib, bg, snr, sf):
+    """BASELINE configs[2]'s regime: Z = 384 at the full 20 iterations on NOISY words (0.5 dB: most words never converge, every
+    iteration changes messages; 2 dB: they converge on the way), both scaling factors the reference uses (sch_nr.c:275 0.8,
+    ldpc_chain_test.c:76 0.75): messages after every one of the 20 iterations and the final soft bits equal the oracle's"""
+    import srslte_amd as S
+
+    n_cw = 6
+    msgs, llrs = O.ldpc_llrs(bg, 384, n_cw, snr, seed=int(1000 * snr) + bg + int(100 * sf))
+    ref, rets = O.ldpc_decode(bg, 384, llrs, sf, 20)
+    assert rets == [20] * n_cw
+    dec = S.LdpcBatch(bg, 384, sf, 20, n_cw)
+    out = dec.decode(llrs)  # the two-positions-per-lane kernel (what bench.py's extra.ldpc times)
+    assert np.array_equal(ref, out), "BG%d: %d words differ" % (bg + 1, np.any(ref != out, axis=1).sum())
+    out, per_it = dec.decode(llrs, want_iter_msgs=True)  # the one-position-per-lane kernel, with snapshots
+    assert np.array_equal(ref, out)
+    # the per-iteration snapshots: iteration k equals an oracle run limited to k iterations (spot: 1, 7, 13, 20)
+    K = dec.liftK
+    for k in (1, 7, 13, 20):
+        rk, _ = O.ldpc_decode(bg, 384, llrs, sf, k)
+        assert np.array_equal(np.unpackbits(per_it[:, k - 1], axis=1)[:, :K], rk), (bg, snr, sf, k)
+    if snr < 1.0:
+        assert not np.array_equal(ref, msgs)  # the regime the test is for: not everything decodes
+
+
 @pytest.mark.parametrize("bg,Z", [(0, 384), (1, 384), (0, 96), (1, 30)])
 def test_rate_matched_lengths_and_scalings(hiplib, bg, Z):
     """cdwd_rm_length clamps of ldpc_decoder.c:51-65 and several scaling factors"""

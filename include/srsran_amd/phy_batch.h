@@ -30,10 +30,10 @@ SRSRAN_API const char* srsran_hip_last_error(void);
 SRSRAN_API const char* srsran_hip_build_info(void);
 
 /* ---- submission queues under the handle API.  The reference runs one worker thread per in-flight subframe, each with its own
- * handles (srsenb/src/phy/lte/cc_worker.cc:212-231, lib/include/srsran/common/thread_pool.h:48).  Calls of srsran_tdec_run_all{,_8bit},
- * srsran_ofdm_rx_sf / srsran_ofdm_tx_sf and srsran_ldpc_decoder_decode_{c,crc_c} that are in flight at the same time with the same
- * kernel configuration are merged into one batch launch (group commit: no timer, a lone caller runs at once); results are
- * unchanged.  Default on; SRSRAN_HIP_COALESCE=0 in the environment or srsran_hip_set_coalescing(0) gives every handle its
+ * handles (srsenb/src/phy/lte/cc_worker.cc:212-231, lib/include/srsran/common/thread_pool.h:48).  Calls of srsran_tdec_run_all{,_8bit}
+ * and srsran_ldpc_decoder_decode_{c,s,f,crc_c} that are in flight at the same time with the same kernel configuration are merged into
+ * batch launches once more callers are in flight than the queue has lanes (group commit: no timer, a lone caller runs at once);
+ * results are unchanged.  OFDM subframes always run on the handle's private stream (measured faster: profiles/r02_bench_handle.json).  Default on; SRSRAN_HIP_COALESCE=0 in the environment or srsran_hip_set_coalescing(0) gives every handle its
  * private stream again.  srsran_hip_coalesce_stats: batches launched and calls carried so far (either pointer may be NULL). */
 SRSRAN_API void srsran_hip_set_coalescing(int enable);
 SRSRAN_API void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_units);

@@ -2,14 +2,17 @@
 //
 // The reference's threading contract is one worker thread per in-flight subframe, each with its OWN handles
 // (srsenb/src/phy/lte/cc_worker.cc:212-231, lib/include/srsran/common/thread_pool.h:48): N threads call
-// srsran_tdec_run_all / srsran_ofdm_rx_sf / srsran_ldpc_decoder_decode_c at the same time on N different handles.  One call is
+// srsran_tdec_run_all / srsran_ldpc_decoder_decode_c at the same time on N different handles.  One call is
 // one code block or one subframe -- far too little to fill 256 CUs -- so calls of the same SHAPE (same kernel configuration)
 // that are in flight together are merged into one batch launch, group-commit style:
-//   * a caller queues its request; if nobody is running a batch for this shape it becomes the leader, takes everything that is
-//     queued (its own request included), stages the inputs in pinned memory, does ONE upload, ONE launch, ONE download and
-//     wakes the others;
-//   * callers that arrive while a batch is on the device simply wait in the queue and form the next batch.
-// Nobody ever waits for a timer: a lone caller runs at once (batch of one), and the busier the process the larger the batches.
+//   * a caller queues its request; if one of the queue's few LANES (stream + staging buffers + batch engine) is free it becomes
+//     the leader of the next batch on that lane, takes everything that is queued (its own request included), stages the inputs
+//     in pinned memory, does ONE upload, ONE launch, ONE download and wakes the others;
+//   * callers that arrive while every lane is on the device wait in the queue and form the next batch.
+// Nobody ever waits for a timer: with few callers every call runs at once on its own lane (the decoder kernels are latency
+// bound -- one wave per code word -- so a handful of small launches overlap perfectly); the busier the process, the larger the
+// batches, and the driver sees at most that many submitting threads per shape however many workers there are.
+// Lanes per shape: 4 for the turbo decoder, 1 for LDPC (measured, profiles/r02_bench_handle.json).
 // Results are the batched kernels' results, which the parity tests pin to the oracle per unit, so a call gives the same bytes
 // whether it was merged or not.  SRSRAN_HIP_COALESCE=0 turns merging off (every handle then uses its private stream).
 #pragma once
@@ -30,41 +33,54 @@ class Coalescer {
 public:
   // runs n units: unit i reads d_in + i * in_stride and writes d_out + i * out_stride (bytes); asynchronous on `st`
   using RunFn = std::function<int(const void* d_in, void* d_out, uint32_t n, hipStream_t st)>;
+  // builds the run function of lane `l` (every lane owns its engine: batches of different lanes are on the device together)
+  using MakeFn = std::function<RunFn(int lane)>;
+  static constexpr int kMaxLanes = 4;
 
-  Coalescer(size_t in_bytes, size_t out_bytes, uint32_t max_batch, RunFn run) :
-    in_bytes_(in_bytes), out_bytes_(out_bytes), in_stride_(stride_of(in_bytes)), out_stride_(stride_of(out_bytes)),
-    max_batch_(max_batch), run_(std::move(run))
+  // n_lanes: batches of this shape that may be on the device together (1 ... kMaxLanes)
+  Coalescer(size_t in_bytes, size_t out_bytes, uint32_t max_batch, int n_lanes, const MakeFn& make) :
+    in_bytes_(in_bytes), out_bytes_(out_bytes), in_stride_(stride_of(in_bytes)), out_stride_(stride_of(out_bytes)), max_batch_(max_batch)
   {
-    ok_ = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d_in_, in_stride_ * max_batch) == hipSuccess &&
-          hipMalloc(&d_out_, out_stride_ * max_batch) == hipSuccess && hipHostMalloc(&h_in_, in_stride_ * max_batch) == hipSuccess &&
-          hipHostMalloc(&h_out_, out_stride_ * max_batch) == hipSuccess;
+    ok_ = true;
+    n_lanes = n_lanes < 1 ? 1 : (n_lanes > kMaxLanes ? kMaxLanes : n_lanes);
+    for (int l = 0; l < n_lanes && ok_; l++) {
+      Lane& ln = lanes_[l];
+      ok_      = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&ln.d_in, in_stride_ * max_batch) == hipSuccess &&
+            hipMalloc(&ln.d_out, out_stride_ * max_batch) == hipSuccess && hipHostMalloc(&ln.h_in, in_stride_ * max_batch) == hipSuccess &&
+            hipHostMalloc(&ln.h_out, out_stride_ * max_batch) == hipSuccess;
+      if (ok_) {
+        ln.run = make(l);
+        ok_    = (bool)ln.run;
+      }
+      free_.push_back(l);
+    }
   }
   // distance between the units of a batch in the staging buffers: the unit size rounded up to 64 bytes
   static size_t stride_of(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
-  bool     ok() const { return ok_; }
-  size_t   in_stride() const { return in_stride_; }
-  size_t   out_stride() const { return out_stride_; }
-  uint32_t max_batch() const { return max_batch_; }
+  bool          ok() const { return ok_; }
 
   // blocking: `in` (in_bytes) -> `out` (out_bytes), host memory of the caller.  Returns the run function's code.
   int submit(const void* in, void* out)
   {
-    Req                          r{in, out, 0, false};
+    Req                          r{in, out, 0, false, false};
     std::unique_lock<std::mutex> lk(mu_);
     queue_.push_back(&r);
     while (!r.done) {
-      if (busy_) {
-        cv_.wait(lk);
+      if (r.taken || free_.empty()) {
+        cv_.wait(lk); // somebody else carries this request, or every lane is on the device: the queue grows meanwhile
         continue;
       }
-      busy_ = true; // leader of the next batch: the oldest requests first (its own is among them unless the queue is very long)
+      // leader of the next batch on a free lane: the oldest requests first (this one is among them)
+      const int l = free_.back();
+      free_.pop_back();
       std::vector<Req*> batch;
       while (!queue_.empty() && batch.size() < max_batch_) {
+        queue_.front()->taken = true;
         batch.push_back(queue_.front());
         queue_.pop_front();
       }
       lk.unlock();
-      const int rc = process(batch);
+      const int rc = process(lanes_[l], batch);
       lk.lock();
       for (Req* b : batch) {
         b->rc   = rc;
@@ -72,7 +88,7 @@ public:
       }
       n_batches_++;
       n_units_ += batch.size();
-      busy_ = false;
+      free_.push_back(l);
       cv_.notify_all();
     }
     return r.rc;
@@ -91,37 +107,41 @@ private:
     void*       out;
     int         rc;
     bool        done;
+    bool        taken;
   };
-  int process(const std::vector<Req*>& batch)
+  struct Lane {
+    hipStream_t st = nullptr;
+    void *      d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    RunFn       run;
+  };
+  int process(Lane& ln, const std::vector<Req*>& batch)
   {
     const uint32_t n = (uint32_t)batch.size();
     for (uint32_t i = 0; i < n; i++) {
-      memcpy(static_cast<uint8_t*>(h_in_) + i * in_stride_, batch[i]->in, in_bytes_);
+      memcpy(static_cast<uint8_t*>(ln.h_in) + i * in_stride_, batch[i]->in, in_bytes_);
     }
-    PHY_HIP_CHECK(hipMemcpyAsync(d_in_, h_in_, in_stride_ * (n - 1) + in_bytes_, hipMemcpyHostToDevice, st_), SRSRAN_ERROR);
-    const int rc = run_(d_in_, d_out_, n, st_);
+    PHY_HIP_CHECK(hipMemcpyAsync(ln.d_in, ln.h_in, in_stride_ * (n - 1) + in_bytes_, hipMemcpyHostToDevice, ln.st), SRSRAN_ERROR);
+    const int rc = ln.run(ln.d_in, ln.d_out, n, ln.st);
     if (rc != SRSRAN_SUCCESS) {
-      (void)hipStreamSynchronize(st_);
+      (void)hipStreamSynchronize(ln.st);
       return rc;
     }
-    PHY_HIP_CHECK(hipMemcpyAsync(h_out_, d_out_, out_stride_ * (n - 1) + out_bytes_, hipMemcpyDeviceToHost, st_), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipStreamSynchronize(st_), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemcpyAsync(ln.h_out, ln.d_out, out_stride_ * (n - 1) + out_bytes_, hipMemcpyDeviceToHost, ln.st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipStreamSynchronize(ln.st), SRSRAN_ERROR);
     for (uint32_t i = 0; i < n; i++) {
-      memcpy(batch[i]->out, static_cast<uint8_t*>(h_out_) + i * out_stride_, out_bytes_);
+      memcpy(batch[i]->out, static_cast<uint8_t*>(ln.h_out) + i * out_stride_, out_bytes_);
     }
     return SRSRAN_SUCCESS;
   }
 
   const size_t            in_bytes_, out_bytes_, in_stride_, out_stride_;
   const uint32_t          max_batch_;
-  RunFn                   run_;
-  hipStream_t             st_    = nullptr;
-  void *                  d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
-  bool                    ok_   = false;
+  Lane                    lanes_[kMaxLanes];
+  std::vector<int>        free_;
+  bool                    ok_ = false;
   std::mutex              mu_;
   std::condition_variable cv_;
   std::deque<Req*>        queue_;
-  bool                    busy_      = false;
   uint64_t                n_batches_ = 0, n_units_ = 0;
 };
 

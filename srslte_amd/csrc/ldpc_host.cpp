@@ -533,25 +533,31 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
              q->max_nof_iter, cdwd_rm_length, poly, order);
     const size_t esz  = c->esz;
     Coalescer*   co   = coalescer_for(key, [&]() -> Coalescer* {
-      const uint32_t           cap = 32;
-      srsran_hip_ldpc_batch_t* b   = nullptr;
-      int*                     d_nit = nullptr;
-      if (srsran_hip_ldpc_batch_create_typed(&b, q->bg, q->ls, q->scaling_fctr, q->max_nof_iter, cap, (srsran_ldpc_decoder_type_t)c->dec_type) != SRSRAN_SUCCESS ||
-          hipMalloc(&d_nit, cap * sizeof(int)) != hipSuccess) {
-        return nullptr;
-      }
+      const uint32_t                   cap = 32;
+      const srsran_basegraph_t         bgq = q->bg;
+      const uint16_t                   lsq = q->ls;
+      const float                      sfq = q->scaling_fctr;
+      const uint32_t                   itq = q->max_nof_iter;
+      const srsran_ldpc_decoder_type_t tyq = (srsran_ldpc_decoder_type_t)c->dec_type;
       const uint32_t in_stride = (uint32_t)(Coalescer::stride_of(n_llr * esz) / esz), out_stride = (uint32_t)Coalescer::stride_of(nit_off + 4);
-      return new Coalescer(n_llr * esz, nit_off + 4, cap, [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) -> int {
-        if (order) {
-          if (srsran_hip_ldpc_batch_run_crc(b, static_cast<const int8_t*>(d_in), in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, poly,
-                                            order, d_nit, st)) {
-            return SRSRAN_ERROR;
-          }
-          PHY_HIP_CHECK(hipMemcpy2DAsync(static_cast<uint8_t*>(d_out) + nit_off, out_stride, d_nit, sizeof(int), sizeof(int), n, hipMemcpyDeviceToDevice, st),
-                        SRSRAN_ERROR);
-          return SRSRAN_SUCCESS;
+      return new Coalescer(n_llr * esz, nit_off + 4, cap, 1, [=](int) -> Coalescer::RunFn {
+        srsran_hip_ldpc_batch_t* b     = nullptr;
+        int*                     d_nit = nullptr;
+        if (srsran_hip_ldpc_batch_create_typed(&b, bgq, lsq, sfq, itq, cap, tyq) != SRSRAN_SUCCESS || hipMalloc(&d_nit, cap * sizeof(int)) != hipSuccess) {
+          return Coalescer::RunFn();
         }
-        return srsran_hip_ldpc_batch_run_typed(b, d_in, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, nullptr, st);
+        return [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) -> int {
+          if (order) {
+            if (srsran_hip_ldpc_batch_run_crc(b, static_cast<const int8_t*>(d_in), in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length,
+                                              poly, order, d_nit, st)) {
+              return SRSRAN_ERROR;
+            }
+            PHY_HIP_CHECK(hipMemcpy2DAsync(static_cast<uint8_t*>(d_out) + nit_off, out_stride, d_nit, sizeof(int), sizeof(int), n, hipMemcpyDeviceToDevice, st),
+                          SRSRAN_ERROR);
+            return SRSRAN_SUCCESS;
+          }
+          return srsran_hip_ldpc_batch_run_typed(b, d_in, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, nullptr, st);
+        };
       });
     });
     if (co) {

@@ -2,7 +2,6 @@
 //
 // Mirrors (interface + behaviour) lib/src/phy/dft/ofdm.c and the sizing helpers of
 // lib/src/phy/common/phy_common.c:322-385 / lib/include/srsran/phy/common/phy_common.h:110-140.
-#include "coalesce.h"
 #include "hip_common.h"
 #include "ofdm_device.h"
 
@@ -561,47 +560,9 @@ void ofdm_free_(srsran_ofdm_t* q)
   memset(q, 0, sizeof(srsran_ofdm_t)); // ofdm.c:240
 }
 
-// The shared submission queue of a subframe shape (coalesce.h): subframes of the same geometry that are in flight on different
-// handles (one worker thread per subframe, cc_worker.cc:212-231) go out as one batch launch.  MBSFN subframes (per-call region)
-// and the receive side with a frequency shift (it writes the shifted samples back into the caller's input) keep the private path.
-Coalescer* ofdm_queue(srsran_ofdm_t* q, bool tx, bool with_ramp)
-{
-  OfdmCtx* c = ctx_of(q);
-  if (!coalescing_enabled() || !c || !c->b) {
-    return nullptr;
-  }
-  const Geometry g = c->b->g;
-  if (g.mbsfn || (!tx && g.shift_on)) {
-    return nullptr;
-  }
-  const size_t nt = (size_t)g.sf_sz * sizeof(cf_t), nr = (size_t)g.nof_re * 2 * g.nsym_slot * sizeof(cf_t);
-  if (Coalescer::stride_of(nt) != nt || Coalescer::stride_of(nr) != nr) {
-    return nullptr; // the batch kernels want the subframes back to back
-  }
-  char key[160];
-  snprintf(key, sizeof(key), "ofdm:%s:N%d:s%d:cp%d,%d:re%d:dc%d:w%d:n%d:sh%d,%a:r%d", tx ? "tx" : "rx", g.N, g.nsym_slot, g.cp0, g.cp1, g.nof_re,
-           g.dc, g.win_n, g.norm ? 1 : 0, g.shift_on ? 1 : 0, (double)(g.shift_on ? g.freq_shift : 0.f), with_ramp ? 1 : 0);
-  const cf_t *shift_tab = q->shift_buffer, *ramp_tab = q->window_offset_buffer;
-  return coalescer_for(key, [&]() -> Coalescer* {
-    srsran_hip_ofdm_batch_t* b = nullptr;
-    if (batch_build(&b, g, tx, shift_tab, ramp_tab)) {
-      return nullptr;
-    }
-    return new Coalescer(tx ? nr : nt, tx ? nt : nr, 32, [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) {
-      return batch_run(b, d_in, d_out, n, tx, tx, st, with_ramp);
-    });
-  });
-}
-
 void rx_run(srsran_ofdm_t* q, cf_t* input, cf_t* output, bool with_ramp)
 {
   if (ctx_sync(q)) {
-    return;
-  }
-  if (Coalescer* co = ofdm_queue(q, false, with_ramp)) {
-    if (co->submit(input, output) != SRSRAN_SUCCESS) {
-      fprintf(stderr, "[srsran_phy_hip] srsran_ofdm_rx_sf: %s\n", get_error());
-    }
     return;
   }
   OfdmCtx*       c  = ctx_of(q);
@@ -772,12 +733,6 @@ extern "C" void srsran_ofdm_rx_sf_ng(srsran_ofdm_t* q, cf_t* input, cf_t* output
 extern "C" void srsran_ofdm_tx_sf(srsran_ofdm_t* q)
 {
   if (ctx_sync(q)) {
-    return;
-  }
-  if (Coalescer* co = ofdm_queue(q, true, true)) {
-    if (co->submit(q->cfg.in_buffer, q->cfg.out_buffer) != SRSRAN_SUCCESS) {
-      fprintf(stderr, "[srsran_phy_hip] srsran_ofdm_tx_sf: %s\n", get_error());
-    }
     return;
   }
   OfdmCtx*     c  = ctx_of(q);

@@ -722,17 +722,19 @@ static bool tdec_run_all_queued(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
   char         key[96];
   snprintf(key, sizeof(key), "tdec:K%u:nb%d:a%d:sb%d:e%d:it%u", K, nb, arith8 ? 1 : 0, sb_layout, in8 ? 1 : 0, nit);
   Coalescer* q = coalescer_for(key, [&]() -> Coalescer* {
-    const uint32_t           cap = 64;
-    srsran_hip_tdec_batch_t* b   = nullptr;
-    const int impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)
-                            : (nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC));
-    if (srsran_hip_tdec_batch_create(&b, K, cap, impl)) {
-      return nullptr;
-    }
+    const uint32_t cap  = 64;
+    const int      impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)
+                                 : (nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC));
     const uint32_t in_stride  = (uint32_t)(Coalescer::stride_of(in_len * sizeof(ELEM)) / sizeof(ELEM));
     const uint32_t out_stride = (uint32_t)Coalescer::stride_of(K / 8);
-    return new Coalescer(in_len * sizeof(ELEM), K / 8, cap, [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) {
-      return tdec_batch_run_range(b, d_in, in8, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, 0, nit, sb_layout, false, st);
+    return new Coalescer(in_len * sizeof(ELEM), K / 8, cap, 4, [=](int) -> Coalescer::RunFn {
+      srsran_hip_tdec_batch_t* b = nullptr;
+      if (srsran_hip_tdec_batch_create(&b, K, cap, impl)) {
+        return Coalescer::RunFn();
+      }
+      return [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) {
+        return tdec_batch_run_range(b, d_in, in8, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, 0, nit, sb_layout, false, st);
+      };
     });
   });
   if (!q) {

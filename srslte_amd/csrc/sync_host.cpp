@@ -136,7 +136,7 @@ void pss_time_replica(uint32_t N_id_2, uint32_t N, int cfo_i, cf_t* freq62, std:
 
 struct PssEngine {
   uint32_t frame_size = 0, fft_size = 0, max_caps = 0;
-  int      n_blocks = 0, hop = 0, n_out = 0;
+  int      n_blocks = 0, hop = 0, n_out = 0, block_n = 4096;
   size_t   corr_stride = 0;
   float2*  d_tw = nullptr;
   float2*  d_filt = nullptr;
@@ -179,35 +179,65 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
   e->fft_size    = fft_size;
   e->max_caps    = max_caps;
   e->direct      = frame_size < fft_size; // pss.c:476-481: sliding dot product, conv_output_len = frame_size
-  e->hop         = 4096 - (int)fft_size;
   e->n_out       = e->direct ? (int)frame_size - 1 : (int)(frame_size + fft_size) - 2; // pss.c:493: conv_output_len - 1 entries
+  // overlap-save block of 4096 points.  Measured dead ends for long captures (a 2048-tap replica keeps only 2049 of 4096 outputs):
+  // 8192-point blocks (6145 kept; spectrum + exchange image = 135 KB of LDS, one 512-lane workgroup per CU) run the 256-capture
+  // bench in 1.92 ms against 1.97 ms -- the kernel is bound by barrier / LDS latency at the 2 waves per SIMD the LDS footprint
+  // allows, not by FLOPs; 16384-point blocks need the spectrum in registers and spill (109 VGPRs at 1024 lanes, 232 at 512).
+  e->block_n     = 4096;
+  const int BN   = e->block_n;
+  e->hop         = BN - (int)fft_size;
   e->n_blocks    = e->direct ? (e->n_out + 255) / 256 : (e->n_out + e->hop - 1) / e->hop;
   e->corr_stride = ((size_t)frame_size + fft_size + 2 + 3) & ~(size_t)3;
-  std::vector<std::complex<float>> tw(4096), filt(3 * 4096);
-  for (int i = 0; i < 4096; i++) {
-    double a = -2.0 * M_PI * (double)i / 4096.0;
+  std::vector<std::complex<float>> tw(BN), filt(3 * (size_t)BN);
+  for (int i = 0; i < BN; i++) {
+    double a = -2.0 * M_PI * (double)i / (double)BN;
     tw[i]    = std::complex<float>((float)cos(a), (float)sin(a));
   }
   for (uint32_t h = 0; h < 3; h++) {
     pss_time_replica(h, fft_size, cfo_i, e->freq[h], e->time[h]);
-    for (int k = 0; k < 4096 && !e->direct; k++) {
-      cd acc(0, 0);
-      for (uint32_t n = 0; n < fft_size; n++) {
-        double a = -2.0 * M_PI * (double)(((uint64_t)k * n) & 4095) / 4096.0;
-        acc += cd(e->time[h][n].real(), e->time[h][n].imag()) * cd(cos(a), sin(a));
+    if (e->direct) {
+      continue;
+    }
+    // DFT_BN of the zero-padded replica, scaled by 1 / BN (double-precision radix-2 transform on the host)
+    std::vector<cd> a(BN, cd(0, 0));
+    for (uint32_t n = 0; n < fft_size; n++) {
+      a[n] = cd(e->time[h][n].real(), e->time[h][n].imag());
+    }
+    for (int i = 1, j = 0; i < BN; i++) { // bit reversal
+      int bit = BN >> 1;
+      for (; j & bit; bit >>= 1) {
+        j ^= bit;
       }
-      acc /= 4096.0;
-      filt[h * 4096 + k] = std::complex<float>((float)acc.real(), (float)acc.imag());
+      j ^= bit;
+      if (i < j) {
+        std::swap(a[i], a[j]);
+      }
+    }
+    for (int len = 2; len <= BN; len <<= 1) {
+      for (int i = 0; i < BN; i += len) {
+        for (int k = 0; k < len / 2; k++) {
+          const double ang = -2.0 * M_PI * (double)k / (double)len;
+          const cd     w(cos(ang), sin(ang));
+          const cd     u = a[i + k], v = a[i + k + len / 2] * w;
+          a[i + k]           = u + v;
+          a[i + k + len / 2] = u - v;
+        }
+      }
+    }
+    for (int k = 0; k < BN; k++) {
+      const cd v = a[k] / (double)BN;
+      filt[(size_t)h * BN + k] = std::complex<float>((float)v.real(), (float)v.imag());
     }
   }
-  bool ok = hipMalloc(&e->d_tw, 4096 * sizeof(float2)) == hipSuccess &&
-            hipMalloc(&e->d_filt, 3 * 4096 * sizeof(float2)) == hipSuccess &&
+  bool ok = hipMalloc(&e->d_tw, (size_t)BN * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&e->d_filt, 3 * (size_t)BN * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_corr, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_val, (size_t)max_caps * 3 * e->n_blocks * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_idx, (size_t)max_caps * 3 * e->n_blocks * sizeof(int)) == hipSuccess &&
             hipMalloc(&e->d_res, (size_t)max_caps * 3 * sizeof(sync::PssResult)) == hipSuccess &&
-            hipMemcpy(e->d_tw, tw.data(), 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(e->d_filt, filt.data(), 3 * 4096 * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(e->d_tw, tw.data(), (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(e->d_filt, filt.data(), 3 * (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemset(e->d_corr, 0, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess;
   if (ok && e->direct) {
     ok = hipMalloc(&e->d_rep, 3 * (size_t)fft_size * sizeof(float2)) == hipSuccess;
@@ -230,7 +260,7 @@ int pss_engine_run(PssEngine* e, const void* d_in, uint32_t n_cap, int mask, int
   sync::PssParams p;
   p.in          = d_in;
   p.twiddle     = e->d_tw;
-  p.filt        = e->d_filt + (size_t)first_filter * 4096;
+  p.filt        = e->d_filt + (size_t)first_filter * e->block_n;
   p.corr        = e->d_corr;
   p.part_val    = e->d_part_val;
   p.part_idx    = e->d_part_idx;

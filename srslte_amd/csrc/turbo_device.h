@@ -37,6 +37,11 @@ struct WinParams {
   const uint32_t* crc_mult; // nb multipliers x^(W (nb-1-d)) mod g
   int*            noi;      // out: half iterations run per code block
   uint8_t*        crc_ok;   // out: 1 = CRC matched
+  // measured launch-shape alternatives (SRSRAN_HIP_TDEC_VARIANT, never the default): 0 product, 1 one wave per SIMD, 2 persistent grid
+  int             variant;
+  uint32_t        n_units;      // persistent grid: units of 64 / (nb / 2) code blocks,
+  uint32_t        max_resident; //   workgroups launched at most,
+  uint32_t*       unit_counter; //   device counter, zero at launch
 };
 
 struct GenParams {

@@ -347,6 +347,24 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     if (getenv("TDEC_DBG_EXTRACT_ONLY")) {
       p.n_end = 0; // development aid: input extraction + decision only
     }
+    // launch-shape alternatives kept for measurement (profiles/r02_turbo_variants.txt); the product path is variant 0
+    static const int variant = [] {
+      const char* e = getenv("SRSRAN_HIP_TDEC_VARIANT");
+      return !e ? 0 : (!strcmp(e, "waves1") ? 1 : (!strcmp(e, "persistent") ? 2 : 0));
+    }();
+    if (variant == 2 && n_begin == 0 && h->nb == 16 && !h->arith8) {
+      static uint32_t* d_counter = nullptr;
+      static int       cus       = 0;
+      if (!d_counter) {
+        PHY_HIP_CHECK(hipMalloc(&d_counter, sizeof(uint32_t)), SRSRAN_ERROR);
+        PHY_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0), SRSRAN_ERROR);
+      }
+      PHY_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), stream), SRSRAN_ERROR);
+      p.n_units      = ceil_div(n_cb, 8);
+      p.max_resident = (uint32_t)cus * 8u; // 4 SIMDs x 2 waves
+      p.unit_counter = d_counter;
+    }
+    p.variant = variant;
     PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   } else {
     turbo::GenParams p = {};

@@ -560,21 +560,21 @@ __device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, 
   }
 }
 
+// One unit of work: the CPW = 64 / LPC code blocks wb * CPW ... of the batch, decoded by one wave in the workspace slab `slab`.
+// Bl: re-derived backward metrics of the current 8-step block (8 steps x 8 states x int16x2 per lane); Tr: staging image of 8
+// exchanged rows (rows_to_lane).
 // ES: early-stop / descriptor mode (transport-block decoding, sch_host.cpp).  A separate instantiation: the CRC state and
 // the per-block descriptors must not cost the fixed-iteration kernel registers (it runs at 2 waves per SIMD).
 template <int LPC, class AR, bool ES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdec_win_kernel(const WinParams p)
+__device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t wb, const uint32_t slab, const int lane, uint4 (&Bl)[8][2][64],
+                                              uint32_t (&Tr)[512])
 {
   const uint32_t crc_poly = ES ? p.crc_poly : 0u;
   const CbDesc*  desc     = ES ? p.desc : nullptr;
   constexpr int NB  = 2 * LPC;
   constexpr int CPW = 64 / LPC;
-  // re-derived backward metrics of the current 8-step block: 8 steps x 8 states x int16x2 per lane
-  __shared__ uint4 Bl[8][2][64];
-  __shared__ uint32_t Tr[512]; // staging image of 8 exchanged rows (rows_to_lane)
-  const int     lane = threadIdx.x;
   const int     pl   = lane % LPC;
-  const int     cb_raw = blockIdx.x * CPW + lane / LPC;
+  const int     cb_raw = (int)wb * CPW + lane / LPC;
   // Lane groups past the end of the batch stay in the wave: the exchanged rows are loaded 16 bytes per lane and
   // re-distributed through LDS (issue_rows / rows_to_lane), which needs all 64 lanes.  They decode a copy of the last
   // code block into their own (allocated) workspace slots and write no output.
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // granularity: every wave-level load/store touches one contiguous 256 B (dword) or 1 KB (dwordx4) run,
   // and the per-step row exchange of all the wave's code blocks is a single contiguous 256 B store.
   const uint32_t AWG = AW * CPW; // dwords per array per wave
-  uint32_t* ws  = p.ws + (size_t)blockIdx.x * p.ws_stride * CPW;
+  uint32_t* ws  = p.ws + (size_t)slab * p.ws_stride * CPW;
   uint32_t* S   = ws;
   uint32_t* P0  = ws + AWG;
   uint32_t* P1  = ws + 2 * AWG;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // 3 K + 12 values, and the decoder never looks at steps >= long_sb
     const bool fast = !desc && !p.in_is8 && !p.sb_layout && (long_sb & 3u) == 0 && ((reinterpret_cast<uintptr_t>(p.input) | (2u * p.in_stride)) & 7u) == 0;
     if (fast) {
-      const int first = blockIdx.x * CPW;
+      const int first = (int)wb * CPW;
       extract_input_natural16<LPC, AR>(p.input + (size_t)first * p.in_stride, p.in_stride, p.n_cb - first, K, long_sb, nblk, lane,
                                        S, P0, P1, TL - 16 * (lane / LPC), reinterpret_cast<uint2*>(&Bl[0][0][0]));
     } else if (!p.in_is8 && p.sb_layout &&
@@ -1087,6 +1087,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+// The product kernel: one workgroup (= one wave) per unit, two waves per SIMD.
+template <int LPC, class AR, bool ES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdec_win_kernel(const WinParams p)
+{
+  __shared__ uint4    Bl[8][2][64];
+  __shared__ uint32_t Tr[512];
+  tdec_win_unit<LPC, AR, ES>(p, blockIdx.x, blockIdx.x, threadIdx.x, Bl, Tr);
+}
+
+// ---- measured alternatives of the launch shape (profiles/r02_turbo_variants.txt, DESIGN.md par. 3.2); selected with
+// SRSRAN_HIP_TDEC_VARIANT for the 16-sub-block int16 decoder without early stop only, never by default.
+// "waves1": one wave per SIMD (half the code blocks in flight, up to 512 VGPRs per lane).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void tdec_win_kernel_waves1(const WinParams p)
+{
+  __shared__ uint4    Bl[8][2][64];
+  __shared__ uint32_t Tr[512];
+  tdec_win_unit<8, Ar16, false>(p, blockIdx.x, blockIdx.x, threadIdx.x, Bl, Tr);
+}
+// "persistent": the grid holds only as many workgroups as the chip keeps resident (p.max_resident), every workgroup owns ONE slab and
+// takes units from a counter until the batch is used up, so the workspace could be sized by the residency (1.2 GB) instead of the
+// batch (5.6 GB for 65,520 blocks).  The parameter block and the lane index go through an opaque asm so that what derives from
+// them is not hoisted in front of the loop (without that: 333 spilled VGPRs; with it 47, all in the input extraction).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void tdec_win_kernel_persistent(const WinParams p)
+{
+  __shared__ uint4    Bl[8][2][64];
+  __shared__ uint32_t Tr[512];
+  uint32_t wb = blockIdx.x;
+  while (wb < p.n_units) {
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const WinParams& q = *(const WinParams*)ka;
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    tdec_win_unit<8, Ar16, false>(q, wb, blockIdx.x, lane, Bl, Tr);
+    __syncthreads();
+    uint32_t nx = 0;
+    if (threadIdx.x == 0) {
+      nx = gridDim.x + atomicAdd(q.unit_counter, 1u);
+    }
+    wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Scalar decoder (turbodecoder_gen.c): one lane per code block, wrapping int16, beta kept in HBM.
 // Used for K <= 400 (AUTO) or SRSRAN_TDEC_GENERIC.  Vectors are stored lane-interleaved
@@ -1315,7 +1358,11 @@ static hipError_t launch_win_es(int nb, bool arith8, const WinParams& p, hipStre
 {
   const int lpc = nb / 2;
   dim3      grid(ceil_div(p.n_cb, 64 / lpc));
-  if (!arith8 && nb == 16) {
+  if (!ES && !arith8 && nb == 16 && p.variant == 1) {
+    hipLaunchKernelGGL(tdec_win_kernel_waves1, grid, dim3(64), 0, stream, p);
+  } else if (!ES && !arith8 && nb == 16 && p.variant == 2 && p.unit_counter) {
+    hipLaunchKernelGGL(tdec_win_kernel_persistent, dim3(p.n_units < p.max_resident ? p.n_units : p.max_resident), dim3(64), 0, stream, p);
+  } else if (!arith8 && nb == 16) {
     hipLaunchKernelGGL((tdec_win_kernel<8, Ar16, ES>), grid, dim3(64), 0, stream, p);
   } else if (!arith8 && nb == 8) {
     hipLaunchKernelGGL((tdec_win_kernel<4, Ar16, ES>), grid, dim3(64), 0, stream, p);

@@ -4,8 +4,9 @@
     leg_cellsearch  configs[4]  PSS (3 N_id_2 hypotheses) + SSS over 10 ms captures at 30.72 Msps -> 504 PCI hypotheses
     leg_uplink      configs[3]  per-GPU shard of the multi-UE PUSCH receive chain (time samples -> transport blocks)
 
-Every leg: inputs made on the device by the library's own transmit side where one exists, resident in HBM before the timed
-region; barrier + synchronize on both sides of `steps` timed steps, max over ranks; kernel time by HIP events on the launch
+Every leg: inputs made by the library's own transmit side (encoders, rate matchers, OFDM modulator, PSS / SSS generators, scrambling
+sequences; the 64-QAM mapper is the one thing synthesised here -- the product has no modulator), resident in HBM before the timed
+region; the oracle is only touched inside the `cpu_baseline` blocks; barrier + synchronize on both sides of `steps` timed steps, max over ranks; kernel time by HIP events on the launch
 stream; a `roofline` against the algorithmic bytes of SURVEY.md par. 8(d) and -- on rank 0 of a 1-GPU run -- a `cpu_baseline`
 on ONE host core over a bounded sample, which is also the leg's parity check.  The CPU side uses the reference's own compiled
 decoder (oracle/_ref) when present, else the C / scipy restatement ("port")."""
@@ -43,6 +44,25 @@ def traffic_of(tj, kernel, units, units_key):
         return k["traffic_bytes_per_launch"] * units / float(k[units_key]), tj.get("source")
     except Exception:
         return None, None
+
+
+def _P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _scrambling_bits(lib, seed, n):
+    """c(n) of the Gold sequence of `seed` (36.211 7.2) from the library's own descrambler: srsran_sequence_apply_c flips the sign where c = 1"""
+    ones, out = np.ones(n, np.int8), np.zeros(n, np.int8)
+    lib.srsran_sequence_apply_c(_P(ones), _P(out), n, seed)
+    return (out < 0).astype(np.uint8)
+
+
+def _qam64(bits):
+    """36.211 Table 7.1.4-1 (bench input synthesis only: the product has no modulator, it is outside the hot path)"""
+    b = 1.0 - 2.0 * np.asarray(bits, np.float64).reshape(-1, 6)
+    i = b[:, 0] * (4.0 - b[:, 2] * (2.0 - b[:, 4]))
+    q = b[:, 1] * (4.0 - b[:, 3] * (2.0 - b[:, 5]))
+    return ((i + 1j * q) / np.sqrt(42.0)).astype(np.complex64)
 
 
 def _timed(ctx, torch, step, steps, warmup):
@@ -194,7 +214,6 @@ def leg_ldpc(ctx, steps=3, warmup=1, want_cpu=True, cw=16384, slots=2048, iters=
 def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
     import torch
 
-    import oracle_api as O
     import srslte_amd as S
     from srslte_amd import capi
 
@@ -206,8 +225,11 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
     grids = np.zeros((len(cells), 14, 1200), np.complex64)
     k0 = 600 - 31
     for i, (cid, _) in enumerate(cells):
-        grids[i, 6, k0:k0 + 62] = O.pss_zc(cid % 3)      # last symbol of slot 0 (sync_test.c:130-150)
-        grids[i, 5, k0:k0 + 62] = O.sss_seq(cid)[0]
+        zc, s0, s5 = np.zeros(62, np.complex64), np.zeros(62, np.float32), np.zeros(62, np.float32)
+        assert lib.srsran_pss_generate(_P(zc), cid % 3) == 0
+        lib.srsran_sss_generate(_P(s0), _P(s5), cid)
+        grids[i, 6, k0:k0 + 62] = zc      # last symbol of slot 0 (sync_test.c:130-150)
+        grids[i, 5, k0:k0 + 62] = s0
     d_grid = torch.from_numpy(grids.reshape(len(cells), -1).view(np.float32)).to(dev)
     d_sf = torch.zeros((len(cells), otx.sf_sz, 2), dtype=torch.float32, device=dev)
     otx.run(d_grid.data_ptr(), d_sf.data_ptr(), len(cells), st)
@@ -253,6 +275,8 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
                         "traffic": tr, "traffic_source": src, "avg_launch_ms": t_k * 1e3, "algorithmic_bytes_per_launch": caps * cap_bytes,
                         "note": "algorithmic = every capture read once (2,457,600 B); events bracket the whole call"}}
     if want_cpu:
+        import oracle_api as O
+
         x = d_caps[1].cpu().numpy().view(np.complex64).reshape(-1)
         O.pss_find_fft(x[:4096], N, 0)
         t0 = time.perf_counter()
@@ -281,7 +305,6 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=46, snr=19.0, i
     own transmit side; channel estimation (out of scope) is replaced by the known flat channel."""
     import torch
 
-    import oracle_api as O
     import srslte_amd as S
     from srslte_amd import capi
 
@@ -291,7 +314,9 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=46, snr=19.0, i
     n_re = len(data_sym) * nsc
     G = n_re * Qm
     tbs = 63776  # 11 code blocks of 5824 bits, no filler bits
-    ncb = O.cbsegm(tbs)["C"]
+    seg = capi.Cbsegm()
+    assert lib.srsran_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0
+    ncb = seg.C
     n_tb = ues * sf
     pool_n = 8
     rng = np.random.default_rng(100 + ctx.rank)
@@ -305,8 +330,8 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=46, snr=19.0, i
     capi.check(lib.srsran_hip_sch_encode(enc, d_pay.data_ptr(), txd, pool_n, d_eb.data_ptr(), st), "sch_encode")
     torch.cuda.synchronize()
     e = np.unpackbits(d_eb.cpu().numpy(), axis=1)
-    seeds = [O.pusch_seed(0x200 + i, 2 * (i % 10), 42) for i in range(pool_n)]
-    x = np.stack([O.modulate(e[i] ^ O.sequence_bits(seeds[i], G), mod) for i in range(pool_n)]).astype(np.complex64)
+    seeds = [lib.srsran_hip_sequence_pusch_seed(0x200 + i, 2 * (i % 10), 42) for i in range(pool_n)]
+    x = np.stack([_qam64(e[i] ^ _scrambling_bits(lib, seeds[i], G)) for i in range(pool_n)])
     d_x = torch.from_numpy(x.view(np.float32)).to(dev)  # [pool][n_re][2]
     fwd, inv = C.c_void_p(), C.c_void_p()
     capi.check(lib.srsran_hip_dft_batch_create(C.byref(fwd), nsc, capi.DFT_FORWARD, False, False, True), "dft fwd")  # dft_precoding.c: normalised
@@ -396,6 +421,8 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=46, snr=19.0, i
                         "algorithmic_bytes_per_launch": n_tb * unit_bytes,
                         "note": "algorithmic = time samples in (245,760 B) + payload out (7,972 B) per UE-subframe; wall time of the step, host work included"}}
     if want_cpu:
+        import oracle_api as O
+
         # one subframe through the CPU restatement of every stage: float stages against the device within 1e-4, integer stages bit for bit
         t0 = time.perf_counter()
         tsamp = d_time[0].cpu().numpy().view(np.complex64).reshape(-1)

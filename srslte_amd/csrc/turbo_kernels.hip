@@ -59,6 +59,8 @@ struct Ar16 {
   static constexpr bool kIs8 = false;
   static constexpr int  kInf = TD_INF;
   static __device__ __forceinline__ s2 add(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+  static __device__ __forceinline__ s2 add_raw(s2 a, s2 b) { return add(a, b); } // (see Ar8)
+  static __device__ __forceinline__ s2 clean(s2 v) { return v; }
   static __device__ __forceinline__ s2 sub(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }
   static __device__ __forceinline__ bool norm_at(uint32_t k) { return (k & 1) == 0 && k != 0; }
   // turbodecoder_win.h:480-498 (normalize_period 2; caller checks the step index)
@@ -73,19 +75,31 @@ struct Ar16 {
   static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return sub(m1, m0); }
   static __device__ __forceinline__ short tadd(short a, short b) { return (short)(a + b); } // tail trellis, plain adds
   static __device__ __forceinline__ short conv_in(int v) { return (short)v; }
+  static __device__ __forceinline__ short out16(short v) { return v; }
   // extrinsic exchange (turbodecoder_iter.h:108,115): srsran_vec_sub_sss, wrapping
   static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return a - b; }
 };
 
-// Arithmetic of the 8-bit window decoders (WINIMP_IS_SSE8 / AVX8, turbodecoder_win.h:154-300): saturating int8
-// (kept in int16 lanes and clamped), INF = 0, metrics re-based on their maximum at every step, LLR halved.
+// Arithmetic of the 8-bit window decoders (WINIMP_IS_SSE8 / AVX8, turbodecoder_win.h:154-300): saturating int8, INF = 0, metrics
+// re-based on their maximum at every step, LLR halved.
+// The int8 values live in the HIGH byte of each int16 half (v << 8, low byte zero): v_pk_add/sub_i16 with clamp then saturates the
+// negative side exactly where int8 does (-128 << 8 = -32768) and the positive side needs one v_pk_min_i16 with 127 << 8 -- two
+// instructions per saturating add instead of add + max + min on unshifted values, and the subtraction of the running maximum (a
+// result <= 0) needs none.  Wrapping int8 arithmetic is plain int16 arithmetic on the shifted values.  The 8-bit decoder is bound
+// by VALU issue (its per-step normalisation and the saturation emulation), not by HBM like the 16-bit one.
 struct Ar8 {
   static constexpr bool kIs8 = true;
   static constexpr int  kInf = 0;
-  static __device__ __forceinline__ s2 clamp8(s2 v) { return vmin(vmax(v, splat(-128)), splat(127)); }
-  static __device__ __forceinline__ s2 sext8(s2 v) { return (s2)(v << 8) >> 8; }
-  static __device__ __forceinline__ s2 add(s2 a, s2 b) { return clamp8(a + b); }
-  static __device__ __forceinline__ s2 sub(s2 a, s2 b) { return clamp8(a - b); }
+  static __device__ __forceinline__ s2 fix_hi(s2 v) { return vmin(v, splat((short)0x7f00)); }
+  static __device__ __forceinline__ s2 add(s2 a, s2 b) { return fix_hi(__builtin_elementwise_add_sat(a, b)); }
+  // add_raw + clean: the positive fix-up deferred past a max.  add_raw of a CLEAN operand (low byte zero) and one that may carry the
+  // low byte 0xff of an earlier positive saturation never carries into the value byte, comparisons are decided by the value byte, and
+  // clean() (one AND) turns both 0x7fff and a left-over 0xff into the exact representation -- so max(add_raw ...) followed by clean()
+  // equals max(add ...).  Never two unclean operands: the branch metrics and the stored betas are clean, the state metrics are
+  // cleaned right after their max.
+  static __device__ __forceinline__ s2 add_raw(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+  static __device__ __forceinline__ s2 clean(s2 v) { return from_u(to_u(v) & 0xff00ff00u); }
+  static __device__ __forceinline__ s2 sub(s2 a, s2 b) { return fix_hi(__builtin_elementwise_sub_sat(a, b)); }
   static __device__ __forceinline__ bool norm_at(uint32_t k) { return k != 0; }
   static __device__ __forceinline__ void normalize(s2 (&o)[8])
   {
@@ -96,26 +110,28 @@ struct Ar8 {
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      o[i] = sub(o[i], m);
+      o[i] = __builtin_elementwise_sub_sat(o[i], m); // <= 0: only the negative bound can be hit, and that one is exact
     }
   }
-  static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return sub(m1, m0) >> 1; } // divide_output 1
-  static __device__ __forceinline__ short tadd(short a, short b) // sadd(), :470-478: clamps the positive side only
+  // divide_output 1: (m1 - m0) >> 1 on int8 = arithmetic shift of the shifted value, then drop the bit that fell into the low byte
+  static __device__ __forceinline__ s2 llr(s2 m1, s2 m0) { return from_u(to_u(sub(m1, m0) >> 1) & 0xff00ff00u); }
+  static __device__ __forceinline__ short tadd(short a, short b) // sadd(), :470-478: clamps the positive side only, the negative one wraps
   {
     int z = a + b;
-    return z > 127 ? (short)127 : (short)(signed char)z;
+    return z > 0x7f00 ? (short)0x7f00 : (short)z;
   }
-  static __device__ __forceinline__ short conv_in(int v) { return (short)(signed char)v; } // convert_16_to_8
+  static __device__ __forceinline__ short conv_in(int v) { return (short)((unsigned)v << 8); } // convert_16_to_8, into the high byte
+  static __device__ __forceinline__ short out16(short v) { return (short)(v >> 8); }
   // srsran_vec_sub_bbb: saturating, except in the ragged tail of its 32-byte vector loop where it wraps
-  static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return wrap ? sext8(a - b) : clamp8(a - b); }
+  static __device__ __forceinline__ s2 ex_sub(s2 a, s2 b, bool wrap) { return wrap ? (s2)(a - b) : sub(a, b); }
 };
 
 // one backward step, turbodecoder_win.h:626-652
 template <class AR>
 __device__ __forceinline__ void beta_step(s2 (&o)[8], s2 x, s2 y)
 {
-  auto adds = [](s2 a, s2 b) { return AR::add(a, b); };
-  s2   xy   = adds(x, y);
+  auto adds = [](s2 a, s2 b) { return AR::add_raw(a, b); };
+  s2   xy   = AR::add(x, y);
   s2 n0 = vmax(adds(o[4], xy), o[0]);
   s2 n1 = vmax(o[4], adds(o[0], xy));
   s2 n2 = vmax(adds(o[5], y), adds(o[1], x));
@@ -124,22 +140,22 @@ __device__ __forceinline__ void beta_step(s2 (&o)[8], s2 x, s2 y)
   s2 n5 = vmax(adds(o[6], y), adds(o[2], x));
   s2 n6 = vmax(o[7], adds(o[3], xy));
   s2 n7 = vmax(adds(o[7], xy), o[3]);
-  o[0] = n0;
-  o[1] = n1;
-  o[2] = n2;
-  o[3] = n3;
-  o[4] = n4;
-  o[5] = n5;
-  o[6] = n6;
-  o[7] = n7;
+  o[0] = AR::clean(n0);
+  o[1] = AR::clean(n1);
+  o[2] = AR::clean(n2);
+  o[3] = AR::clean(n3);
+  o[4] = AR::clean(n4);
+  o[5] = AR::clean(n5);
+  o[6] = AR::clean(n6);
+  o[7] = AR::clean(n7);
 }
 
 // one forward step, turbodecoder_win.h:753-826.  WITH_LLR: also max1-max0 using the beta of the next step.
 template <class AR, bool WITH_LLR>
 __device__ __forceinline__ s2 alpha_step(s2 (&o)[8], const s2 (&b)[8], s2 x, s2 y)
 {
-  auto adds = [](s2 a, s2 b) { return AR::add(a, b); };
-  s2   xy   = adds(x, y);
+  auto adds = [](s2 a, s2 b) { return AR::add_raw(a, b); };
+  s2   xy   = AR::add(x, y);
   s2 m_b[8], nw[8];
   m_b[0] = o[0];
   m_b[1] = adds(o[3], y);
@@ -166,11 +182,11 @@ __device__ __forceinline__ s2 alpha_step(s2 (&o)[8], const s2 (&b)[8], s2 x, s2 
       m0 = vmax(m0, adds(b[i], m_b[i]));
       m1 = vmax(m1, adds(b[i], nw[i]));
     }
-    out = AR::llr(m1, m0);
+    out = AR::llr(AR::clean(m1), AR::clean(m0));
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    o[i] = vmax(m_b[i], nw[i]);
+    o[i] = AR::clean(vmax(m_b[i], nw[i]));
   }
   return out;
 }
@@ -694,8 +710,8 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
               c1 = ((c1 << 1) & 0xffffffu) ^ ((((c1 >> 23) ^ x1) & 1u) ? poly : 0u);
             }
             if (o16 && whole) { // parity aid: decision LLRs in natural order
-              o16[(2 * pl) * long_sb + b * 8 + j]     = v.x;
-              o16[(2 * pl + 1) * long_sb + b * 8 + j] = v.y;
+              o16[(2 * pl) * long_sb + b * 8 + j]     = AR::out16(v.x);
+              o16[(2 * pl + 1) * long_sb + b * 8 + j] = AR::out16(v.y);
             }
           }
         }
@@ -788,7 +804,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
         const short* sd = reinterpret_cast<const short*>(D);
         for (uint32_t nn = pl; nn < K; nn += LPC) {
           const uint32_t d = nn / long_sb, k = nn % long_sb;
-          o16[nn] = sd[(k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1)];
+          o16[nn] = AR::out16(sd[(k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1)]);
         }
       }
     }

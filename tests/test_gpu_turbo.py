@@ -94,6 +94,28 @@ def test_8bit_auto_all_regimes(hiplib, K):
         _check8(S, K, capi.TDEC_AUTO, O.ORC_TDEC_AUTO, 7, snr, (1, 2, 3, 4, 7, 8), seed=K * 5 + int(scale), scale=scale)
 
 
+@pytest.mark.parametrize("K", [6144, 1024, 816])
+def test_8bit_saturation_corner_cases(hiplib, K):
+    """LLRs that are nothing but extremes (-128, -127, 127 and a few small values, no code word behind them): every saturating add of
+    the 8-bit decoders hits a bound somewhere -- the device keeps int8 in the high byte of int16 halves and fixes the positive bound up
+    after the fact (turbo_kernels.hip, Ar8); hard bits and decision LLRs must still equal the oracle's after every iteration count"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    rng = np.random.default_rng(K)
+    n_cb = 6
+    llr = rng.choice(np.array([-128, -127, 127, 127, -128, 0, 1, -1, 64, -64], np.int8), size=(n_cb, 3 * K + 12))
+    llr[0] = 127
+    llr[1] = -128
+    dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO, llr8=True)
+    for nit in (1, 2, 3, 8):
+        ref, ref_llr = O.turbo_decode_8bit(llr, nit, K, O.ORC_TDEC_AUTO, 0, want_llr=True)
+        out, out_llr = dec.decode(llr, nit, 0, want_llr=True)
+        assert np.array_equal(ref, out), (K, nit)
+        assert np.array_equal(ref_llr, out_llr), (K, nit)
+    dec.free()
+
+
 @pytest.mark.parametrize("impl,K", [("SSE8_WINDOW", 816), ("SSE8_WINDOW", 6144), ("AVX8_WINDOW", 1344), ("AVX8_WINDOW", 6144)])
 def test_8bit_manual_implementations(hiplib, impl, K):
     import srslte_amd as S

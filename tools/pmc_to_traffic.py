@@ -20,14 +20,14 @@ def mean_counter(d, counter):
         cur = sqlite3.connect(path).cursor()
         for n, v in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
             acc[n].append(v)
-    return {n: sum(v) / len(v) for n, v in acc.items()}
+    return {n: max(v) for n, v in acc.items()}  # the bench-sized dispatches are the largest ones of each kernel
 
 
 def main():
     fetch, write = mean_counter(sys.argv[1], "FETCH_SIZE"), mean_counter(sys.argv[2], "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) on `python bench.py --steps 2 --warmup 1 "
                      "--extra-steps 2 --no-cpu`; FETCH_SIZE (KB) doubled for 16-byte-per-lane reads on gfx950 as MI355X_MICROARCH.md prescribes, "
-                     "WRITE_SIZE (KB) taken as is; mean over the dispatches of the run"}
+                     "WRITE_SIZE (KB) taken as is; largest dispatch of each kernel (= the bench-sized launch)"}
     for frag, (key, ukey, units) in UNITS.items():
         f = [v for n, v in fetch.items() if frag in n]
         w = [v for n, v in write.items() if frag in n]

@@ -62,6 +62,7 @@ public:
   // blocking: `in` (in_bytes) -> `out` (out_bytes), host memory of the caller.  Returns the run function's code.
   int submit(const void* in, void* out)
   {
+    bind_thread();
     Req                          r{in, out, 0, false, false};
     std::unique_lock<std::mutex> lk(mu_);
     queue_.push_back(&r);

@@ -22,8 +22,23 @@ const char* get_error()
   return g_err;
 }
 
+namespace {
+std::atomic<int> g_device{-1}; // -1: never chosen, every thread stays where HIP put it
+}
+
+void bind_thread()
+{
+  static thread_local int bound = -1;
+  const int               want  = g_device.load(std::memory_order_relaxed);
+  if (want >= 0 && bound != want) {
+    (void)hipSetDevice(want);
+    bound = want;
+  }
+}
+
 bool device_available()
 {
+  bind_thread();
   static std::once_flag once;
   static bool           ok = false;
   std::call_once(once, [] {
@@ -126,6 +141,7 @@ extern "C" int srsran_hip_device_count(void)
 extern "C" int srsran_hip_set_device(int device)
 {
   PHY_HIP_CHECK(hipSetDevice(device), SRSRAN_ERROR);
+  g_device.store(device, std::memory_order_relaxed); // worker threads follow (bind_thread)
   return SRSRAN_SUCCESS;
 }
 

@@ -42,6 +42,11 @@ const char* get_error();
 // true when a HIP device is usable; prints one diagnostic otherwise
 bool device_available();
 
+// The device chosen with srsran_hip_set_device() is the PROCESS's device (one process per GPU): HIP keeps the current device per
+// thread and starts every new thread on device 0, so the handle-API entry points bind the calling worker thread to the process's
+// device before they touch a stream (a thread-local compare after the first call).
+void bind_thread();
+
 static inline uint32_t ceil_div(uint32_t a, uint32_t b)
 {
   return (a + b - 1) / b;

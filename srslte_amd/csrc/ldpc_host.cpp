@@ -521,6 +521,7 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   if (!c) {
     return -1;
   }
+  bind_thread();
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
   if (coalescing_enabled()) {

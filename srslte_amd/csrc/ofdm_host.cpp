@@ -505,6 +505,7 @@ int ctx_sync(srsran_ofdm_t* q)
     fprintf(stderr, "[srsran_phy_hip] srsran_ofdm: object not initialised\n");
     return SRSRAN_ERROR;
   }
+  bind_thread();
   const bool normcp = q->cfg.cp == SRSRAN_CP_NORM;
   Geometry   g;
   g.N          = (int)q->cfg.symbol_sz;

@@ -655,6 +655,7 @@ static void tdec_handle_iterate(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
     fprintf(stderr, "[srsran_phy_hip] srsran_tdec: handle not initialised\n");
     return;
   }
+  bind_thread();
   const uint32_t K = h->current_long_cb;
   if ((uint32_t)srsran_cbsegm_cbsize(h->current_cbidx) != K) {
     fprintf(stderr, "[srsran_phy_hip] srsran_tdec: K=%u is not a valid turbo block size\n", K);

@@ -38,6 +38,9 @@ SRSRAN_API const char* srsran_hip_build_info(void);
 SRSRAN_API void srsran_hip_set_coalescing(int enable);
 SRSRAN_API void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_units);
 
+/* Batch objects (every srsran_hip_*_batch_t, srsran_hip_sch_t, srsran_hip_sch_nr_t, srsran_hip_cellsearch_t ...) own device workspace
+ * (decoder state, message slabs, correlation buffers): ONE stream per object at a time.  Calls on the same object are ordered by that
+ * stream; to run two batches concurrently create two objects. */
 /* ---- turbo decoder: srsran_tdec_run_all (turbodecoder.c:536-549) over n_cb code blocks ---- */
 typedef struct srsran_hip_tdec_batch srsran_hip_tdec_batch_t;
 

@@ -10,10 +10,14 @@
  *   - turbo / QPP / LDPC: pinned bit-exactly against the reference's own compiled sources
  *     (oracle/_ref/libsrsran_ref.so, built by oracle/Makefile) and against the reference's golden
  *     vectors (turbodecoder_test.h K=504 known answer; examplesBG1/BG2.dat) -- tests/test_oracle_*.py
- *   - OFDM / DFT / PSS / SSS: the reference needs FFTW3, absent from this image -> unbuildable here.
+ *   - PSS / SSS: pinned to the recorded air captures the reference's own tests hold (phch/test/signal.1.92M.dat,
+ *     signal.1.92M.amar.dat, signal.10M.dat with the cell ids of phch/test/CMakeLists.txt:433,439-442: 150, 1, 150):
+ *     tests/golden/sync_captures.npz, tests/test_oracle_golden.py::test_sync_oracle_on_reference_captures; all 504 SSS
+ *     sequences bit-equal to gen_sss.c (part of oracle/_ref).
+ *   - OFDM / DFT: the reference needs FFTW3, absent from this image -> unbuildable here.
  *     The restatement is pinned by the reference's own acceptance criteria (ofdm_test.c:176 loop-back
- *     RMS < 1e-4; sync_test.c:164 peak position) and a float64 direct DFT.  FFT values themselves are
- *     parity-unpinned beyond 1e-4, exactly as in the reference (FFTW is an unpinned system library).
+ *     RMS < 1e-4; sync_test.c:164 peak position) and a float64 direct DFT.  FFT VALUES themselves are
+ *     "parity unpinned" beyond 1e-4, exactly as in the reference (FFTW is an unpinned system library).
  */
 #ifndef ORACLE_H
 #define ORACLE_H

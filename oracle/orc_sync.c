@@ -13,6 +13,9 @@
  * IS part of oracle/_ref, which pins orc_sss_generate bit-exactly.  The correlation is evaluated in
  * float64 (exact linear convolution) and rounded to float: parity on the peak INDEX and on PSR /
  * peak value within 1e-4 relative is what the tests require (sync_test.c:164-176 asserts the index).
+ * Pinned to known answers the reference holds: its recorded captures signal.1.92M.dat (cell 150), signal.1.92M.amar.dat (cell 1,
+ * subframes 0 and 5) and signal.10M.dat (cell 150) give exactly these cells through orc_pss_find + orc_sss_m0m1
+ * (tests/golden/sync_captures.npz, tests/test_oracle_golden.py::test_sync_oracle_on_reference_captures).
  */
 #include "oracle.h"
 

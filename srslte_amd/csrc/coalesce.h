@@ -12,7 +12,8 @@
 // Nobody ever waits for a timer: with few callers every call runs at once on its own lane (the decoder kernels are latency
 // bound -- one wave per code word -- so a handful of small launches overlap perfectly); the busier the process, the larger the
 // batches, and the driver sees at most that many submitting threads per shape however many workers there are.
-// Lanes per shape: 4 for the turbo decoder, 1 for LDPC (measured, profiles/r02_bench_handle.json).
+// Lanes per shape: 4 for the turbo decoder; 1 for LDPC, which also keeps its private streams while at most four callers are inside the
+// decoder (measured, profiles/r02_bench_handle.json).
 // Results are the batched kernels' results, which the parity tests pin to the oracle per unit, so a call gives the same bytes
 // whether it was merged or not.  SRSRAN_HIP_COALESCE=0 turns merging off (every handle then uses its private stream).
 #pragma once

@@ -8,6 +8,7 @@
 #include "tables/nr_ldpc_bg_table.h"
 #include "tables/nr_ldpc_lsindex.h"
 
+#include <atomic>
 #include <map>
 #include <vector>
 
@@ -524,7 +525,16 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   bind_thread();
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
-  if (coalescing_enabled()) {
+  // callers inside this function right now (any handle): with a handful of them the private streams overlap their one-workgroup
+  // launches perfectly (3 threads: 23 Mbit/s against 10 through the single-lane queue), beyond that the driver serialises the
+  // submissions and the queue wins (16 threads: 35 against 32; profiles/r02_bench_handle.json)
+  static std::atomic<int> g_inflight{0};
+  struct Inflight {
+    int n;
+    Inflight() : n(++g_inflight) {}
+    ~Inflight() { --g_inflight; }
+  } inflight;
+  if (coalescing_enabled() && inflight.n > 4) {
     // decodes of the same shape that are in flight on different handles share one batch launch (coalesce.h); a record of the
     // output staging area is the message followed by the iteration count of the CRC early stop
     const uint32_t nit_off = (liftK + 3u) & ~3u;

@@ -49,7 +49,8 @@ def test_concurrent_handles_all_results_equal_the_oracle(hiplib, coalesce):
     b0, u0 = _stats(lib)
     calls = 6
     workers = []
-    n_queued = [0]
+    n_queued = [0]  # turbo calls: always through a queue
+    n_maybe = [0]   # LDPC calls: through the queue only while more than four callers are inside the decoder
 
     def tdec_worker(K, llr8, seed, nit):
         if llr8:
@@ -134,7 +135,7 @@ def test_concurrent_handles_all_results_equal_the_oracle(hiplib, coalesce):
                     assert np.array_equal(out, refs[i]), ("ldpc", bg, Z, i)
             lib.srsran_ldpc_decoder_free(C.byref(q))
 
-        n_queued[0] += calls
+        n_maybe[0] += calls
         return run
 
     workers += [tdec_worker(6144, False, 1, 8), tdec_worker(6144, False, 2, 8), tdec_worker(6144, True, 3, 8), tdec_worker(1024, False, 4, 5),
@@ -145,8 +146,8 @@ def test_concurrent_handles_all_results_equal_the_oracle(hiplib, coalesce):
         _run_threads(workers)
         b1, u1 = _stats(lib)
         if coalesce:
-            assert u1 - u0 == n_queued[0]          # every decoder call went through a queue
-            assert 0 < b1 - b0 <= u1 - u0          # ... in at most as many launches
+            assert n_queued[0] <= u1 - u0 <= n_queued[0] + n_maybe[0]  # every turbo call went through a queue
+            assert 0 < b1 - b0 <= u1 - u0                              # ... in at most as many launches
         else:
             assert (b1, u1) == (b0, u0)            # private streams only
     finally:

@@ -332,6 +332,91 @@ __device__ __forceinline__ void rows_to_lane(uint32_t* stage, int lane, const ui
   }
 }
 
+// ---- storage policy.  The 16-bit decoders keep one int16x2 dword per (lane, step) in the workspace.  The 8-bit decoders' values are
+// int8 by construction (in registers: value << 8 in each int16 half, low bytes zero -- see Ar8), so their workspace holds ONE 16-bit
+// word per (lane, step): half the HBM traffic of a kernel that runs at the HBM ceiling.  S8 = AR::kIs8 selects the layout:
+//   blocked arrays (S, P0, P1, check-points): 8 steps of a lane = 16 bytes = ONE dwordx4 (1 KB contiguous per wave instruction)
+//   row arrays (A1, A2, D): a row of the wave = 64 x 2 bytes; the 8 rows of a block are 1 KB = ONE dwordx4 per lane
+// Loads stay PACKED in the prefetch registers (4 dwords instead of 8 per operand block) and are widened where they are consumed:
+// one v_perm_b32 per step puts the two bytes into the high bytes of the halves; one v_perm_b32 packs two steps for a store.
+__device__ __forceinline__ uint32_t s8_unpack_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x010c000cu); } // bytes 0, 1
+__device__ __forceinline__ uint32_t s8_unpack_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x030c020cu); } // bytes 2, 3
+__device__ __forceinline__ uint32_t s8_pack2(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07050301u); } // (a.b1, a.b3, b.b1, b.b3)
+__device__ __forceinline__ uint16_t s8_pack1(uint32_t a) { return (uint16_t)__builtin_amdgcn_perm(0u, a, 0x0c0c0301u); }
+
+// raw (as stored) form of one 8-step block of a blocked array: 8 dwords, or 4 with 8-bit storage
+template <bool S8>
+__device__ __forceinline__ void load_block_raw(const uint32_t* arr, uint32_t blk_lane, uint32_t (&r)[8])
+{
+  if constexpr (S8) {
+    const uint4 a = *reinterpret_cast<const uint4*>(arr + (size_t)blk_lane * 4);
+    r[0] = a.x;
+    r[1] = a.y;
+    r[2] = a.z;
+    r[3] = a.w;
+  } else {
+    load_block(arr, blk_lane, r);
+  }
+}
+// raw -> the 8 int16x2 values of the block
+template <bool S8>
+__device__ __forceinline__ void block_values(const uint32_t (&raw)[8], uint32_t (&v)[8])
+{
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    v[2 * d]     = S8 ? s8_unpack_lo(raw[d]) : raw[2 * d];
+    v[2 * d + 1] = S8 ? s8_unpack_hi(raw[d]) : raw[2 * d + 1];
+  }
+}
+template <bool S8>
+__device__ __forceinline__ void store_block_v(uint32_t* arr, uint32_t blk_lane, const uint32_t (&v)[8])
+{
+  if constexpr (S8) {
+    *reinterpret_cast<uint4*>(arr + (size_t)blk_lane * 4) = make_uint4(s8_pack2(v[0], v[1]), s8_pack2(v[2], v[3]), s8_pack2(v[4], v[5]), s8_pack2(v[6], v[7]));
+  } else {
+    store_block(arr, blk_lane, v);
+  }
+}
+// the 8 rows of block b of a row array, as stored: two dwordx4 per lane, or one with 8-bit storage
+template <bool S8>
+__device__ __forceinline__ void issue_rows_raw(const uint32_t* arr, uint32_t b, int lane, uint32_t (&t)[8])
+{
+  if constexpr (S8) {
+    const uint4 a = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(arr) + (size_t)(b * 8) * 64)[lane];
+    t[0] = a.x;
+    t[1] = a.y;
+    t[2] = a.z;
+    t[3] = a.w;
+  } else {
+    issue_rows(arr, b, lane, t);
+  }
+}
+// ... turned into "8 rows of this lane's column" (int16x2 values) through the LDS stage
+template <bool S8>
+__device__ __forceinline__ void rows_to_lane_v(uint32_t* stage, int lane, const uint32_t (&t)[8], uint32_t (&r)[8])
+{
+  if constexpr (S8) {
+    reinterpret_cast<uint4*>(stage)[lane] = make_uint4(t[0], t[1], t[2], t[3]); // in-order LDS pipeline, one wave per workgroup: no barrier
+    const uint16_t* s16 = reinterpret_cast<const uint16_t*>(stage);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      r[j] = s8_unpack_lo((uint32_t)s16[j * 64 + lane]);
+    }
+  } else {
+    rows_to_lane(stage, lane, t, r);
+  }
+}
+// one element of a row array: (row, lane) <- int16x2 value
+template <bool S8>
+__device__ __forceinline__ void store_row(uint32_t* arr, size_t row, int lane, uint32_t v)
+{
+  if constexpr (S8) {
+    reinterpret_cast<uint16_t*>(arr)[row * 64 + lane] = s8_pack1(v);
+  } else {
+    arr[row * 64 + lane] = v;
+  }
+}
+
 // value for this lane's two destination sub-blocks, fetched from the lanes holding the source sub-blocks
 template <int LPC>
 __device__ __forceinline__ uint32_t permute_pair(uint32_t v, uint32_t sel)
@@ -386,9 +471,9 @@ __device__ __forceinline__ void extract_input(const T* in, int sb_layout, uint32
       y0[j] = (uint32_t)(uint16_t)r[0][3 * j + 1] | ((uint32_t)(uint16_t)r[1][3 * j + 1] << 16);
       y1[j] = (uint32_t)(uint16_t)r[0][3 * j + 2] | ((uint32_t)(uint16_t)r[1][3 * j + 2] << 16);
     }
-    store_block(S, b * 64 + lane, s);
-    store_block(P0, b * 64 + lane, y0);
-    store_block(P1, b * 64 + lane, y1);
+    store_block_v<AR::kIs8>(S, b * 64 + lane, s);
+    store_block_v<AR::kIs8>(P0, b * 64 + lane, y0);
+    store_block_v<AR::kIs8>(P1, b * 64 + lane, y1);
   }
   if (pl == 0 && tails) {
     const uint32_t tb = sb_layout ? 3 * (K + 32) : 3 * K;
@@ -507,9 +592,9 @@ __device__ __forceinline__ void extract_input_natural16(const short* in_wave, ui
             y1[j] = (uint32_t)(uint16_t)AR::conv_in(r[0][3 * j + 2]) | ((uint32_t)(uint16_t)AR::conv_in(r[1][3 * j + 2]) << 16);
           }
           const uint32_t slot = (b0 + lb) * 64 + cw * LPC + pp;
-          store_block(S, slot, sv);
-          store_block(P0, slot, y0);
-          store_block(P1, slot, y1);
+          store_block_v<AR::kIs8>(S, slot, sv);
+          store_block_v<AR::kIs8>(P0, slot, y0);
+          store_block_v<AR::kIs8>(P1, slot, y1);
         }
       }
     }
@@ -550,7 +635,7 @@ __device__ __forceinline__ void extract_input_sb16(const short* in, uint32_t K, 
       const uint32_t w = stage[cbw * 8 * LPC + j * LPC + pl];
       r[j] = (uint32_t)(uint16_t)AR::conv_in((short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((short)(w >> 16)) << 16);
     }
-    store_block(dst, b * 64 + lane, r);
+    store_block_v<AR::kIs8>(dst, b * 64 + lane, r);
   };
   for (uint32_t b = 0; b < nblk; b++) {
     // all six loads of the block are issued before the first use (named registers: an indexed local array ends up in scratch)
@@ -661,7 +746,8 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
   uint32_t m_own_v = ~0u, m_row_v = ~0u;
   auto     set_masks = [&](bool dead) {
     const unsigned long long dm = __ballot(dead);
-    const int                og = ((4 * (lane & 15)) / LPC) * LPC; // first lane of the group owning columns 4 (lane % 16) .. + 3
+    // first lane of the group owning the columns this lane fetches in issue_rows: 4 (lane % 16) .. + 3, or 8 (lane % 8) .. + 7 with 8-bit storage
+    const int                og = AR::kIs8 ? ((8 * (lane & 7)) / LPC) * LPC : ((4 * (lane & 15)) / LPC) * LPC;
     m_own_v                     = dead ? 0u : ~0u;
     m_row_v                     = ((dm >> og) & 1ull) ? 0u : ~0u;
   };
@@ -690,13 +776,13 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
       const bool wide = whole && ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0) && out_bytes == K / 8;
       uint32_t   w0 = 0, w1 = 0;
       uint32_t   t[8], tn[8];
-      issue_rows(D, 0, lane, t);
+      issue_rows_raw<AR::kIs8>(D, 0, lane, t);
       for (uint32_t b = 0; b < nblk; b++) {
         if (b + 1 < nblk) {
-          issue_rows(D, (b + 1) & M_ROW, lane, tn);
+          issue_rows_raw<AR::kIs8>(D, (b + 1) & M_ROW, lane, tn);
         }
         uint32_t r[8];
-        rows_to_lane(Tr, lane, t, r);
+        rows_to_lane_v<AR::kIs8>(Tr, lane, t, r);
         uint32_t b0 = 0, b1 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -804,7 +890,8 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
         const short* sd = reinterpret_cast<const short*>(D);
         for (uint32_t nn = pl; nn < K; nn += LPC) {
           const uint32_t d = nn / long_sb, k = nn % long_sb;
-          o16[nn] = AR::out16(sd[(k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1)]);
+          const uint32_t e = (k * 64 + (lane / LPC) * LPC + (d >> 1)) * 2 + (d & 1);
+          o16[nn] = AR::kIs8 ? (short)reinterpret_cast<const signed char*>(D)[e] : sd[e]; // (8-bit storage holds the plain int8 values)
         }
       }
     }
@@ -829,32 +916,30 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
     };
     auto issue = [&](uint32_t b, Ops& q) {
       if (dec1) {
-        load_block(S, (b & M_OWN) * 64 + lane, q.x);
+        load_block_raw<AR::kIs8>(S, (b & M_OWN) * 64 + lane, q.x);
       } else {
-        issue_rows(A2, b & M_ROW, lane, q.x);
+        issue_rows_raw<AR::kIs8>(A2, b & M_ROW, lane, q.x);
       }
-      load_block(Y, (b & M_OWN) * 64 + lane, q.y);
+      load_block_raw<AR::kIs8>(Y, (b & M_OWN) * 64 + lane, q.y);
       if (has_app) {
-        issue_rows(A1, b & M_ROW, lane, q.a);
+        issue_rows_raw<AR::kIs8>(A1, b & M_ROW, lane, q.a);
       }
     };
     auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
-      uint32_t xr[8], ar[8];
+      uint32_t xr[8], ar[8], yr[8];
       if (dec1) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          xr[j] = q.x[j];
-        }
+        block_values<AR::kIs8>(q.x, xr);
       } else {
-        rows_to_lane(Tr, lane, q.x, xr);
+        rows_to_lane_v<AR::kIs8>(Tr, lane, q.x, xr);
       }
       if (has_app) {
-        rows_to_lane(Tr, lane, q.a, ar);
+        rows_to_lane_v<AR::kIs8>(Tr, lane, q.a, ar);
       }
+      block_values<AR::kIs8>(q.y, yr);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         xs[j] = from_u(xr[j]);
-        ys[j] = from_u(q.y[j]);
+        ys[j] = from_u(yr[j]);
         ap[j] = splat(0);
         if (has_app) {
           ap[j] = from_u(ar[j]);
@@ -903,7 +988,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
       for (int i = 0; i < 8; i++) {
         ck[i] = to_u(o[i]);
       }
-      store_block(CK, (nblk & M_OWN) * 64 + lane, ck);
+      store_block_v<AR::kIs8>(CK, (nblk & M_OWN) * 64 + lane, ck);
     }
     // pass 1: whole sub-block, keep a check-point at every block boundary
     if (nblk > 1) {
@@ -926,7 +1011,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
             for (int i = 0; i < 8; i++) {
               ck[i] = to_u(o[i]);
             }
-            store_block(CK, ((uint32_t)b & M_OWN) * 64 + lane, ck);
+            store_block_v<AR::kIs8>(CK, ((uint32_t)b & M_OWN) * 64 + lane, ck);
           }
           if (AR::norm_at(k)) {
             AR::normalize(o);
@@ -987,7 +1072,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
     const bool last = (n + 1 == p.n_end) || crc_poly; // with early stop every half iteration may be the last
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
-    load_block(CK, (1u & M_OWN) * 64 + lane, ck);
+    load_block_raw<AR::kIs8>(CK, (1u & M_OWN) * 64 + lane, ck);
     load_lut(lut, pl, tr);
     if (nblk > 1) {
       issue(1, nxt);
@@ -999,20 +1084,22 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
         issue(b + 2, nx2);
       }
       if (b + 1 < nblk) {
-        load_block(CK, ((b + 2) & M_OWN) * 64 + lane, ckn);
+        load_block_raw<AR::kIs8>(CK, ((b + 2) & M_OWN) * 64 + lane, ckn);
         load_lut(lut, (b + 1) * LPC + pl, trn);
       }
       prep(cur, xs, ys, ap);
       // re-derive beta[8b+1 .. 8b+len] (the stored, pre-normalisation values) from the check-point into
       // this lane's private LDS slots (registers are needed for the prefetched operands)
       {
-        s2 st[8];
+        s2       st[8];
+        uint32_t ckv[8];
+        block_values<AR::kIs8>(ck, ckv);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          st[i] = from_u(ck[i]);
+          st[i] = from_u(ckv[i]);
         }
-        Bl[len - 1][0][lane] = make_uint4(ck[0], ck[1], ck[2], ck[3]);
-        Bl[len - 1][1][lane] = make_uint4(ck[4], ck[5], ck[6], ck[7]);
+        Bl[len - 1][0][lane] = make_uint4(ckv[0], ckv[1], ckv[2], ckv[3]);
+        Bl[len - 1][1][lane] = make_uint4(ckv[4], ckv[5], ckv[6], ckv[7]);
 #pragma unroll
         for (int j = 6; j >= 0; j--) {
           if (j <= len - 2) {
@@ -1054,14 +1141,14 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
       for (int j = 0; j < 8; j++) {
         if (j < len) {
           const uint32_t row = tr[j] & 0xffffu & M_OWN;
-          dst[(size_t)row * 64 + lane] = permute_pair<LPC>(outv[j], tr[j] >> 16);
+          store_row<AR::kIs8>(dst, row, lane, permute_pair<LPC>(outv[j], tr[j] >> 16));
           if (last) {
             // what tdec_decision_byte reads (turbodecoder.c:370-378), in natural order: ext1 after decoder 1,
             // the de-interleaved ext2 (= app1 before the subtraction) after decoder 2
             if (dec1) {
-              D[(size_t)((b * 8 + j) & M_OWN) * 64 + lane] = rawv[j];
+              store_row<AR::kIs8>(D, (b * 8 + j) & M_OWN, lane, rawv[j]);
             } else {
-              D[(size_t)row * 64 + lane] = permute_pair<LPC>(rawv[j], tr[j] >> 16);
+              store_row<AR::kIs8>(D, row, lane, permute_pair<LPC>(rawv[j], tr[j] >> 16));
             }
           }
         }

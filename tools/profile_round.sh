@@ -40,6 +40,14 @@ for V in product waves1 persistent; do
   rm -rf $OUT/v_f $OUT/v_w $OUT/v_s
 done
 unset SRSRAN_HIP_TDEC_VARIANT
+# ---- the 8-bit decoders (what srsenb / srsue run): time against the 16-bit one and the reference's, traffic and VALU counters
+python tools/dbg/turbo8_time.py > $OUT/turbo8_time.txt 2> /dev/null
+: > $OUT/pmc_turbo8.txt
+for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  rocprofv3 --pmc $C -d $OUT/t8 -o p -- python tools/dbg/turbo8_time.py > /dev/null 2> $OUT/v.err &&
+  python tools/rocpd_summary.py $OUT/t8 | grep -E "tdec_win" >> $OUT/pmc_turbo8.txt
+  rm -rf $OUT/t8
+done
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o acs_layout_probe acs_layout_probe.hip 2> /dev/null; ./acs_layout_probe ) > $OUT/acs_layout_probe.txt 2>&1
 cat $OUT/acs_layout_probe.txt
 echo "profile pass rc=$?"

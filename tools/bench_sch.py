@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3); ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tbs", type=int, default=2496); ap.add_argument("--snr", type=float, default=6.0)  # 2496 x 13 blocks = 4056 waves: two rounds of the 2048 resident ones
     ap.add_argument("--iters", type=int, default=8); ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--llr8", action="store_true", help="q->llr_is_8bit (what srsenb / srsue set, cc_worker.cc): int8 LLRs and soft buffers, srsran_hip_sch_decode_8bit")
     a = ap.parse_args()
     import torch
     import srslte_amd as S, oracle_api as O
@@ -27,11 +28,14 @@ def main():
     pool_n = 8
     rng = np.random.default_rng(4)
     pool = [O.make_tb(tbs, Qm, G, 0, a.snr, rng) for _ in range(pool_n)]
+    sdt, tdt = (np.int8, torch.int8) if a.llr8 else (np.int16, torch.int16)
+    if a.llr8:  # scaled to about +-10 per soft bit and clipped, as the 8-bit tests do
+        pool = [(np.clip(np.round(e * (10.0 / np.mean(np.abs(e)))), -100, 100).astype(np.int8), pay) for e, pay in pool]
     e_pool = torch.from_numpy(np.stack([p[0] for p in pool])).to(dev)
     d_e = e_pool.repeat((a.tbs + pool_n - 1) // pool_n, 1)[:a.tbs].contiguous()
     dlen = tbs // 8 + 8
     d_data = torch.zeros((a.tbs, dlen), dtype=torch.uint8, device=dev)
-    d_soft = torch.zeros((a.tbs * ncb, capi.SOFTBUFFER_CB_SIZE), dtype=torch.int16, device=dev)
+    d_soft = torch.zeros((a.tbs * ncb, capi.SOFTBUFFER_CB_SIZE), dtype=tdt, device=dev)
     tb_arr = (capi.HipTb * a.tbs)(*[capi.HipTb(tbs, Qm, 0x100, G, i * G, i * dlen, i * ncb) for i in range(a.tbs)])
     res = (capi.HipTbResult * a.tbs)()
     flags = np.zeros(a.tbs * ncb, np.uint8)
@@ -44,8 +48,8 @@ def main():
         # first transmission: the blocks carry SRSRAN_HIP_TB_NEW_DATA (0x100 in rv), which stands for srsran_softbuffer_rx_reset
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        capi.check(lib.srsran_hip_sch_decode(h, d_e.data_ptr(), tb_arr, a.tbs, a.iters, d_soft.data_ptr(), flags.ctypes.data, d_data.data_ptr(),
-                                             res, st), "sch_decode")
+        fn = lib.srsran_hip_sch_decode_8bit if a.llr8 else lib.srsran_hip_sch_decode
+        capi.check(fn(h, d_e.data_ptr(), tb_arr, a.tbs, a.iters, d_soft.data_ptr(), flags.ctypes.data, d_data.data_ptr(), res, st), "sch_decode")
         return time.perf_counter() - t0
 
     for _ in range(a.warmup):
@@ -59,18 +63,22 @@ def main():
     t1 = time.perf_counter()
     par = True
     for i in range(a.cpu_sample):
-        soft, crc = np.zeros((ncb, capi.SOFTBUFFER_CB_SIZE), np.int16), np.zeros(ncb, np.uint8)
+        soft, crc = np.zeros((ncb, capi.SOFTBUFFER_CB_SIZE), sdt), np.zeros(ncb, np.uint8)
         ret, data, avg = O.sch_decode_tb(tbs, Qm, 0, pool[i][0], soft, crc, a.iters)
         par = par and ret == res[i].crc_ok and abs(avg - res[i].avg_iterations) < 1e-6 and np.array_equal(data[:tbs // 8 + 3], got[i][:tbs // 8 + 3])
     tc = time.perf_counter() - t1
     # the same code blocks at a fixed number of half iterations (srsran_tdec_run_all through the batch API)
     K = seg["K1"]
-    nb = lib.srsran_tdec_autoimp_get_subblocks(K)
-    dec = S.TdecBatch(K, a.tbs * ncb, capi.TDEC_AUTO)
+    dec = S.TdecBatch(K, a.tbs * ncb, capi.TDEC_AUTO, llr8=a.llr8)
     d_bits = torch.zeros((a.tbs * ncb, K // 8), dtype=torch.uint8, device=dev)
     def fixed():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); dec.run(d_soft, capi.SOFTBUFFER_CB_SIZE, d_bits, K // 8, a.tbs * ncb, a.iters, 1, st); e1.record()
+        e0.record()
+        if a.llr8:
+            capi.check(lib.srsran_hip_tdec_batch_run_8bit(dec._h, d_soft.data_ptr(), capi.SOFTBUFFER_CB_SIZE, d_bits.data_ptr(), K // 8, a.tbs * ncb, a.iters, 1, st), "run8")
+        else:
+            dec.run(d_soft, capi.SOFTBUFFER_CB_SIZE, d_bits, K // 8, a.tbs * ncb, a.iters, 1, st)
+        e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3
     fixed(); t_fixed = fixed()
@@ -90,8 +98,8 @@ def main():
     enc_ok = np.array_equal(np.unpackbits(d_tx[0].cpu().numpy())[:e_ref.size], e_ref)
     out = {"metric": "transport blocks decoded, Mbit/s of TBS (LTE 64-QAM TBS 75376: rate de-matching + turbo with CRC early stop + TB CRC)",
            "value": a.tbs * tbs / dt / 1e6, "unit": "Mbit/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
-           "config": {"workload": "%d transport blocks x %d code blocks of %d bits, first transmission, Es/N0 knob %.1f dB, max %d half iterations"
-                                  % (a.tbs, ncb, K, a.snr, a.iters)},
+           "config": {"workload": "%d transport blocks x %d code blocks of %d bits, first transmission, Es/N0 knob %.1f dB, max %d half iterations, %s"
+                                  % (a.tbs, ncb, K, a.snr, a.iters, "int8 LLRs (q->llr_is_8bit)" if a.llr8 else "int16 LLRs")},
            "tb_crc_ok": ok, "avg_half_iterations": avg_it, "payload_matches_on_ok_blocks": bool(good),
            "encode_ms": t_enc * 1e3, "encode_mbit_per_s": a.tbs * tbs / t_enc / 1e6, "encode_matches_oracle": bool(enc_ok),
            "fixed_iterations_turbo_only_ms": t_fixed * 1e3, "fixed_iterations_mbit_per_s": a.tbs * ncb * K / t_fixed / 1e6,

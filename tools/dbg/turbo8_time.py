@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import srslte_amd as S, oracle_api as O
 from srslte_amd import capi
-n_cb = 65520
+n_cb = int(os.environ.get("N_CB", "65520"))
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 K = 6144

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrsran_phy_hip.so")
+# SRSRAN_HIP_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("SRSRAN_HIP_LIB") or os.path.join(_HERE, "lib", "libsrsran_phy_hip.so")
 
 SRSRAN_SUCCESS = 0
 SRSRAN_ERROR = -1

@@ -30,6 +30,23 @@ typedef short s2 __attribute__((ext_vector_type(2)));
 
 #define TD_INF 10000 // turbodecoder_win.h:56 / turbodecoder_gen.c:37
 #define TD_WIN_OVERLAP 40
+// Non-temporal workspace loads (NT): nothing the fixed-iteration 16-bit decoder reads is read again before several hundred KB per
+// wave have passed, so keeping it in L2 only evicts lines that are still being written.  Measured on one box (K = 6144, 65,520 blocks,
+// 8 half iterations): 12.03 ms without, 11.81 ms with the systematic / parity operands non-temporal, 11.74 ms with the exchanged rows
+// too, 11.58 ms with the check-points as well; non-temporal STORES cost (12.2 ms).  The 8-bit decoders (14.7 -> 15.8 ms) and the
+// early-stop mode (-2.5 % on the transport-block benches) lose with it -- their smaller, partly re-touched working sets do hit in L2 --
+// so NT = fixed iterations and int16 only.
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ws_load16(const void* p)
+{
+  if constexpr (NT) {
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
 
 __device__ __forceinline__ s2 from_u(uint32_t u)
 {
@@ -236,11 +253,12 @@ __device__ __forceinline__ void tail_trellis(const short* xt, const short* yt, s
 // Blocked arrays hold, per 8-step block and lane, 8 dwords.  They are stored as two half-blocks of 4 dwords so
 // that each dwordx4 access of a wave covers one contiguous 1 KB (measured: 5.5 TB/s against 4.5 TB/s for a
 // 32-byte-per-lane layout where every 128-byte line is touched by two instructions).
+template <bool NT = false>
 __device__ __forceinline__ void load_block(const uint32_t* arr, uint32_t blk_lane, uint32_t (&r)[8])
 {
   const uint32_t blk = blk_lane >> 6, ln = blk_lane & 63u;
-  const uint4    a = *reinterpret_cast<const uint4*>(arr + ((size_t)(blk * 2) * 64 + ln) * 4);
-  const uint4    c = *reinterpret_cast<const uint4*>(arr + ((size_t)(blk * 2 + 1) * 64 + ln) * 4);
+  const uint4    a = ws_load16<NT>(arr + ((size_t)(blk * 2) * 64 + ln) * 4);
+  const uint4    c = ws_load16<NT>(arr + ((size_t)(blk * 2 + 1) * 64 + ln) * 4);
   r[0] = a.x;
   r[1] = a.y;
   r[2] = a.z;
@@ -307,10 +325,11 @@ __device__ __forceinline__ void load_rows(const uint32_t* arr, uint32_t b, int l
 // The same 8 rows fetched with TWO dwordx4 per lane (the 2 KB of rows 8b..8b+7 are contiguous): dword-per-lane
 // loads top out near 3 TB/s on this part, 16-byte ones reach 5.5 TB/s.  Lane L then holds columns 4(L%16)..+3
 // of rows L/16 and 4 + L/16; rows_to_lane() turns that into "8 rows of column L" through a 2 KB LDS image.
+template <bool NT = false>
 __device__ __forceinline__ void issue_rows(const uint32_t* arr, uint32_t b, int lane, uint32_t (&t)[8])
 {
   const uint4* q = reinterpret_cast<const uint4*>(arr + (size_t)(b * 8) * 64) + lane;
-  const uint4  a = q[0], c = q[64];
+  const uint4  a = ws_load16<NT>(q), c = ws_load16<NT>(q + 64);
   t[0] = a.x;
   t[1] = a.y;
   t[2] = a.z;
@@ -345,17 +364,17 @@ __device__ __forceinline__ uint32_t s8_pack2(uint32_t a, uint32_t b) { return __
 __device__ __forceinline__ uint16_t s8_pack1(uint32_t a) { return (uint16_t)__builtin_amdgcn_perm(0u, a, 0x0c0c0301u); }
 
 // raw (as stored) form of one 8-step block of a blocked array: 8 dwords, or 4 with 8-bit storage
-template <bool S8>
+template <bool S8, bool NT = false>
 __device__ __forceinline__ void load_block_raw(const uint32_t* arr, uint32_t blk_lane, uint32_t (&r)[8])
 {
   if constexpr (S8) {
-    const uint4 a = *reinterpret_cast<const uint4*>(arr + (size_t)blk_lane * 4);
+    const uint4 a = ws_load16<NT>(arr + (size_t)blk_lane * 4);
     r[0] = a.x;
     r[1] = a.y;
     r[2] = a.z;
     r[3] = a.w;
   } else {
-    load_block(arr, blk_lane, r);
+    load_block<NT>(arr, blk_lane, r);
   }
 }
 // raw -> the 8 int16x2 values of the block
@@ -378,17 +397,17 @@ __device__ __forceinline__ void store_block_v(uint32_t* arr, uint32_t blk_lane, 
   }
 }
 // the 8 rows of block b of a row array, as stored: two dwordx4 per lane, or one with 8-bit storage
-template <bool S8>
+template <bool S8, bool NT = false>
 __device__ __forceinline__ void issue_rows_raw(const uint32_t* arr, uint32_t b, int lane, uint32_t (&t)[8])
 {
   if constexpr (S8) {
-    const uint4 a = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(arr) + (size_t)(b * 8) * 64)[lane];
+    const uint4 a = ws_load16<NT>(reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(arr) + (size_t)(b * 8) * 64) + lane);
     t[0] = a.x;
     t[1] = a.y;
     t[2] = a.z;
     t[3] = a.w;
   } else {
-    issue_rows(arr, b, lane, t);
+    issue_rows<NT>(arr, b, lane, t);
   }
 }
 // ... turned into "8 rows of this lane's column" (int16x2 values) through the LDS stage
@@ -672,8 +691,9 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
 {
   const uint32_t crc_poly = ES ? p.crc_poly : 0u;
   const CbDesc*  desc     = ES ? p.desc : nullptr;
-  constexpr int NB  = 2 * LPC;
-  constexpr int CPW = 64 / LPC;
+  constexpr int  NB  = 2 * LPC;
+  constexpr int  CPW = 64 / LPC;
+  constexpr bool NT  = !ES && !AR::kIs8; // non-temporal workspace loads (see ws_load16)
   const int     pl   = lane % LPC;
   const int     cb_raw = (int)wb * CPW + lane / LPC;
   // Lane groups past the end of the batch stay in the wave: the exchanged rows are loaded 16 bytes per lane and
@@ -776,10 +796,10 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
       const bool wide = whole && ((bps & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0) && out_bytes == K / 8;
       uint32_t   w0 = 0, w1 = 0;
       uint32_t   t[8], tn[8];
-      issue_rows_raw<AR::kIs8>(D, 0, lane, t);
+      issue_rows_raw<AR::kIs8, NT>(D, 0, lane, t);
       for (uint32_t b = 0; b < nblk; b++) {
         if (b + 1 < nblk) {
-          issue_rows_raw<AR::kIs8>(D, (b + 1) & M_ROW, lane, tn);
+          issue_rows_raw<AR::kIs8, NT>(D, (b + 1) & M_ROW, lane, tn);
         }
         uint32_t r[8];
         rows_to_lane_v<AR::kIs8>(Tr, lane, t, r);
@@ -916,13 +936,13 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
     };
     auto issue = [&](uint32_t b, Ops& q) {
       if (dec1) {
-        load_block_raw<AR::kIs8>(S, (b & M_OWN) * 64 + lane, q.x);
+        load_block_raw<AR::kIs8, NT>(S, (b & M_OWN) * 64 + lane, q.x);
       } else {
-        issue_rows_raw<AR::kIs8>(A2, b & M_ROW, lane, q.x);
+        issue_rows_raw<AR::kIs8, NT>(A2, b & M_ROW, lane, q.x);
       }
-      load_block_raw<AR::kIs8>(Y, (b & M_OWN) * 64 + lane, q.y);
+      load_block_raw<AR::kIs8, NT>(Y, (b & M_OWN) * 64 + lane, q.y);
       if (has_app) {
-        issue_rows_raw<AR::kIs8>(A1, b & M_ROW, lane, q.a);
+        issue_rows_raw<AR::kIs8, NT>(A1, b & M_ROW, lane, q.a);
       }
     };
     auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
@@ -1072,7 +1092,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
     const bool last = (n + 1 == p.n_end) || crc_poly; // with early stop every half iteration may be the last
 
     uint32_t ck[8], tr[8], ckn[8], trn[8];
-    load_block_raw<AR::kIs8>(CK, (1u & M_OWN) * 64 + lane, ck);
+    load_block_raw<AR::kIs8, NT>(CK, (1u & M_OWN) * 64 + lane, ck);
     load_lut(lut, pl, tr);
     if (nblk > 1) {
       issue(1, nxt);
@@ -1084,7 +1104,7 @@ __device__ __forceinline__ void tdec_win_unit(const WinParams& p, const uint32_t
         issue(b + 2, nx2);
       }
       if (b + 1 < nblk) {
-        load_block_raw<AR::kIs8>(CK, ((b + 2) & M_OWN) * 64 + lane, ckn);
+        load_block_raw<AR::kIs8, NT>(CK, ((b + 2) & M_OWN) * 64 + lane, ckn);
         load_lut(lut, (b + 1) * LPC + pl, trn);
       }
       prep(cur, xs, ys, ap);

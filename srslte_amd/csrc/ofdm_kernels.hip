@@ -17,7 +17,7 @@ namespace ofdm {
 using namespace fft;
 
 // time samples are read exactly once: non-temporal loads keep them out of L2 (N = 2048: 0.369 -> 0.360 ms per 5040 subframes, A/B on one
-// box, tools/dbg/ab_ofdm.sh; non-temporal stores of the resource elements made no difference)
+// box with two builds selected through SRSRAN_HIP_LIB; non-temporal stores of the resource elements made no difference)
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 stream_load(const float2* p)
 {

@@ -39,7 +39,7 @@ def _run_threads(workers):
 
 @pytest.mark.parametrize("coalesce", [1, 0])
 def test_concurrent_handles_all_results_equal_the_oracle(hiplib, coalesce):
-    """12 threads at once: 5 turbo decoders (K = 6144 x3 incl. one 8-bit, 1024, 40), 4 OFDM objects (100 PRB rx x2, 6 PRB rx, 100 PRB tx),
+    """15 threads at once: 3 threads in the handle-less rate de-matcher / soft demodulator / descrambler, 5 turbo decoders (K = 6144 x3 incl. one 8-bit, 1024, 40), 4 OFDM objects (100 PRB rx x2, 6 PRB rx, 100 PRB tx),
     3 LDPC decoders (BG1 Z=384 x2, one of them with CRC early stop; BG2 Z=96); every thread makes `calls` calls on its own handle"""
     import srslte_amd as S
     from srslte_amd import capi
@@ -138,8 +138,40 @@ def test_concurrent_handles_all_results_equal_the_oracle(hiplib, coalesce):
         n_maybe[0] += calls
         return run
 
+    def stateless_worker(seed):
+        """the handle-less host-pointer functions (srsran_rm_turbo_rx_lut, srsran_demod_soft_demodulate_s, srsran_sequence_apply_s) keep a
+        staging context per calling thread behind two process-wide table caches: three threads use them at once"""
+        rng = np.random.default_rng(seed)
+        K, rv = (6144, 0) if seed % 2 else (1024, 2)
+        ci = O.tc_sizes().index(K)
+        nsb = lib.srsran_tdec_autoimp_get_subblocks(K)
+        E = 3 * K + 500 + seed
+        es = [rng.integers(-200, 200, E).astype(np.int16) for _ in range(calls)]
+        t = np.zeros(3 * K + 12, np.uint16)
+        assert lib.srsran_hip_rm_turbo_table(O.P(t), K, rv, nsb) == 0
+        L = 3000 + 7 * seed
+        syms = [O.qam_symbols(3, L, seed + i, snr_db=15.0) for i in range(calls)]
+        seq_seed = 12345 + seed
+
+        def run():
+            for i in range(calls):
+                soft = np.zeros(3 * (K + 32) + 12, np.int16)
+                assert lib.srsran_rm_turbo_rx_lut(O.P(es[i]), O.P(soft), E, ci, rv) == 0
+                ref = np.zeros_like(soft)
+                np.add.at(ref, t[np.arange(E) % t.size], es[i])  # out[T[i mod n_out]] += in[i] (rm_turbo.c:412-440); no wrap at these amplitudes
+                assert np.array_equal(soft, ref), ("rm", seed, i)
+                llr = np.zeros(6 * L, np.int16)
+                assert lib.srsran_demod_soft_demodulate_s(3, O.P(syms[i]), O.P(llr), L) == 0
+                assert np.array_equal(llr, O.demod_soft(3, syms[i], "s")), ("demod", seed, i)
+                out = np.zeros_like(llr)
+                lib.srsran_sequence_apply_s(O.P(llr), O.P(out), llr.size, seq_seed)
+                assert np.array_equal(out, O.sequence_apply(llr, seq_seed)), ("seq", seed, i)
+
+        return run
+
     workers += [tdec_worker(6144, False, 1, 8), tdec_worker(6144, False, 2, 8), tdec_worker(6144, True, 3, 8), tdec_worker(1024, False, 4, 5),
                 tdec_worker(40, False, 5, 8)]
+    workers += [stateless_worker(21), stateless_worker(22), stateless_worker(23)]
     workers += [ofdm_worker(100, 2048, False, 6), ofdm_worker(100, 2048, False, 7), ofdm_worker(6, 0, False, 8), ofdm_worker(100, 2048, True, 9)]
     workers += [ldpc_worker(0, 384, 10, False), ldpc_worker(0, 384, 11, True), ldpc_worker(1, 96, 12, False)]
     try:

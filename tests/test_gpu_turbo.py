@@ -116,6 +116,30 @@ def test_8bit_saturation_corner_cases(hiplib, K):
     dec.free()
 
 
+def test_8bit_every_block_size(hiplib):
+    """all 188 block sizes through the 8-bit API (avx8 / sse8 windows, or widened to the 16-bit window / scalar decoders): noisy code
+    words at an LLR scale that clips at +-127 most of the time, and inputs made of extremes only; hard bits and decision LLRs after
+    1, 2, 3 and 8 half iterations equal the oracle's"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    rng = np.random.default_rng(1)
+    bad = []
+    for K in O.tc_sizes():
+        n_cb = 3
+        _, noisy = O.turbo_llrs_8bit(K, n_cb, -2.0, seed=K, scale=70.0)
+        extreme = rng.choice(np.array([-128, -127, 127, 127, 0, 1, -1, 90, -90], np.int8), size=(n_cb, 3 * K + 12))
+        dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO, llr8=True)
+        for si, llr in enumerate((noisy, extreme)):
+            for nit in (1, 2, 3, 8):
+                ref, ref_llr = O.turbo_decode_8bit(llr, nit, K, O.ORC_TDEC_AUTO, 0, want_llr=True)
+                out, out_llr = dec.decode(llr, nit, 0, want_llr=True)
+                if not (np.array_equal(ref, out) and np.array_equal(ref_llr, out_llr)):
+                    bad.append((K, si, nit))
+        dec.free()
+    assert not bad, bad[:10]
+
+
 @pytest.mark.parametrize("impl,K", [("SSE8_WINDOW", 816), ("SSE8_WINDOW", 6144), ("AVX8_WINDOW", 1344), ("AVX8_WINDOW", 6144)])
 def test_8bit_manual_implementations(hiplib, impl, K):
     import srslte_amd as S

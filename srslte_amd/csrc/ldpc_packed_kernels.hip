@@ -8,9 +8,14 @@
 //     byte).  The circular shift of an edge sends the lane's pair (c, c + H) to (j, j + H mod Z) with j = (c + s) mod Z:
 //     that is the word j mod H, bytes in order when j < H and swapped otherwise -- the swap is folded into the byte
 //     selector of the v_perm_b32 that widens the two bytes to int16x2 (and narrows them again on the way back).
-//   * check-to-variable messages: one 16-bit word per (edge, lane) in the same per-slot slab as the plain kernel.
+//   * check-to-variable messages: one 16-bit word per (edge, lane) in the same per-slot slab as the plain kernel, accessed
+//     with buffer instructions (descriptor + lane offset + scalar edge offset).
+//   * stored bytes are BIASED by 128 (zero extension is then the widening; the biases cancel in s - c) and the reference's
+//     +-127 "infinity" is kept as +-64 in the soft words (what a saturating store produces by itself): layer_packed().
+//   * the base graph is read through the scalar cache (s_load): no vector instruction and no LDS traffic for it.
 //   * scaling x * (int)(sf * 100) / 100 (ldpc_dec_c.c:275-278) as (x * M) >> 9 on the packed 16-bit multiplier, with M
 //     checked on the host to give the same quotient for every x in 0..127 (otherwise the plain kernel runs).
+// 32 vector instructions per edge and pair of positions (round 1: 43; the steps are in DESIGN 3.3).
 // Everything else (layer pipeline, slabs, CRC early stop by the remainder of all K Z hard bits) follows ldpc_kernels.hip.
 #include "hip_common.h"
 #include "ldpc_device.h"
@@ -46,54 +51,68 @@ static __device__ __forceinline__ s2v clip(s2v x, short lim)
 {
   return pmin(pmax(x, splat2((short)-lim)), splat2(lim));
 }
+constexpr short kBias = 128; // stored bytes are value + 128 (layer_packed)
 // KEEP_A: keep the magnitudes in registers between the two passes (the early-stop instantiation recomputes them instead:
 // its extra state would push the 19-edge rows into scratch)
 template <int DEG, bool KEEP_A>
-__device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_t coff, int my_edge, int e0, int c, uint32_t Z, uint32_t H,
+__device__ __forceinline__ void layer_packed(const __attribute__((address_space(4))) int* ec, char* sbase, __amdgpu_buffer_rsrc_t c2v, uint32_t coff, int e0, int c, uint32_t Z, uint32_t H,
                                              unsigned short m9, bool active)
 {
   int ed[DEG];
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    ed[i] = __builtin_amdgcn_readlane(my_edge, i);
+    ed[i] = ec[e0 + i]; // scalar loads (the graph sits in the constant address space): no vector instruction, no LDS traffic
   }
   if (!active) {
     return;
   }
-  const uint32_t coffb = coff * 2u;        // this lane's byte offset inside an edge's run of messages (32-bit: scalar base + VGPR offset addressing)
+  const uint32_t coffb = coff * 2u;        // this lane's byte offset inside an edge's run of messages
   const uint32_t rowb  = (uint32_t)e0 * Z; // byte offset of this row's first edge (H words of 2 bytes per edge); wave-uniform
-  char*          cbase = reinterpret_cast<char*>(c2v);
+  // Check-to-variable words go through buffer instructions: slab descriptor + this lane's offset (VGPR) + the edge's offset (SGPR),
+  // so that no vector instruction is spent on their addresses.
+  // Both the soft words and the check-to-variable words are kept BIASED (value + 128 in each byte, see kBias): a byte then widens to
+  // its int16 half with the one v_perm_b32 that also sorts the halves (zero extension, no arithmetic shift), the biases cancel in
+  // s - c, and the bias of what is stored comes for free with the multiply-add that applies the sign.
   // (byte-wide d16 loads / stores of the two halves would save the widening and narrowing instructions below, but were
   // measured 28 % slower: the LDS and vector-memory pipes then take twice the instructions)
-  int  idx[DEG];  // LDS byte offset of the soft word holding the lane's pair
-  bool swp[DEG];  // ... byte-swapped in it (a lane mask in scalar registers)
+  const uint32_t cb = (uint32_t)(sbase - static_cast<char*>(nullptr)) + (uint32_t)c * 2u; // LDS byte address of (node 0, word c) of this lane's code word
+  uint32_t       c2 = (uint32_t)c * 2u, negZ = 0u - Z;
+  asm volatile("" : "+v"(c2), "+v"(negZ)); // (values of their own in VGPRs: the select below wants a register operand)
+  int  idx[DEG];  // LDS byte address of the soft word holding the lane's pair
+  uint32_t wsel[DEG]; // byte selector that narrows the lane's pair back into that word (swapped or not; kept per edge in a VGPR -- the
+                      // lane masks of 19 edges do not fit the scalar registers)
   s2v  s[DEG], co[DEG];
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    // lane pair (c, c + H) rotated by the shift: word (c + shift) mod H, bytes swapped when floor((c + shift) / H) is odd
-    const uint32_t sh = (uint32_t)ed[i] >> 16;            // scalar, < Z
-    const bool     sq = sh >= H;                          // scalar
-    const uint32_t a  = (uint32_t)c + (sq ? sh - H : sh); // < 2 H
-    const uint32_t dw = min(a, a - H);                    // mod H: the wrapped difference is huge when a < H
-    swp[i]            = sq ? (dw == a) : (dw != a);
-    idx[i]            = (int)(((uint32_t)ed[i] & 0xffffu) + dw * 2u); // node * Z + 2 dw
-    const uint32_t sw = *reinterpret_cast<const uint16_t*>(sbase + idx[i]);
-    const uint32_t cw = *reinterpret_cast<const uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb));
-    // bytes 0 / 1 to the halves of the lane's pair, sign-extended (swapped pairs: byte 1 is the low half)
-    s[i]  = as_s2(__builtin_amdgcn_perm(0u, sw, swp[i] ? 0x000c010cu : 0x010c000cu)) >> 8;
-    co[i] = as_s2(__builtin_amdgcn_perm(0u, cw, 0x010c000cu)) >> 8;
+    // lane pair (c, c + H) rotated by the shift: word (c + shift) mod H, bytes swapped when floor((c + shift) / H) is odd.
+    // Three vector instructions: does 2 c reach the (scalar) wrap point, select 0 / -Z, three-operand add.
+    const uint32_t sh   = (uint32_t)ed[i] >> 16;                  // scalar, < Z
+    const bool     sq   = sh >= H;                                // scalar
+    const uint32_t sh2  = 2u * (sq ? sh - H : sh);                // scalar: byte offset of the rotation inside the row, < Z
+    const bool     wrap = c2 >= Z - sh2;
+    const bool swp      = sq != wrap;
+    wsel[i]             = swp ? 0x0c0c0002u : 0x0c0c0200u;
+    idx[i]              = (int)(cb + (wrap ? negZ : 0u) + (((uint32_t)ed[i] & 0xffffu) + sh2));
+    const uint32_t sw   = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>((uintptr_t)idx[i]);
+    const uint32_t cw   = __builtin_amdgcn_raw_buffer_load_b16(c2v, coffb, rowb + (uint32_t)i * Z, 0);
+    // bytes 0 / 1 to the halves of the lane's pair, zero-extended (swapped pairs: byte 1 is the low half)
+    s[i]  = as_s2(__builtin_amdgcn_perm(0u, sw, swp ? 0x0c000c01u : 0x0c010c00u));
+    co[i] = as_s2(__builtin_amdgcn_perm(0u, cw, 0x0c010c00u));
   }
-  s2v      x[DEG], a[KEEP_A ? DEG : 1];
-  s2v      min0 = splat2(127), min1 = splat2(127);
-  uint32_t sgn  = 0;
+  short k64s = 64;
+  asm volatile("" : "+s"(k64s));
+  const s2v k64 = splat2(k64s);
+  s2v       x[DEG], a[KEEP_A ? DEG : 1];
+  s2v       min0 = splat2(127), min1 = splat2(127);
+  uint32_t  sgn  = 0;
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
-    // ldpc_dec_c.c:338-363: +-127 passes as infinity, everything else is clip(s - c, +-63).  Soft words only hold -63..63
-    // and +-127 (the kernel normalises the channel LLRs when it loads them), so h = s - clip(s) is +-64 for the
-    // infinite values and 0 otherwise; pushing s - c out by 3 h makes the clip produce +-63, h completes it to +-127.
-    const s2v h  = s[i] - clip(s[i], 63);
-    const s2v t  = (s[i] - co[i]) + h * splat2(3); // (3, not a power of two: one v_pk_mad_i16 instead of a shift and an add)
-    const s2v xv = clip(t, 63) + h;
+    // ldpc_dec_c.c:338-363: +-127 passes as infinity, everything else is clip(s - c, +-63).  Soft words hold -63..63, and +-64
+    // for the reference's +-127 (see the store below), so h = s - clip(s) is +-1 for the infinite values and 0 otherwise;
+    // pushing s - c out by 129 h makes the clip produce +-63, 64 h completes it to +-127.
+    const s2v h  = s[i] - pmin(pmax(s[i], splat2(kBias - 63)), splat2(kBias + 63));
+    const s2v t  = (s[i] - co[i]) + h * splat2(129);
+    const s2v xv = clip(t, 63) + h * k64; // (k64 is opaque: one v_pk_mad_u16 instead of a shift and an add)
     x[i]         = xv;
     const s2v av = pmax(xv, splat2(0) - xv);
     if (KEEP_A) {
@@ -110,18 +129,20 @@ __device__ __forceinline__ void layer_packed(char* sbase, uint16_t* c2v, uint32_
   // the edge(s) holding the minimum get the second minimum (equal magnitudes: both are the same number):
   // max(s0, s1 - 129 (a - min0)) is s1 where a == min0 and s0 (>= 0 > s1 - 129) elsewhere
   const s2v c1 = s1 + min0 * splat2(129);
+  short kbs = kBias;
+  asm volatile("" : "+s"(kbs));
+  const s2v kb = splat2(kbs);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     const s2v av  = KEEP_A ? a[i] : pmax(x[i], splat2(0) - x[i]);
     const s2v mag = pmax(s0, c1 - av * splat2(129)); // 129: a multiply-add, and 129 * 127 + 127 still fits 16 bits
-    const s2v m   = as_s2(sgn ^ as_u32(x[i])) >> 15; // all ones where the product of the OTHER signs is negative
-    const s2v cn  = (mag ^ m) - m;
-    *reinterpret_cast<uint16_t*>(cbase + (rowb + (uint32_t)i * Z + coffb)) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cn), 0x0c0c0200u);
-    // :308-315: t > 63 -> 127, t < -63 -> -127.  u = clip(t, 64) reaches +-64 exactly when t is out of range, and then
-    // u - clip(u, 63) = +-1 (written with a multiplication so that it is not expanded into compares as a signum)
-    const s2v u   = clip(cn + x[i], 64);
-    const s2v res = u + (u - clip(u, 63)) * splat2(63);
-    *reinterpret_cast<uint16_t*>(sbase + idx[i]) = (uint16_t)__builtin_amdgcn_perm(0u, as_u32(res), swp[i] ? 0x0c0c0002u : 0x0c0c0200u);
+    const s2v sg  = (as_s2(sgn ^ as_u32(x[i])) >> 15) | splat2(1); // -1 where the product of the OTHER signs is negative, else 1
+    const s2v cnb = mag * sg + kb;                                 // the new message, biased
+    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)__builtin_amdgcn_perm(0u, as_u32(cnb), 0x0c0c0200u), c2v, coffb, rowb + (uint32_t)i * Z, 0);
+    // :308-315: t > 63 -> 127, t < -63 -> -127, kept in the soft words as +-64 (only this kernel reads them, and only their sign leaves it)
+    const s2v res = pmin(pmax(cnb + x[i], splat2(kBias - 64)), splat2(kBias + 64));
+    *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)idx[i]) =
+        (uint16_t)__builtin_amdgcn_perm(0u, as_u32(res), wsel[i]);
   }
 }
 
@@ -129,7 +150,7 @@ static size_t lds_bytes_packed(const Params& p)
 {
   const size_t per_cw = (size_t)p.bgN * (p.Z / 2) * 2;
   const size_t red    = p.crc_order ? (p.cpb == 1 ? (size_t)16 : (size_t)((p.cpb * (p.Z / 2) + 63) / 64) * 64 + 8) : 0;
-  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (48 + (size_t)p.n_edges + red) * sizeof(int);
+  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + red * sizeof(int);
 }
 
 template <bool ES>
@@ -146,12 +167,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   uint16_t*      soft2  = reinterpret_cast<uint16_t*>(sbase);
   uint16_t*      c2v    = reinterpret_cast<uint16_t*>(p.c2v_ws) + (size_t)blockIdx.x * p.cpb * p.n_edges * H; // wave-uniform slab base
   const uint32_t coff   = (uint32_t)(cwl < p.cpb ? cwl : 0) * (uint32_t)p.n_edges * H + (uint32_t)c;
-  int* graph = reinterpret_cast<int*>(lds + (((size_t)p.cpb * per_cw + 15) & ~(size_t)15));
-  for (int i = t; i < 48 + p.n_edges; i += blockDim.x) {
-    graph[i] = i < 48 ? (i <= p.n_layers ? p.row_start[i] : 0) : p.edges[i - 48];
-  }
-  const int* row_start = graph;
-  const int* edges     = graph + 48;
+  // raw buffer over this workgroup's slab (gfx9 descriptor word 3: 32-bit data format); accesses beyond it are dropped by the hardware
+  const __amdgpu_buffer_rsrc_t c2v_rsrc = __builtin_amdgcn_make_buffer_rsrc(c2v, 0, (int)((uint32_t)p.cpb * (uint32_t)p.n_edges * Z), 0x00020000);
+  // base graph: row starts and edge words come through the scalar cache
+  typedef const __attribute__((address_space(4))) int* cint_p;
+  const cint_p ec = (cint_p)p.edges, row_start = (cint_p)p.row_start;
   const unsigned short m9 = (unsigned short)p.sf_m9;
 
   for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
@@ -165,39 +185,35 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // init_ldpc_dec_c (ldpc_dec_c.c:170-188)
     if (active) {
       const int8_t* llr = reinterpret_cast<const int8_t*>(p.llrs) + (size_t)cwi * p.llr_stride;
-      soft2[c]     = 0;
-      soft2[H + c] = 0;
+      soft2[c]     = (uint16_t)(kBias | (kBias << 8));
+      soft2[H + c] = (uint16_t)(kBias | (kBias << 8));
       for (int n = 2; n < p.bgN; n++) {
-        // values the first variable-to-check pass treats alike are stored alike: |llr| >= 127 is infinity (+-127), anything
+        // values the first variable-to-check pass treats alike are stored alike: |llr| >= 127 is infinity (kept as +-64), anything
         // else enters as clip(llr, +-63) (its check-to-variable messages are still zero then, ldpc_dec_c.c:345-353)
-        auto norm = [](int v) { return v >= 127 ? 127 : (v <= -127 ? -127 : (v > 63 ? 63 : (v < -63 ? -63 : v))); };
-        const uint32_t lo = (uint8_t)norm(llr[(n - 2) * Z + c]), hi = (uint8_t)norm(llr[(n - 2) * Z + H + c]);
+        auto norm = [](int v) { return v >= 127 ? 64 : (v <= -127 ? -64 : (v > 63 ? 63 : (v < -63 ? -63 : v))); };
+        const uint32_t lo = (uint32_t)(norm(llr[(n - 2) * Z + c]) + kBias), hi = (uint32_t)(norm(llr[(n - 2) * Z + H + c]) + kBias);
         soft2[n * H + c] = (uint16_t)(lo | (hi << 8));
       }
       for (int e = 0; e < p.n_edges; e++) {
-        c2v[(uint32_t)e * H + coff] = 0;
+        c2v[(uint32_t)e * H + coff] = (uint16_t)(kBias | (kBias << 8));
       }
     }
     __syncthreads();
 
-    const int lane = t & 63;
-    int       e0n  = __builtin_amdgcn_readfirstlane(row_start[0]);
-    int       degn = __builtin_amdgcn_readfirstlane(row_start[1]) - e0n;
-    int       edgn = edges[e0n + (lane < degn ? lane : 0)];
+    int e0n = row_start[0], e1n = row_start[1];
     for (int it = 0; it < p.max_iter; it++) {
       for (int l = 0; l < p.n_layers; l++) {
-        const int e0 = e0n, deg = degn, my_edge = edgn;
+        const int e0 = e0n, deg = e1n - e0n;
         {
-          const int ln = l + 1 < p.n_layers ? l + 1 : 0;
-          e0n          = __builtin_amdgcn_readfirstlane(row_start[ln]);
-          degn         = __builtin_amdgcn_readfirstlane(row_start[ln + 1]) - e0n;
-          edgn         = edges[e0n + (lane < degn ? lane : 0)];
+          const int ln = l + 1 < p.n_layers ? l + 1 : 0; // fetched one row ahead: the edge words' addresses depend on it
+          e0n          = row_start[ln];
+          e1n          = row_start[ln + 1];
         }
 
         switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer_packed<D, !ES>(sbase, c2v, coff, my_edge, e0, c, Z, H, m9, active);                                               \
+    layer_packed<D, !ES>(ec, sbase, c2v_rsrc, coff, e0, c, Z, H, m9, active);                                               \
     break;
           LDPC_CASE(1)
           LDPC_CASE(2)
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       if (ES && p.crc_order) {
         // remainder of all liftK hard decisions (ldpc_decoder.c:87-99, crc.c:187-193): every lane takes 2 bgK consecutive
         // bits of the message, shifts its partial remainder into place with x^(bits behind it) mod g
-        uint32_t*      red   = reinterpret_cast<uint32_t*>(graph + 48 + p.n_edges);
+        uint32_t*      red   = reinterpret_cast<uint32_t*>(lds + (((size_t)p.cpb * per_cw + 15) & ~(size_t)15));
         const uint32_t order = (uint32_t)p.crc_order, mask = order == 32 ? 0xffffffffu : ((1u << order) - 1u), poly = p.crc_poly & mask;
         uint32_t       r     = 0;
         if (active) {
@@ -227,8 +243,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
           uint32_t col = i0 / Z, pos = i0 - col * Z;
           for (int k = 0; k < 2 * p.bgK; k++) {
             const uint32_t half = pos >= H ? 1u : 0u;
-            const int8_t   v    = reinterpret_cast<const int8_t*>(sbase)[(col * H + pos - half * H) * 2 + half];
-            const uint32_t bit  = v < 0 ? 1u : 0u;
+            const uint8_t  v    = reinterpret_cast<const uint8_t*>(sbase)[(col * H + pos - half * H) * 2 + half];
+            const uint32_t bit  = v < kBias ? 1u : 0u;
             r = ((r << 1) & mask) ^ ((((r >> (order - 1)) ^ bit) & 1u) ? poly : 0u);
             if (++pos == Z) {
               pos = 0;
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       uint32_t col = 0, pos = (uint32_t)c;
       for (int i = c; i < liftK; i += (int)H) {
         const uint32_t half = pos >= H ? 1u : 0u;
-        m[i] = reinterpret_cast<const int8_t*>(sbase)[(col * H + pos - half * H) * 2 + half] < 0;
+        m[i] = reinterpret_cast<const uint8_t*>(sbase)[(col * H + pos - half * H) * 2 + half] < kBias;
         pos += H;
         if (pos >= Z) {
           pos -= Z;

@@ -24,6 +24,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-Wno-unused-value", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+# per-source flags.  pss_wave_kernels: the register FFT is written with scalar f32 on purpose (on gfx950 v_pk_*_f32 has the same peak as
+# v_fma_f32 and costs a lone wave ~5x the issue cycles); keep the SLP vectoriser and vector-combine from packing it again.
+EXTRA_FLAGS = {"pss_wave_kernels.hip": ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]}
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -43,7 +48,7 @@ def build(force=False, verbose=True, jobs=8):
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1,0 +1,373 @@
+// pss_wave_kernels.hip -- PSS correlation (pss.c:446-534, convolution.c:113-120), one WAVE per overlap-save block.
+//
+// Same arithmetic plan as pss_block_kernel (sync_kernels.hip): 4096-point overlap-save blocks, the block is transformed
+// once, multiplied by the cached spectrum of each N_id_2 replica, transformed back, |.|^2 (+ the moving average of
+// pss.c:496-503), block arg-max.  What differs is where the transform lives:
+//   * 4096 = 64 x 64.  Lane l of ONE wave holds the 64 points n = l + 64 r in registers and runs a complete 64-point
+//     FFT on them without talking to anybody (8 x 8, all indices and inner twiddles compile-time constants); one
+//     multiplication by W_4096^(l k), ONE 64 x 64 transposition through LDS (wave-private: no barrier, 65-element rows:
+//     no bank conflict), and a second register FFT gives X[l + 64 k] -- the layout the block was loaded in.  A 4096-point
+//     transform therefore costs one LDS round trip instead of the two workgroup-wide exchanges + barriers of the
+//     three-pass radix-16 engine, and nothing waits for another wave.
+//   * complex numbers are register PAIRS and everything runs on the packed fp32 pipe (v_pk_add/mul/fma_f32): a complex
+//     addition is one instruction, a multiplication by +-i rides in the operand selectors of the addition that consumes
+//     it, a complex multiplication is two instructions.
+//   * the spectrum of the block (64 complex per lane) is kept for the three hypotheses; with the working set of the
+//     transform that is more than 256 registers, so the kernel runs ONE wave per SIMD with the 512-register budget of
+//     gfx950 (the compiler parks what is not in use in the accumulation registers).  One wave per SIMD is enough here:
+//     the instruction stream is ~7,000 packed VALU instructions per block with 64-fold instruction-level parallelism,
+//     and the only memory waits are the block load, the filter spectra (L2-resident) and four LDS transpositions.
+#include "hip_common.h"
+#include "sync_device.h"
+
+#include <type_traits>
+
+namespace phyhip {
+namespace sync {
+
+// Complex numbers are pairs of plain f32 registers and the arithmetic is v_add / v_mul / v_fma_f32: on gfx950 the packed-f32 forms
+// (v_pk_add/mul/fma_f32) have the same peak (64 flop per clock and SIMD) and cost a lone wave ~20 cycles of issue each -- measured here:
+// the packed version of this kernel took 23 cycles per vector instruction, 2.9 ms per 256 captures.
+struct cx {
+  float x, y;
+};
+static __device__ __forceinline__ cx operator+(cx a, cx b) { return {a.x + b.x, a.y + b.y}; }
+static __device__ __forceinline__ cx operator-(cx a, cx b) { return {a.x - b.x, a.y - b.y}; }
+// a + w b and a - w b for w = -i (forward transform) or +i (inverse): the rotation is a renaming of registers
+template <bool INV>
+static __device__ __forceinline__ cx add_rot(cx a, cx b)
+{
+  return INV ? cx{a.x - b.y, a.y + b.x} : cx{a.x + b.y, a.y - b.x};
+}
+template <bool INV>
+static __device__ __forceinline__ cx sub_rot(cx a, cx b)
+{
+  return INV ? cx{a.x + b.y, a.y - b.x} : cx{a.x - b.y, a.y + b.x};
+}
+// z * w (CONJ: z * conj(w)): two multiplications, two fused multiply-adds
+template <bool CONJ>
+static __device__ __forceinline__ cx cmul2(cx z, cx w)
+{
+  const float wy = CONJ ? -w.y : w.y;
+  return {__builtin_fmaf(-z.y, wy, z.x * w.x), __builtin_fmaf(z.x, wy, z.y * w.x)};
+}
+
+// 8-point transform in place, natural order in and out
+template <bool INV>
+static __device__ __forceinline__ void fft8(cx (&x)[8])
+{
+  constexpr float c = 0.70710678118654752440f;
+  const cx a0 = x[0] + x[4], a1 = x[0] - x[4], a2 = x[2] + x[6], a3 = x[2] - x[6];
+  const cx a4 = x[1] + x[5], a5 = x[1] - x[5], a6 = x[3] + x[7], a7 = x[3] - x[7];
+  const cx b0 = a0 + a2, b2 = a0 - a2, b1 = add_rot<INV>(a1, a3), b3 = sub_rot<INV>(a1, a3);
+  const cx b4 = a4 + a6, b6 = a4 - a6, b5 = add_rot<INV>(a5, a7), b7 = sub_rot<INV>(a5, a7);
+  // W8 b5 = c (b5 + rot b5), W8^3 b7 = -c (b7 - rot b7) with rot = -i (forward) / +i (inverse)
+  const cx r5 = add_rot<INV>(b5, b5), r7 = sub_rot<INV>(b7, b7);
+  const cx t5 = {c * r5.x, c * r5.y}, t7 = {-c * r7.x, -c * r7.y};
+  x[0] = b0 + b4;
+  x[4] = b0 - b4;
+  x[2] = add_rot<INV>(b2, b6);
+  x[6] = sub_rot<INV>(b2, b6);
+  x[1] = b1 + t5;
+  x[5] = b1 - t5;
+  x[3] = b3 + t7;
+  x[7] = b3 - t7;
+}
+
+// e^{-+ 2 pi i J / 64} (forward: minus) as a compile-time constant
+template <int J, bool INV>
+static __device__ __forceinline__ cx w64()
+{
+  // cos(2 pi j / 64), j = 0 ... 16
+  constexpr float C[17] = {1.0f,
+                           0.99518472667219688624f,
+                           0.98078528040323044913f,
+                           0.95694033573220886494f,
+                           0.92387953251128675613f,
+                           0.88192126434835502971f,
+                           0.83146961230254523708f,
+                           0.77301045336273696081f,
+                           0.70710678118654752440f,
+                           0.63439328416364549822f,
+                           0.55557023301960222474f,
+                           0.47139673682599764856f,
+                           0.38268343236508977173f,
+                           0.29028467725446236764f,
+                           0.19509032201612826785f,
+                           0.09801714032956060199f,
+                           0.0f};
+  constexpr int   q  = (J & 63) >> 4, r = J & 15;
+  constexpr float co = q == 0 ? C[r] : (q == 1 ? -C[16 - r] : (q == 2 ? -C[r] : C[16 - r]));
+  constexpr float si = q == 0 ? C[16 - r] : (q == 1 ? C[r] : (q == 2 ? -C[16 - r] : -C[r]));
+  return {co, INV ? si : -si};
+}
+
+template <int N2, int K1, bool INV>
+static __device__ __forceinline__ cx inner_twiddle(cx z)
+{
+  constexpr int j = (N2 * K1) & 63;
+  if constexpr (j == 0) {
+    return z;
+  } else if constexpr (j == 16) {
+    return add_rot<INV>(cx{0.f, 0.f}, z);
+  } else {
+    return cmul2<false>(z, w64<j, INV>());
+  }
+}
+
+template <int N2, bool INV>
+static __device__ __forceinline__ void fft64_column(cx (&a)[64])
+{
+  cx t[8];
+#pragma unroll
+  for (int n1 = 0; n1 < 8; n1++) {
+    t[n1] = a[8 * n1 + N2];
+  }
+  fft8<INV>(t);
+  a[8 * 0 + N2] = inner_twiddle<N2, 0, INV>(t[0]);
+  a[8 * 1 + N2] = inner_twiddle<N2, 1, INV>(t[1]);
+  a[8 * 2 + N2] = inner_twiddle<N2, 2, INV>(t[2]);
+  a[8 * 3 + N2] = inner_twiddle<N2, 3, INV>(t[3]);
+  a[8 * 4 + N2] = inner_twiddle<N2, 4, INV>(t[4]);
+  a[8 * 5 + N2] = inner_twiddle<N2, 5, INV>(t[5]);
+  a[8 * 6 + N2] = inner_twiddle<N2, 6, INV>(t[6]);
+  a[8 * 7 + N2] = inner_twiddle<N2, 7, INV>(t[7]);
+  __builtin_amdgcn_sched_barrier(0); // one 8-point transform at a time: 64 of them in flight is what the scheduler would like, and 512 registers are not enough for that
+}
+
+// 64-point transform of the lane's own 64 registers, natural order in and out (8 x 8)
+template <bool INV>
+static __device__ __forceinline__ void fft64(cx (&a)[64])
+{
+  fft64_column<0, INV>(a);
+  fft64_column<1, INV>(a);
+  fft64_column<2, INV>(a);
+  fft64_column<3, INV>(a);
+  fft64_column<4, INV>(a);
+  fft64_column<5, INV>(a);
+  fft64_column<6, INV>(a);
+  fft64_column<7, INV>(a);
+  cx o[64];
+#pragma unroll
+  for (int k1 = 0; k1 < 8; k1++) {
+    cx t[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; n2++) {
+      t[n2] = a[8 * k1 + n2];
+    }
+    fft8<INV>(t);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+      o[k1 + 8 * k2] = t[k2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    a[i] = o[i];
+  }
+}
+
+// 4096-point transform of one wave: v[r] of lane l = element l + 64 r, in and out.  T1[b] = W^(l b), T2[a] = W^(8 l a),
+// W = e^{-2 pi i / 4096}; `img` = the wave's 64 x 65 LDS image of floats: real and imaginary parts cross it one after the other
+// (16.6 KB per wave, so that eight waves fit a CU; LDS operations of one wave execute in order, no barrier is involved).
+template <bool INV>
+static __device__ __forceinline__ void fft4096_first(cx (&v)[64], const cx (&T1)[8], const cx (&T2)[8], float* img, int lane) // ... up to the transposition
+{
+  fft64<INV>(v);
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    if (k != 0) {
+      const cx w = (k & 7) == 0 ? T2[k >> 3] : ((k >> 3) == 0 ? T1[k & 7] : cmul2<false>(T2[k >> 3], T1[k & 7]));
+      v[k]       = cmul2<INV>(v[k], w);
+    }
+    img[k * 65 + lane] = v[k].x;
+    if ((k & 7) == 7) {
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 64; n++) {
+    v[n].x = img[lane * 65 + n];
+  }
+  __builtin_amdgcn_sched_barrier(0); // (the LDS operations of a wave execute in issue order: every read above precedes every write below)
+#pragma unroll
+  for (int k = 0; k < 64; k++) {
+    img[k * 65 + lane] = v[k].y;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < 64; n++) {
+    v[n].y = img[lane * 65 + n];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <bool INV>
+static __device__ __forceinline__ void fft4096(cx (&v)[64], const cx (&T1)[8], const cx (&T2)[8], float* img, int lane)
+{
+  fft4096_first<INV>(v, T1, T2, img, lane);
+  fft64<INV>(v);
+}
+
+// One wave per overlap-save block and TWO waves per SIMD: a lone wave issues one vector instruction every four cycles, half of what
+// the SIMD takes, and stands still through every memory wait.  Two need <= 256 registers each, which leaves no room for the
+// block's spectrum next to the transform's working set -- it waits in global memory (see below).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pss_wave_kernel(const PssParams p)
+{
+  __shared__ float img[64 * 65];
+  const int        cap = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
+  const cx*        x   = reinterpret_cast<const cx*>(p.in) + (size_t)cap * p.in_stride;
+  const cx*        tw  = reinterpret_cast<const cx*>(p.twiddle);
+
+  cx T1[8], T2[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    T1[j] = tw[lane * j];
+    T2[j] = tw[lane * 8 * j];
+  }
+
+  const int i0  = blk * p.hop;           // first convolution output of this block
+  const int off = i0 - (p.fft_size - 1); // capture index of segment element 0
+  // the capture as a raw buffer: elements before its start (negative offsets wrap to huge ones) and behind its end read as zero,
+  // which is the zero padding of the convolution -- no compare, no branch
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<cx*>(x), 0, p.frame_size * 8, 0x00020000);
+
+  const int m_lo = p.fft_size - 1, m_hi = p.fft_size - 1 + p.hop;
+  bool      have_spec = false;
+  for (int h = 0; h < 3; h++) {
+    if (!(p.n_id_2_mask & (1 << h))) {
+      continue;
+    }
+    // Nothing below may look loop-invariant: hoisted out of the hypothesis loop, the 64 twiddle products, the 64 output offsets and
+    // the 64 row predicates are several hundred registers that stay live across the whole loop.  Passing the lane index, the twiddle
+    // tables and the bounds through an empty asm makes them values of this iteration.
+    int lane_h = lane, m_lo_h = m_lo;
+    asm volatile("" : "+v"(lane_h), "+s"(m_lo_h));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      asm volatile("" : "+v"(T1[j].x), "+v"(T1[j].y), "+v"(T2[j].x), "+v"(T2[j].y)); // (in place: no second copy of the tables)
+    }
+    cx        v[64];
+    const cx* filt = reinterpret_cast<const cx*>(p.filt) + (size_t)h * 4096 + lane_h;
+    cx        f[16];
+    // The filter spectrum of a hypothesis comes in batches of 16 values.  (Fenced: short of registers, the compiler otherwise issues one
+    // load, waits for it, uses it -- 64 L2 round trips in a row per hypothesis: 1.3 of 2.8 ms per 256 captures.)
+    cx* spec = reinterpret_cast<cx*>(p.spec) + ((size_t)cap * p.n_blocks + blk) * 4096 + lane_h;
+    if (!have_spec) {
+#pragma unroll
+      for (int r = 0; r < 64; r++) {
+        v[r] = __builtin_bit_cast(cx, __builtin_amdgcn_raw_buffer_load_b64(xb, (off + lane_h + 64 * r) * 8, 0, 0));
+      }
+      fft4096_first<false>(v, T1, T2, img, lane_h);
+      // the first batch is requested before the second half of the forward transform and arrives under it
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        f[j] = filt[64 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      fft64<false>(v);
+      __builtin_amdgcn_sched_barrier(0);
+      // The spectrum of the block serves every hypothesis, but two waves per SIMD have no registers to keep it (and one wave per SIMD
+      // issues at half rate): it is parked in the block's 32 KB of the spectrum area and comes back from L2 / the Infinity Cache in
+      // place of the block itself -- the same 64 loads the forward transform would start with, and no second and third transform.
+      // (Requesting it row by row while the previous hypothesis is post-processed, into the registers that become free, was built too:
+      // the values carried around the loop cost 100 spilled registers and the kernel took 2.3 instead of 1.4 ms.)
+      if ((p.n_id_2_mask >> (h + 1)) != 0) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+          spec[64 * r] = v[r];
+        }
+      }
+      have_spec = true;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 64; r++) {
+        v[r] = spec[64 * r];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        f[j] = filt[64 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        v[16 * g + j] = cmul2<false>(v[16 * g + j], f[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g < 3) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          f[j] = filt[64 * (16 * (g + 1) + j)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (the inverse transform wants the same 64 twiddle products as the forward one: common-subexpression elimination would keep all
+    // of them alive in between -- 128 registers; the tables go through the empty asm again instead)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      asm volatile("" : "+v"(T1[j].x), "+v"(T1[j].y), "+v"(T2[j].x), "+v"(T2[j].y));
+    }
+    fft4096<true>(v, T1, T2, img, lane_h);
+
+    // the correlation row as a raw buffer of n_out floats: lanes outside the block's share get an offset beyond it, and the
+    // hardware drops their stores (and returns zero for their loads)
+    const __amdgpu_buffer_rsrc_t cb =
+        __builtin_amdgcn_make_buffer_rsrc(p.corr + ((size_t)cap * 3 + h) * p.corr_stride, 0, p.n_out * 4, 0x00020000);
+    float best  = -1.0f;
+    int   besti = 0x7fffffff;
+    auto  post  = [&](auto ema_tag) {
+      constexpr bool EMA = decltype(ema_tag)::value;
+#pragma unroll
+      for (int r = 0; r < 64; r++) {
+        if (64 * r + 63 < m_lo_h) { // wave-uniform: the whole register row lies in the discarded head of the block
+          continue;
+        }
+        const int  m = lane_h + 64 * r, i = off + m;
+        const bool ok = m >= m_lo_h && m < m_hi && i < p.n_out;
+        const int  bo = ok ? i * 4 : -1;
+        float      pw = v[r].x * v[r].x + v[r].y * v[r].y; // srsran_vec_abs_square_cf
+        if (EMA) {
+          const float old = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cb, bo, 0, 0));
+          pw              = pw * p.ema_alpha + old * (1.0f - p.ema_alpha); // pss.c:497-500
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pw), cb, bo, 0, 0);
+        const bool gt = ok && pw > best; // i grows with r: the first maximum of the lane stays
+        best          = gt ? pw : best;
+        besti         = gt ? i : besti;
+      }
+    };
+    if (p.ema_alpha > 0.0f && p.ema_alpha < 1.0f) {
+      post(std::true_type{});
+    } else {
+      post(std::false_type{});
+    }
+    // block arg-max (first maximum wins on ties, as srsran_vec_max_fi)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob  = __shfl_down(best, o);
+      const int   obi = __shfl_down(besti, o);
+      if (ob > best || (ob == best && obi < besti)) {
+        best  = ob;
+        besti = obi;
+      }
+    }
+    if (lane == 0) {
+      const size_t o = ((size_t)cap * 3 + h) * p.n_blocks + blk;
+      p.part_val[o]  = best;
+      p.part_idx[o]  = besti;
+    }
+  }
+}
+
+hipError_t launch_pss_wave_blocks(const PssParams& p, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pss_wave_kernel, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+} // namespace sync
+} // namespace phyhip

@@ -27,6 +27,7 @@ struct PssParams {
   float*      corr;    // n_cap x 3 x corr_stride floats: |conv|^2 (moving average), zero beyond n_out
   float*      part_val; // n_cap x 3 x n_blocks
   int*        part_idx;
+  void*       spec;     // n_cap x n_blocks x 4096 cf: spectrum of every block between its hypotheses (pss_wave_kernel)
   size_t      in_stride;
   size_t      corr_stride;
   int         n_cap;
@@ -94,6 +95,7 @@ hipError_t launch_decim(const void* in, void* out, int n_out, int M, const float
 
 hipError_t launch_pack(const PssResult* a, const SssResult* b, CellResult* out, int n, hipStream_t stream);
 hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream);
+hipError_t launch_pss_wave_blocks(const PssParams& p, hipStream_t stream); // pss_wave_kernels.hip: corr / part_val / part_idx of every block
 hipError_t launch_sss(const SssParams& p, const PssResult* d_pss, SssResult* d_res, hipStream_t stream);
 hipError_t launch_pss_direct(const PssParams& p, const void* d_replica, PssResult* d_res, hipStream_t stream);
 

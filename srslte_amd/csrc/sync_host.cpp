@@ -145,6 +145,7 @@ struct PssEngine {
   float*   d_corr = nullptr;
   float*   d_part_val = nullptr;
   int*     d_part_idx = nullptr;
+  float2*  d_spec = nullptr; // block spectra between the hypotheses of a launch (32 KB per block and capture)
   sync::PssResult* d_res = nullptr;
   cf_t     freq[3][SRSRAN_PSS_LEN];
   std::vector<cf_t> time[3];
@@ -161,6 +162,7 @@ void pss_engine_free(PssEngine* e)
   (void)hipFree(e->d_corr);
   (void)hipFree(e->d_part_val);
   (void)hipFree(e->d_part_idx);
+  (void)hipFree(e->d_spec);
   (void)hipFree(e->d_res);
   delete e;
 }
@@ -235,6 +237,7 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
             hipMalloc(&e->d_corr, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_val, (size_t)max_caps * 3 * e->n_blocks * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_idx, (size_t)max_caps * 3 * e->n_blocks * sizeof(int)) == hipSuccess &&
+            hipMalloc(&e->d_spec, (size_t)max_caps * e->n_blocks * e->block_n * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_res, (size_t)max_caps * 3 * sizeof(sync::PssResult)) == hipSuccess &&
             hipMemcpy(e->d_tw, tw.data(), (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(e->d_filt, filt.data(), 3 * (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
@@ -264,6 +267,7 @@ int pss_engine_run(PssEngine* e, const void* d_in, uint32_t n_cap, int mask, int
   p.corr        = e->d_corr;
   p.part_val    = e->d_part_val;
   p.part_idx    = e->d_part_idx;
+  p.spec        = e->d_spec;
   p.in_stride   = e->frame_size;
   p.corr_stride = e->corr_stride;
   p.n_cap       = (int)n_cap;

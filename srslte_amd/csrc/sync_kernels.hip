@@ -10,6 +10,9 @@
 // spectrum, inverse-transforms, takes |.|^2 (optionally the exponential moving average of pss.c:496-503)
 // and reduces a block arg-max -- the capture is read from HBM once for all three hypotheses.
 #include "fft_device.h"
+
+#include <cstdlib>
+#include <cstring>
 #include "hip_common.h"
 #include "sync_device.h"
 
@@ -468,7 +471,18 @@ hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream)
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(pss_block_kernel, dim3(p.n_blocks, p.n_cap), dim3(256), lds, stream, p);
+  static const bool by_workgroup = [] {
+    const char* e = getenv("SRSRAN_HIP_PSS_VARIANT"); // development knob: "block" = the workgroup-per-block kernel of round 1
+    return e && !strcmp(e, "block");
+  }();
+  if (by_workgroup) {
+    hipLaunchKernelGGL(pss_block_kernel, dim3(p.n_blocks, p.n_cap), dim3(256), lds, stream, p);
+  } else {
+    hipError_t e = launch_pss_wave_blocks(p, stream);
+    if (e != hipSuccess) {
+      return e;
+    }
+  }
   hipLaunchKernelGGL(pss_peak_kernel, dim3(3, p.n_cap), dim3(256), 0, stream, p, d_res);
   return hipGetLastError();
 }

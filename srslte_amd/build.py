@@ -24,9 +24,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-Wno-unused-value", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
-# per-source flags.  pss_wave_kernels: the register FFT is written with scalar f32 on purpose (on gfx950 v_pk_*_f32 has the same peak as
-# v_fma_f32 and costs a lone wave ~5x the issue cycles); keep the SLP vectoriser and vector-combine from packing it again.
-EXTRA_FLAGS = {"pss_wave_kernels.hip": ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]}
+# per-source flags.  The FFT kernels are written with scalar f32 on purpose: on gfx950 v_pk_add/mul/fma_f32 have the same peak as v_fma_f32
+# (64 flop per clock and SIMD) and cost more issue cycles, and the SLP vectoriser packs adjacent real / imaginary operations into them with a
+# v_mov shuffle around every pack.  Measured with and without (one box): OFDM rx 415 -> 457 Gsamples/s (LTE), 397 -> 432 (NR); the register
+# FFT of the PSS kernel 2.9 -> 2.8 ms before its other fixes.
+_NO_PACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
+EXTRA_FLAGS = {"pss_wave_kernels.hip": _NO_PACK, "ofdm_kernels.hip": _NO_PACK}
 
 
 def _stale():

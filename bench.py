@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip every cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no extra.ldpc / cellsearch / uplink)")
     ap.add_argument("--only", default="", help="comma list of extras to run (default: all of %s)" % ",".join(EXTRAS))
-    ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of each extra leg")
+    ap.add_argument("--extra-steps", type=int, default=8, help="timed steps of each extra leg (a cell-search step is 1.4 ms: three of them are mostly launch latency)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo): launcher, rendezvous, config broadcast, sharding, "
                          "barrier + max-over-ranks timing; no kernels run and `value` is null")

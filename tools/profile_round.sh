@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round measurement pass on the GPU box (run through gpurun from the repository root):
 #   GPU test suite, bench.py (headline + extra legs), the chain benches, the handle-API bench, rocprofv3 kernel trace of bench.py,
-#   separate PMC passes (traffic, SQ, LDS), the turbo launch-shape variants with their counters, and the lane-mapping probe.
+#   separate PMC passes (traffic, SQ, LDS), the turbo launch-shape variants and the PSS kernels with their counters, and the lane-mapping probe.
 # Outputs go to gpurun_out/round/; the summaries to keep are copied into profiles/ by hand afterwards.
 set -o pipefail
 export TMPDIR=/tmp
@@ -48,6 +48,19 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ
   python tools/rocpd_summary.py $OUT/t8 | grep -E "tdec_win" >> $OUT/pmc_turbo8.txt
   rm -rf $OUT/t8
 done
+# ---- PSS correlation kernels (DESIGN.md par. 3.4): the product (one wave per block), two waves per block, round 1's workgroup per block
+C="python bench.py --steps 3 --warmup 1 --only cellsearch --no-cpu"
+: > $OUT/pss_variants.txt
+for V in wave pair block; do
+  export SRSRAN_HIP_PSS_VARIANT=$V
+  echo "==== variant $V" >> $OUT/pss_variants.txt
+  $C 2> /dev/null | python -c "import sys,json; e=json.loads(sys.stdin.read().strip().splitlines()[-1])['extra']['cellsearch']; print('bench: %.3f ms per 256 captures, %.0f captures/s, results correct: %s' % (e['ms_per_step'], e['captures_per_s'], e['results_correct']))" >> $OUT/pss_variants.txt &&
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/v_s -o p -- $C > /dev/null 2> $OUT/v.err &&
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/v_l -o p -- $C > /dev/null 2> $OUT/v.err &&
+  python tools/rocpd_summary.py $OUT/v_s $OUT/v_l | grep -E "pss_(wave|pair|block)_kernel" >> $OUT/pss_variants.txt
+  rm -rf $OUT/v_s $OUT/v_l
+done
+unset SRSRAN_HIP_PSS_VARIANT
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o acs_layout_probe acs_layout_probe.hip 2> /dev/null; ./acs_layout_probe ) > $OUT/acs_layout_probe.txt 2>&1
 cat $OUT/acs_layout_probe.txt
 echo "profile pass rc=$?"

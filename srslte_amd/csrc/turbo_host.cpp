@@ -348,10 +348,9 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
       p.n_end = 0; // development aid: input extraction + decision only
     }
     // launch-shape alternatives kept for measurement (profiles/r02_turbo_variants.txt); the product path is variant 0
-    static const int variant = [] {
-      const char* e = getenv("SRSRAN_HIP_TDEC_VARIANT");
-      return !e ? 0 : (!strcmp(e, "waves1") ? 1 : (!strcmp(e, "persistent") ? 2 : 0));
-    }();
+    // (read at every launch: tests/test_gpu_variants.py switches it inside one process)
+    const char* ve      = getenv("SRSRAN_HIP_TDEC_VARIANT");
+    const int   variant = !ve ? 0 : (!strcmp(ve, "waves1") ? 1 : (!strcmp(ve, "persistent") ? 2 : 0));
     if (variant == 2 && n_begin == 0 && h->nb == 16 && !h->arith8) {
       static uint32_t* d_counter = nullptr;
       static int       cus       = 0;

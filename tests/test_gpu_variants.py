@@ -1,0 +1,62 @@
+"""The measured alternatives kept in the tree behind development knobs (DESIGN.md par. 3.2 and 3.4: the turbo decoder's launch
+shapes, the three PSS correlation kernels) must stay CORRECT -- a variants table whose rows compute different things says nothing.
+The knobs are read at every launch, so one process switches between them."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+import test_gpu_sync as TS
+import test_gpu_turbo as TT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def knob():
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, os.environ.get(name))
+        os.environ[name] = value
+
+    yield set_
+    for name, value in saved.items():
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = value
+
+
+@pytest.mark.parametrize("variant", ["wave", "pair", "block"])
+@pytest.mark.parametrize("N,frame", [(128, 9600), (2048, 61440)])
+def test_pss_kernels_agree_with_the_oracle(hiplib, knob, variant, N, frame):
+    import srslte_amd as S
+
+    knob("SRSRAN_HIP_PSS_VARIANT", variant)
+    prb = 6 if N == 128 else 100
+    rng = np.random.default_rng(7 * N)
+    cells_id = [3, 151, 302, 500]
+    delays = [0] + [int(rng.integers(0, frame - 15 * N)) for _ in cells_id[1:]]
+    caps = np.stack([TS._capture(c, prb, N, frame, d, 0.05, rng, sf5=(i % 2 == 1)) for i, (c, d) in enumerate(zip(cells_id, delays))])
+    h, got = TS._run_batch(S, caps, frame, N, 1)
+    for i, (cid, d) in enumerate(zip(cells_id, delays)):
+        for n2 in range(3):
+            g = got[i * 3 + n2]
+            pk, pv, psr = O.pss_find(caps[i], N, n2)[:3]
+            assert g.peak_pos == pk, (variant, cid, n2, g.peak_pos, pk)
+            assert abs(g.peak_value - pv) <= 1e-4 * pv and abs(g.psr - psr) <= 1e-3 * psr
+        g = got[i * 3 + cid % 3]
+        assert g.peak_pos == d + 15 * N // 2 and g.N_id_1 == cid // 3 and g.sf_idx == (5 if i % 2 else 0)
+    S.lib().srsran_hip_cellsearch_free(h)
+
+
+@pytest.mark.parametrize("variant", ["product", "waves1", "persistent"])
+def test_turbo_launch_shapes_agree_with_the_oracle(hiplib, knob, variant):
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    knob("SRSRAN_HIP_TDEC_VARIANT", variant)
+    # 40 blocks = 5 units of 8: the persistent grid's counter hands out more than one unit
+    TT._check(S, 6144, capi.TDEC_AUTO, O.ORC_TDEC_AUTO, 40, 0.0, [1, 4], seed=5)

@@ -223,9 +223,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
   cx T1[8], T2[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    T1[j] = tw[lane * j];
-    T2[j] = tw[lane * 8 * j];
+  for (int j = 0; j < 8; j++) { // (the host stores these behind the 4096 twiddles in [entry][lane] order)
+    T1[j] = tw[4096 + 64 * j + lane];
+    T2[j] = tw[4096 + 64 * (8 + j) + lane];
   }
 
   const int i0  = blk * p.hop;           // first convolution output of this block

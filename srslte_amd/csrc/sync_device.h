@@ -22,7 +22,7 @@ struct SssResult {
 
 struct PssParams {
   const void* in;      // n_cap captures of frame_size cf, in_stride cf apart
-  const void* twiddle; // 4096 x cf
+  const void* twiddle; // 4096 x cf, then 16 x 64 cf: the per-lane tables of pss_wave_kernel
   const void* filt;    // 3 x 4096 cf: DFT_4096 of the zero-padded time replica of each N_id_2, / 4096
   float*      corr;    // n_cap x 3 x corr_stride floats: |conv|^2 (moving average), zero beyond n_out
   float*      part_val; // n_cap x 3 x n_blocks

@@ -191,10 +191,17 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
   e->hop         = BN - (int)fft_size;
   e->n_blocks    = e->direct ? (e->n_out + 255) / 256 : (e->n_out + e->hop - 1) / e->hop;
   e->corr_stride = ((size_t)frame_size + fft_size + 2 + 3) & ~(size_t)3;
-  std::vector<std::complex<float>> tw(BN), filt(3 * (size_t)BN);
+  // twiddles: W^i (i < BN), then the per-lane tables of pss_wave_kernel in [entry][lane] order (W^(lane j), W^(8 lane j), j < 8: coalesced loads)
+  std::vector<std::complex<float>> tw(BN + 16 * 64), filt(3 * (size_t)BN);
   for (int i = 0; i < BN; i++) {
     double a = -2.0 * M_PI * (double)i / (double)BN;
     tw[i]    = std::complex<float>((float)cos(a), (float)sin(a));
+  }
+  for (int j = 0; j < 8; j++) {
+    for (int l = 0; l < 64; l++) {
+      tw[BN + j * 64 + l]       = tw[(l * j) % BN];
+      tw[BN + (8 + j) * 64 + l] = tw[(l * 8 * j) % BN];
+    }
   }
   for (uint32_t h = 0; h < 3; h++) {
     pss_time_replica(h, fft_size, cfo_i, e->freq[h], e->time[h]);
@@ -232,14 +239,14 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
       filt[(size_t)h * BN + k] = std::complex<float>((float)v.real(), (float)v.imag());
     }
   }
-  bool ok = hipMalloc(&e->d_tw, (size_t)BN * sizeof(float2)) == hipSuccess &&
+  bool ok = hipMalloc(&e->d_tw, tw.size() * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_filt, 3 * (size_t)BN * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_corr, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_val, (size_t)max_caps * 3 * e->n_blocks * sizeof(float)) == hipSuccess &&
             hipMalloc(&e->d_part_idx, (size_t)max_caps * 3 * e->n_blocks * sizeof(int)) == hipSuccess &&
             hipMalloc(&e->d_spec, (size_t)max_caps * e->n_blocks * e->block_n * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_res, (size_t)max_caps * 3 * sizeof(sync::PssResult)) == hipSuccess &&
-            hipMemcpy(e->d_tw, tw.data(), (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(e->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(e->d_filt, filt.data(), 3 * (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemset(e->d_corr, 0, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess;
   if (ok && e->direct) {

@@ -240,11 +240,33 @@ def plumbing_only(a, rank, world):
     else:
         ranges = [(lo, hi)]
     if rank == 0:
-        print(json.dumps({"metric": "plumbing rehearsal (no kernels)", "value": None, "unit": "Mbit/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "plumbing_only": True, "config": cfg, "shards": ranges, "max_step_time_s": dt,
-                          "torch": torch.__version__}), flush=True)
+        emit({"metric": "plumbing rehearsal (no kernels)", "value": None, "unit": "Mbit/s", "n_gpus": world, "steps": a.steps,
+              "warmup": a.warmup, "plumbing_only": True, "config": cfg, "shards": ranges, "max_step_time_s": dt,
+              "torch": torch.__version__})
     if world > 1:
         dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def _quiet_stdout():
+    """Only the JSON line may reach stdout: native libraries write there too (gloo: "[Gloo] Rank 0 is connected to 1 peer ranks ...").
+    The process's stdout is kept aside for emit() and file descriptor 1 points at stderr from here on."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
 
 
 def worker(a):
@@ -253,6 +275,7 @@ def worker(a):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    _quiet_stdout()
     if a.plumbing_only:
         return plumbing_only(a, rank, world)
     import numpy as np
@@ -449,7 +472,7 @@ def worker(a):
         if rank == 0:
             res["extra"] = extra
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.destroy_process_group()
 

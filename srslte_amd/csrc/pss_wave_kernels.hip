@@ -9,14 +9,15 @@
 //     no bank conflict), and a second register FFT gives X[l + 64 k] -- the layout the block was loaded in.  A 4096-point
 //     transform therefore costs one LDS round trip instead of the two workgroup-wide exchanges + barriers of the
 //     three-pass radix-16 engine, and nothing waits for another wave.
-//   * complex numbers are register PAIRS and everything runs on the packed fp32 pipe (v_pk_add/mul/fma_f32): a complex
-//     addition is one instruction, a multiplication by +-i rides in the operand selectors of the addition that consumes
-//     it, a complex multiplication is two instructions.
-//   * the spectrum of the block (64 complex per lane) is kept for the three hypotheses; with the working set of the
-//     transform that is more than 256 registers, so the kernel runs ONE wave per SIMD with the 512-register budget of
-//     gfx950 (the compiler parks what is not in use in the accumulation registers).  One wave per SIMD is enough here:
-//     the instruction stream is ~7,000 packed VALU instructions per block with 64-fold instruction-level parallelism,
-//     and the only memory waits are the block load, the filter spectra (L2-resident) and four LDS transpositions.
+//   * complex numbers are two plain f32 registers; +-i is a renaming of registers, a complex multiplication two v_mul + two v_fma.
+//     (The first version ran on the packed f32 pipe, one instruction per complex addition: slower, see `cx` below; the file is
+//     compiled without the SLP vectoriser so that it stays unpacked, srslte_amd/build.py.)
+//   * TWO waves per SIMD (235 registers): a wave issues at most one vector instruction per four cycles, the SIMD takes one per
+//     two, and a lone wave stands still through every memory wait.  The spectrum of the block serves three hypotheses but does not
+//     fit next to the transform's working set at that occupancy: it is parked in global memory in between (pss_wave_kernel).
+//   * every global access is 512 contiguous bytes per wave instruction (capture, filter spectra, parked spectrum, correlation row);
+//     block borders, the zero padding of the convolution and the ragged last block are the bounds checks of buffer instructions.
+// A measured alternative with two waves per block and three waves per SIMD (pss_pair_kernel) is at the end of the file.
 #include "hip_common.h"
 #include "sync_device.h"
 

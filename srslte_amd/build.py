@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # v_mov shuffle around every pack.  Measured with and without (one box): OFDM rx 415 -> 457 Gsamples/s (LTE), 397 -> 432 (NR); the register
 # FFT of the PSS kernel 2.9 -> 2.8 ms before its other fixes.
 _NO_PACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
-EXTRA_FLAGS = {"pss_wave_kernels.hip": _NO_PACK, "ofdm_kernels.hip": _NO_PACK}
+EXTRA_FLAGS = {"pss_wave_kernels.hip": _NO_PACK, "ofdm_kernels.hip": _NO_PACK, "sync_kernels.hip": _NO_PACK}
 
 
 def _stale():

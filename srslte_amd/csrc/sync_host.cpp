@@ -319,6 +319,10 @@ SssEngine* sss_engine_new(uint32_t fft_size)
   if (!device_available()) {
     return nullptr;
   }
+  if (fft_size < 64 || fft_size > 2048 || fft_size % 64) { // the symbol transform is N / 64 interleaved 64-point transforms (sss_kernel)
+    set_error("SSS: unsupported symbol size %u (a multiple of 64 up to 2048)", fft_size);
+    return nullptr;
+  }
   auto* e     = new SssEngine;
   e->fft_size = fft_size;
   std::vector<std::complex<float>> tw(fft_size);

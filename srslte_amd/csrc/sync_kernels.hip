@@ -10,6 +10,7 @@
 // spectrum, inverse-transforms, takes |.|^2 (optionally the exponential moving average of pss.c:496-503)
 // and reduces a block arg-max -- the capture is read from HBM once for all three hypotheses.
 #include "fft_device.h"
+#include "fft_reg.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -264,8 +265,7 @@ __global__ __launch_bounds__(256) void pss_peak_kernel(const PssParams p, PssRes
 // correlations and their arg-max (find_sss.c) on the first wave.  fft_size <= 2048 (sss.c:38, checked by the host).
 __global__ __launch_bounds__(256) void sss_kernel(const SssParams p, const PssResult* pss, SssResult* res)
 {
-  extern __shared__ float2 s_stage[]; // [N] symbol, [N] twiddles
-  __shared__ float2 s_part[4][62];
+  extern __shared__ float2 s_stage[]; // [N] symbol, [N / 64][65] its decimated 64-point transforms
   __shared__ float2 y[2][31];
   __shared__ float  corr[2][31];
   __shared__ float  s_pow[2];
@@ -294,41 +294,45 @@ __global__ __launch_bounds__(256) void sss_kernel(const SssParams p, const PssRe
   const float*  st = p.s_tilde;
   const float*  ct = p.c_tilde;
   const float*  zt = p.z_tilde;
-  float2* s_x  = s_stage;
-  float2* s_tw = s_stage + N;
+  // The 62 bins around DC of the N-point transform of the symbol (find_sss.c:81-84, dft_fftw.c:310-320), N = 64 D: with n = D q + r,
+  //   X[b] = sum_r W_N^(b r) Y_r[b mod 64],   Y_r[k] = sum_q x[D q + r] W_64^(k q)
+  // -- D 64-point transforms (lane r of the first wave runs one on its own registers, fft_reg.h) and 62 sums of D terms, instead of 62 sums
+  // of N terms.  The 62 bins are different modulo 64.
+  regfft::cx* s_x = reinterpret_cast<regfft::cx*>(s_stage);
+  regfft::cx* s_y = s_x + N; // [r][65]: Y_r[k] at r * 65 + k
+  const int   D   = N >> 6;
   for (int n = lane; n < N; n += 256) {
-    s_x[n]  = x[n];
-    s_tw[n] = tw[n];
+    s_x[n] = reinterpret_cast<const regfft::cx*>(x)[n];
   }
   __syncthreads();
-  {
-    // mirrored + dc-removed spectrum index N/2-31+k  ->  FFT bin (find_sss.c:81-84, dft_fftw.c:310-320)
-    const int k = lane & 63, wv = lane >> 6;
-    if (k < 62) {
-      const int bin   = k < 31 ? N - 31 + k : 1 + (k - 31);
-      const int chunk = (N + 3) / 4;
-      const int n0 = wv * chunk, n1 = min(n0 + chunk, N);
-      float     re = 0.f, im = 0.f;
-      int       idx = (int)(((long)bin * n0) % N);
-      for (int n = n0; n < n1; n++) {
-        const float2 w = s_tw[idx];
-        const float2 v = s_x[n];
-        re += v.x * w.x - v.y * w.y;
-        im += v.x * w.y + v.y * w.x;
-        idx += bin;
-        idx = idx >= N ? idx - N : idx;
-      }
-      s_part[wv][k] = make_float2(re, im);
+  if (lane < D) {
+    regfft::cx v[64];
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+      v[q] = s_x[D * q + lane];
+    }
+    regfft::fft64<false>(v);
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+      s_y[lane * 65 + k] = v[k];
     }
   }
   __syncthreads();
   if (lane < 62) {
-    float2 v = s_part[0][lane];
-#pragma unroll
-    for (int w = 1; w < 4; w++) {
-      v.x += s_part[w][lane].x;
-      v.y += s_part[w][lane].y;
+    // mirrored + dc-removed spectrum index N/2-31+k  ->  FFT bin
+    const int bin = lane < 31 ? N - 31 + lane : 1 + (lane - 31);
+    const int kb  = bin & 63;
+    float     re = 0.f, im = 0.f;
+    int       idx = 0;
+    for (int r = 0; r < D; r++) {
+      const float2     w  = tw[idx];
+      const regfft::cx yv = s_y[r * 65 + kb];
+      re += yv.x * w.x - yv.y * w.y;
+      im += yv.x * w.y + yv.y * w.x;
+      idx += bin;
+      idx = idx >= N ? idx - N : idx;
     }
+    float2 v = make_float2(re, im);
     if (p.ce) { // find_sss.c:73-76: divide by the channel estimate
       const float2 c = reinterpret_cast<const float2*>(p.ce)[((size_t)cap * 3 + h) * 62 + lane];
       const float  d = c.x * c.x + c.y * c.y;
@@ -488,7 +492,7 @@ hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream)
 
 hipError_t launch_sss(const SssParams& p, const PssResult* d_pss, SssResult* d_res, hipStream_t stream)
 {
-  hipLaunchKernelGGL(sss_kernel, dim3(3, p.n_cap), dim3(256), 2 * (size_t)p.fft_size * sizeof(float2), stream, p, d_pss, d_res);
+  hipLaunchKernelGGL(sss_kernel, dim3(3, p.n_cap), dim3(256), ((size_t)p.fft_size + 65 * (size_t)(p.fft_size / 64)) * sizeof(float2), stream, p, d_pss, d_res);
   return hipGetLastError();
 }
 

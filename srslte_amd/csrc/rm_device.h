@@ -19,12 +19,18 @@ struct RxJob {
 struct TbCrcJob {
   uint32_t data_offset; // first byte of the transport block
   uint32_t tbs;         // payload bits (multiple of 8); the 3 parity bytes follow
+  // the block's code blocks in THIS launch: two runs of consecutive entries of the decoder's per-block verdicts (blocks of K1, blocks of K2);
+  // the parity is only computed when all of them are good (`need` = their number; blocks decoded in earlier HARQ rounds are not listed)
+  uint32_t run_start[2], run_len[2], need;
 };
 struct TbCrcResult {
-  uint32_t par_rx; // CRC24A of the payload
-  uint32_t par_tx; // the received parity bytes
+  uint32_t par_rx;   // CRC24A of the payload
+  uint32_t par_tx;   // the received parity bytes
+  uint32_t computed; // 0: some code block of the transport block failed, no parity taken (sch.c:473-477)
 };
-hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, TbCrcResult* d_res, hipStream_t stream);
+// d_cb_ok: the decoder's verdict per code block of the launch (1 = CRC good)
+hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, TbCrcResult* d_res,
+                         hipStream_t stream);
 
 // d_jobs: device array of n_jobs descriptors.  elem8: int8 soft bits (wrapping), else int16.
 hipError_t launch_rx(const void* d_in, void* d_out, const uint16_t* d_tables, const RxJob* d_jobs, int n_jobs, bool elem8,

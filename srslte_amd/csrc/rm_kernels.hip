@@ -265,7 +265,7 @@ namespace phyhip {
 namespace rm {
 
 // ---- transport-block CRC (decode_tb, sch.c:540-560): CRC24A over the tbs payload bits, compared with the three
-// parity bytes that follow.  One workgroup per block: every lane runs the bit-serial CRC (crc.c:92-140) of its chunk,
+// parity bytes that follow.  One workgroup per block: every lane runs the CRC (crc.c:92-140, a byte per table look-up) of its chunk,
 // shifts it to its place by x^(8 * bytes behind the chunk) mod g (square-and-multiply) and the partial checksums
 // are XOR-ed.
 __device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b, uint32_t poly)
@@ -278,21 +278,51 @@ __device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b, uint32_t p
   return r;
 }
 
-__global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const TbCrcJob* jobs, uint32_t poly_full, TbCrcResult* res)
+// Only blocks whose code blocks all passed get a parity (sch.c:473-477), decided HERE from the decoder's verdicts: the host does not have
+// to come back between decoding and this.  Byte-wise with a 256-entry table of the generator built in LDS (one entry per lane).
+__global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const TbCrcJob* jobs, uint32_t poly_full, const uint8_t* cb_ok, TbCrcResult* res)
 {
   __shared__ uint32_t red[256];
+  __shared__ uint32_t tab[256];
+  __shared__ uint32_t s_good;
   const TbCrcJob jb   = jobs[blockIdx.x];
   const uint32_t poly = poly_full & 0xffffffu;
+  {
+    uint32_t c = (uint32_t)threadIdx.x << 16;
+    for (int b = 0; b < 8; b++) {
+      c = ((c << 1) & 0xffffffu) ^ ((c & 0x800000u) ? poly : 0u);
+    }
+    tab[threadIdx.x] = c;
+  }
+  if (threadIdx.x == 0) {
+    s_good = 0;
+  }
+  __syncthreads();
+  {
+    uint32_t good = 0;
+    for (int k = 0; k < 2; k++) {
+      for (uint32_t i = threadIdx.x; i < jb.run_len[k]; i += 256) {
+        good += cb_ok[jb.run_start[k] + i] ? 1u : 0u;
+      }
+    }
+    if (good) {
+      atomicAdd(&s_good, good);
+    }
+  }
+  __syncthreads();
+  if (s_good != jb.need) {
+    if (threadIdx.x == 0) {
+      res[blockIdx.x] = {0u, 0u, 0u};
+    }
+    return;
+  }
   const uint8_t* d    = data + jb.data_offset;
   const uint32_t nb   = jb.tbs / 8;
   const uint32_t c    = (nb + 255) / 256;
   const uint32_t lo = threadIdx.x * c, hi = lo + c < nb ? lo + c : nb;
   uint32_t       crc = 0;
   for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t byte = d[i];
-    for (int b = 7; b >= 0; b--) {
-      crc = ((crc << 1) & 0xffffffu) ^ ((((crc >> 23) ^ (byte >> b)) & 1u) ? poly : 0u);
-    }
+    crc = ((crc << 8) & 0xffffffu) ^ tab[((crc >> 16) ^ d[i]) & 0xffu];
   }
   if (lo < nb) {
     uint32_t e = 8 * (nb - hi), result = 1, base = 2; // x^e mod g
@@ -316,14 +346,14 @@ __global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const 
   if (threadIdx.x == 0) {
     const uint32_t par_rx = red[0];
     const uint32_t par_tx = ((uint32_t)d[nb] << 16) | ((uint32_t)d[nb + 1] << 8) | (uint32_t)d[nb + 2];
-    res[blockIdx.x].par_rx = par_rx;
-    res[blockIdx.x].par_tx = par_tx;
+    res[blockIdx.x]       = {par_rx, par_tx, 1u};
   }
 }
 
-hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, TbCrcResult* d_res, hipStream_t stream)
+hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, TbCrcResult* d_res,
+                         hipStream_t stream)
 {
-  hipLaunchKernelGGL(tb_crc_kernel, dim3(n_jobs), dim3(256), 0, stream, d_data, d_jobs, poly, d_res);
+  hipLaunchKernelGGL(tb_crc_kernel, dim3(n_jobs), dim3(256), 0, stream, d_data, d_jobs, poly, d_cb_ok, d_res);
   return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 #include "srsran_amd/phy_sch_abi.h"
 #include "turbo_device.h"
 
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -64,6 +65,7 @@ struct srsran_hip_sch {
   // one turbo batch object per (K, arithmetic is 16 bit), grown on demand
   std::map<uint32_t, std::pair<srsran_hip_tdec_batch_t*, uint32_t>> dec; // K | 8-bit flag << 31 -> (object, capacity)
   void*  d_scratch = nullptr; // job / descriptor / result arrays
+  void*  h_scratch = nullptr; // ... and their pinned host image: descriptors go up and verdicts come down with one asynchronous copy each
   size_t scratch_cap = 0;
 };
 
@@ -89,16 +91,12 @@ extern "C" void srsran_hip_sch_free(srsran_hip_sch_t* h)
     srsran_hip_tdec_batch_free(kv.second.first);
   }
   (void)hipFree(h->d_scratch);
+  (void)hipHostFree(h->h_scratch);
   delete h;
 }
 
 namespace {
 
-struct CbWork {
-  uint32_t tb, cb_idx, K, slot, poly;
-  rm::RxJob       job;
-  turbo::CbDesc   desc;
-};
 
 srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n, bool llr8)
 {
@@ -132,18 +130,32 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
     set_error("sch decode: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  hipStream_t          st = (hipStream_t)stream;
-  std::vector<CbWork>  work;
-  std::vector<srsran_cbsegm_t> seg(n_tb);
-  std::vector<float>   iters(n_tb, 0.f);
+  hipStream_t st = (hipStream_t)stream;
+  // The host's share of a call is two passes over the blocks with nothing allocated per code block: pass 1 segments and validates the
+  // transport blocks and sizes the launch groups -- (K, rv, generator): one rate de-matching launch and one decoder launch each --, pass 2
+  // writes every pending code block's job and descriptor straight into its place of the pinned image of the device arrays (32 k code
+  // blocks per call in the benches: the work list, the per-group index vectors and their copies used to keep the GPU waiting 0.33 ms).
+  struct TbPlan {
+    srsran_cbsegm_t seg;
+    int             grp[2] = {-1, -1}; // launch group of the blocks of size K1 / K2
+    uint32_t        pend[2] = {0, 0};  // pending code blocks of each size (not decoded in an earlier HARQ round)
+    uint32_t        start[2] = {0, 0}; // their first place in launch order
+  };
+  struct Group {
+    uint64_t key;
+    uint32_t K, rv, poly, count, base, cursor, max_in;
+  };
+  std::vector<TbPlan> plan(n_tb);
+  std::vector<Group>  groups;
+  size_t              n = 0;
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
+    srsran_cbsegm_t&       cs = plan[t].seg;
     results[t] = {SRSRAN_ERROR, 0.f, 0};
-    if (srsran_cbsegm(&seg[t], tb.tbs) || tb.Qm == 0 || (tb.rv & ~(uint32_t)SRSRAN_HIP_TB_NEW_DATA) > 3 || (tb.tbs & 7)) {
+    if (srsran_cbsegm(&cs, tb.tbs) || tb.Qm == 0 || (tb.rv & ~(uint32_t)SRSRAN_HIP_TB_NEW_DATA) > 3 || (tb.tbs & 7)) {
       set_error("sch decode: transport block %u: invalid tbs / Qm / rv", t);
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
-    const srsran_cbsegm_t& cs = seg[t];
     results[t].nof_cb = cs.C;
     if (cs.tbs == 0 || cs.C == 0) {
       results[t].crc_ok = SRSRAN_SUCCESS; // sch.c:517-519
@@ -160,142 +172,191 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
     for (uint32_t i = 0; i < cs.C; i++) {
-      if (cb_crc[tb.first_cb + i]) {
-        continue; // decoded in an earlier HARQ round: its bytes stay in d_data (sch.c:466-471)
+      if (!cb_crc[tb.first_cb + i]) { // (else decoded in an earlier HARQ round: its bytes stay in d_data, sch.c:466-471)
+        plan[t].pend[i < cs.C1 ? 0 : 1]++;
       }
-      // sch.c:389-405
-      const uint32_t K     = i < cs.C1 ? cs.K1 : cs.K2;
-      const uint32_t rlen  = cs.C == 1 ? K : K - 24;
-      const uint32_t Gp    = tb.nof_e_bits / tb.Qm;
-      const uint32_t gamma = Gp % cs.C;
-      const uint32_t n_e   = tb.Qm * (Gp / cs.C);
+    }
+    for (int k = 0; k < 2; k++) {
+      if (!plan[t].pend[k]) {
+        continue;
+      }
+      const uint32_t K    = k == 0 ? cs.K1 : cs.K2;
+      const uint32_t poly = cs.C > 1 ? CRC24B : CRC24A; // sch.c:432-438
+      const uint64_t key  = ((uint64_t)K << 34) | ((uint64_t)(tb.rv & 3u) << 32) | poly;
+      int            g    = -1;
+      for (size_t j = 0; j < groups.size(); j++) {
+        if (groups[j].key == key) {
+          g = (int)j;
+          break;
+        }
+      }
+      if (g < 0) {
+        g = (int)groups.size();
+        groups.push_back({key, K, tb.rv & 3u, poly, 0, 0, 0, 0});
+      }
+      plan[t].grp[k] = g;
+      groups[g].count += plan[t].pend[k];
+      n += plan[t].pend[k];
+    }
+  }
+  std::sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.key < b.key; });
+  {
+    // (the sort moved the groups: redo the blocks' group indices by key, then lay the groups out one behind the other)
+    uint32_t base = 0;
+    for (Group& g : groups) {
+      g.base = g.cursor = base;
+      base += g.count;
+    }
+    for (uint32_t t = 0; t < n_tb; t++) {
+      const srsran_cbsegm_t& cs = plan[t].seg;
+      for (int k = 0; k < 2; k++) {
+        if (plan[t].grp[k] < 0) {
+          continue;
+        }
+        const uint64_t key = ((uint64_t)(k == 0 ? cs.K1 : cs.K2) << 34) | ((uint64_t)(tbs[t].rv & 3u) << 32) | (cs.C > 1 ? CRC24B : CRC24A);
+        for (size_t j = 0; j < groups.size(); j++) {
+          if (groups[j].key == key) {
+            plan[t].grp[k] = (int)j;
+            break;
+          }
+        }
+      }
+    }
+  }
+
+  // Scratch, on the device and as a pinned host image of the same layout: per code block a job, a descriptor, an iteration count and a
+  // verdict; per transport block a CRC job and its result.  [jobs | descriptors | CRC jobs] go up in one copy, [iteration counts | verdicts |
+  // CRC results] come down in one, and the host waits ONCE: the transport-block CRC kernel decides by itself from the verdicts which blocks
+  // are complete (sch.c:473-477), so nothing has to come back between decoding and it.
+  auto         al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t o_jobs = 0, o_desc = al(o_jobs + n * sizeof(rm::RxJob)), o_tbj = al(o_desc + n * sizeof(turbo::CbDesc));
+  const size_t o_noi = al(o_tbj + n_tb * sizeof(rm::TbCrcJob)), o_ok = al(o_noi + n * sizeof(int)), o_tbr = al(o_ok + n);
+  const size_t bytes = al(o_tbr + n_tb * sizeof(rm::TbCrcResult));
+  if (bytes > h->scratch_cap) {
+    (void)hipFree(h->d_scratch);
+    (void)hipHostFree(h->h_scratch);
+    h->d_scratch = h->h_scratch = nullptr;
+    h->scratch_cap               = 0;
+    PHY_HIP_CHECK(hipMalloc(&h->d_scratch, bytes), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipHostMalloc(&h->h_scratch, bytes), SRSRAN_ERROR);
+    h->scratch_cap = bytes;
+  }
+  uint8_t* base = static_cast<uint8_t*>(h->d_scratch);
+  uint8_t* hb   = static_cast<uint8_t*>(h->h_scratch);
+  auto*    d_jobs = reinterpret_cast<rm::RxJob*>(base + o_jobs);
+  auto*    d_desc = reinterpret_cast<turbo::CbDesc*>(base + o_desc);
+  auto*    d_tbj  = reinterpret_cast<rm::TbCrcJob*>(base + o_tbj);
+  auto*    d_noi  = reinterpret_cast<int*>(base + o_noi);
+  auto*    d_ok   = base + o_ok;
+  auto*    d_tbr  = reinterpret_cast<rm::TbCrcResult*>(base + o_tbr);
+  auto*    jobs   = reinterpret_cast<rm::RxJob*>(hb + o_jobs);
+  auto*    descs  = reinterpret_cast<turbo::CbDesc*>(hb + o_desc);
+  auto*    tbj    = reinterpret_cast<rm::TbCrcJob*>(hb + o_tbj);
+  const int*             noi = reinterpret_cast<const int*>(hb + o_noi);
+  const uint8_t*         ok  = hb + o_ok;
+  const rm::TbCrcResult* tbr = reinterpret_cast<const rm::TbCrcResult*>(hb + o_tbr);
+
+  // pass 2: jobs and descriptors in launch order; per transport block the CRC job with the two runs of verdicts that are its code blocks
+  size_t n_crc = 0;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    const srsran_hip_tb_t& tb = tbs[t];
+    const srsran_cbsegm_t& cs = plan[t].seg;
+    if (cs.C == 0) {
+      continue;
+    }
+    for (int k = 0; k < 2; k++) {
+      if (plan[t].grp[k] >= 0) {
+        plan[t].start[k] = groups[plan[t].grp[k]].cursor;
+      }
+    }
+    // sch.c:389-405
+    const uint32_t Gp    = tb.nof_e_bits / tb.Qm;
+    const uint32_t gamma = Gp % cs.C;
+    const uint32_t n_e   = tb.Qm * (Gp / cs.C);
+    const uint32_t fresh = (tb.rv & SRSRAN_HIP_TB_NEW_DATA) ? 1u : 0u;
+    for (uint32_t i = 0; i < cs.C; i++) {
+      if (cb_crc[tb.first_cb + i]) {
+        continue;
+      }
+      const int      k    = i < cs.C1 ? 0 : 1;
+      const uint32_t K    = k == 0 ? cs.K1 : cs.K2;
+      const uint32_t rlen = cs.C == 1 ? K : K - 24;
       uint32_t       rp = i * n_e, n_e2 = n_e;
       if (i > cs.C - gamma) {
         n_e2 = n_e + tb.Qm;
         rp   = (cs.C - gamma) * n_e + (i - (cs.C - gamma)) * n_e2;
       }
-      CbWork w;
-      w.tb     = t;
-      w.cb_idx = i;
-      w.K      = K;
-      w.slot   = tb.first_cb + i;
-      w.poly   = cs.C > 1 ? CRC24B : CRC24A; // sch.c:432-438
-      w.job    = {tb.e_offset + rp, n_e2, w.slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 3 * K + 12, 0, (tb.rv & SRSRAN_HIP_TB_NEW_DATA) ? 1u : 0u};
-      w.desc   = {w.slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, tb.data_offset + i * rlen / 8,
-                  (i + 1 == cs.C) ? K / 8 : rlen / 8, 0};
-      work.push_back(w);
+      Group&         g    = groups[plan[t].grp[k]];
+      const uint32_t j    = g.cursor++;
+      const uint32_t slot = tb.first_cb + i;
+      jobs[j]  = {tb.e_offset + rp, n_e2, slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 3 * K + 12, 0, fresh};
+      descs[j] = {slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, tb.data_offset + i * rlen / 8, (i + 1 == cs.C) ? K / 8 : rlen / 8, 0};
+      g.max_in = std::max(g.max_in, n_e2);
     }
+    tbj[n_crc++] = {tb.data_offset, cs.tbs, {plan[t].start[0], plan[t].start[1]}, {plan[t].pend[0], plan[t].pend[1]}, plan[t].pend[0] + plan[t].pend[1]};
   }
-  // device scratch: per code block a job, a descriptor, an iteration count and a flag; per block a CRC job + result
-  const size_t n = work.size();
-  const size_t bytes = n * (sizeof(rm::RxJob) + sizeof(turbo::CbDesc) + sizeof(int) + 4) + n_tb * (sizeof(rm::TbCrcJob) + sizeof(rm::TbCrcResult)) + 256;
-  if (bytes > h->scratch_cap) {
-    (void)hipFree(h->d_scratch);
-    h->d_scratch = nullptr;
-    PHY_HIP_CHECK(hipMalloc(&h->d_scratch, bytes), SRSRAN_ERROR);
-    h->scratch_cap = bytes;
+  if (n || n_crc) {
+    PHY_HIP_CHECK(hipMemcpyAsync(base, hb, o_tbj + n_crc * sizeof(rm::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMemsetAsync(d_noi, 0, o_tbr - o_noi, st), SRSRAN_ERROR);
   }
-  uint8_t* base = static_cast<uint8_t*>(h->d_scratch);
-  auto*    d_jobs = reinterpret_cast<rm::RxJob*>(base);
-  auto*    d_desc = reinterpret_cast<turbo::CbDesc*>(d_jobs + n);
-  auto*    d_noi  = reinterpret_cast<int*>(d_desc + n);
-  auto*    d_ok   = reinterpret_cast<uint8_t*>(d_noi + n);
-  auto*    d_tbj  = reinterpret_cast<rm::TbCrcJob*>(base + ((reinterpret_cast<uintptr_t>(d_ok + n) - reinterpret_cast<uintptr_t>(base) + 15) & ~(uintptr_t)15));
-  auto*    d_tbr  = reinterpret_cast<rm::TbCrcResult*>(d_tbj + n_tb);
-
-  // group by (K, rv, generator): one rate de-matching launch and one decoder launch per group
-  std::map<uint64_t, std::vector<size_t>> groups;
-  for (size_t i = 0; i < n; i++) {
-    groups[((uint64_t)work[i].K << 34) | ((uint64_t)(tbs[work[i].tb].rv & 3u) << 32) | work[i].poly].push_back(i);
-  }
-  std::vector<rm::RxJob>     jobs;
-  std::vector<turbo::CbDesc> descs;
-  std::vector<size_t>        order;
-  for (auto& g : groups) {
-    for (size_t i : g.second) {
-      jobs.push_back(work[i].job);
-      descs.push_back(work[i].desc);
-      order.push_back(i);
-    }
-  }
-  if (n) {
-    PHY_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), n * sizeof(rm::RxJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(d_desc, descs.data(), n * sizeof(turbo::CbDesc), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemsetAsync(d_noi, 0, n * sizeof(int) + n, st), SRSRAN_ERROR);
-  }
-  size_t at = 0;
-  for (auto& g : groups) {
-    const uint32_t K = (uint32_t)(g.first >> 34), rv = (uint32_t)((g.first >> 32) & 3), poly = (uint32_t)g.first;
-    const uint32_t m = (uint32_t)g.second.size();
+  for (const Group& g : groups) {
+    const uint32_t K = g.K, m = g.count, at = g.base;
     const uint32_t nsb = llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K);
-    const uint16_t* tab = rm::device_table(K, rv, nsb);
+    const uint16_t* tab = rm::device_table(K, g.rv, nsb);
     srsran_hip_tdec_batch_t* dec = decoder_for(h, K, m, llr8);
     if (!tab || !dec) {
       return SRSRAN_ERROR;
     }
     // softbuffer += rate-matched soft bits (srsran_rm_turbo_rx_lut, sch.c:414), in the decoder's sub-block layout
-    uint32_t max_in = 0;
-    for (uint32_t i = 0; i < m; i++) {
-      max_in = std::max(max_in, work[g.second[i]].job.in_len);
-    }
-    if ((size_t)max_in * (llr8 ? 1 : 2) > 40 * 1024 - 16) {
+    if ((size_t)g.max_in * (llr8 ? 1 : 2) > 40 * 1024 - 16) {
       // (the kernel for inputs beyond its LDS staging area only accumulates: clear the new blocks' rows here)
       for (uint32_t i = 0; i < m; i++) {
-        const CbWork& w = work[g.second[i]];
-        if (w.job.fresh) {
-          PHY_HIP_CHECK(hipMemsetAsync(static_cast<uint8_t*>(d_softbuf) + (size_t)w.job.out_offset * (llr8 ? 1 : 2), 0,
+        const rm::RxJob& jb = jobs[at + i];
+        if (jb.fresh) {
+          PHY_HIP_CHECK(hipMemsetAsync(static_cast<uint8_t*>(d_softbuf) + (size_t)jb.out_offset * (llr8 ? 1 : 2), 0,
                                        (size_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE * (llr8 ? 1 : 2), st), SRSRAN_ERROR);
         }
       }
     }
     // (blocks of K <= 400 have no sub-block layout: nsb = 0, natural soft buffer, scalar decoder -- turbodecoder.c:381-408, rm_turbo.c:412-421)
-    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, nsb ? 3 * (K + 32) + 12 : 3 * K + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, max_in), SRSRAN_ERROR);
-    if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, nsb ? 1 : 0, poly, d_noi + at, d_ok + at, st)) {
+    PHY_HIP_CHECK(rm::launch_rx_gather(d_e_bits, d_softbuf, tab, nsb ? 3 * (K + 32) + 12 : 3 * K + 12, d_jobs + at, rm::RxJob{}, 0, 0, (int)m, llr8, st, g.max_in), SRSRAN_ERROR);
+    if (turbo::batch_run_early_stop(dec, d_softbuf, llr8, d_desc + at, d_data, m, max_iterations, nsb ? 1 : 0, g.poly, d_noi + at, d_ok + at, st)) {
       return SRSRAN_ERROR;
     }
-    at += m;
   }
-  std::vector<int>     noi(n);
-  std::vector<uint8_t> ok(n);
-  if (n) {
-    PHY_HIP_CHECK(hipMemcpyAsync(noi.data(), d_noi, n * sizeof(int), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(ok.data(), d_ok, n, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+  // transport-block CRC (sch.c:473-477,540-560) of the blocks whose code blocks are all good, straight behind the decoders
+  if (n_crc) {
+    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)n_crc, CRC24A, d_ok, d_tbr, st), SRSRAN_ERROR);
+  }
+  if (n || n_crc) {
+    PHY_HIP_CHECK(hipMemcpyAsync(hb + o_noi, base + o_noi, o_tbr + n_crc * sizeof(rm::TbCrcResult) - o_noi, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
   }
   PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
-  for (size_t j = 0; j < n; j++) {
-    const CbWork& w = work[order[j]];
-    if (ok[j]) {
-      cb_crc[w.slot] = 1;
-    }
-    iters[w.tb] += (float)noi[j];
-  }
-  // transport-block CRC of the blocks whose code blocks are all good (sch.c:473-477,540-560)
-  std::vector<rm::TbCrcJob> tbj;
-  std::vector<uint32_t>     tbi;
+  // results, walking the blocks in the order of pass 2
+  size_t jc = 0;
   for (uint32_t t = 0; t < n_tb; t++) {
-    const srsran_cbsegm_t& cs = seg[t];
+    const srsran_hip_tb_t& tb = tbs[t];
+    const srsran_cbsegm_t& cs = plan[t].seg;
     if (cs.C == 0) {
       continue;
     }
-    results[t].avg_iterations = iters[t] / (float)cs.C; // sch.c:485
-    bool all = true;
+    float    it_sum = 0.f;
+    uint32_t at[2]  = {plan[t].start[0], plan[t].start[1]};
     for (uint32_t i = 0; i < cs.C; i++) {
-      all = all && cb_crc[tbs[t].first_cb + i];
+      if (cb_crc[tb.first_cb + i]) {
+        continue;
+      }
+      const uint32_t j = at[i < cs.C1 ? 0 : 1]++;
+      it_sum += (float)noi[j];
+      if (ok[j]) {
+        cb_crc[tb.first_cb + i] = 1;
+      }
     }
-    if (all) {
-      tbj.push_back({tbs[t].data_offset, cs.tbs});
-      tbi.push_back(t);
+    results[t].avg_iterations = it_sum / (float)cs.C; // sch.c:485
+    if (tbr[jc].computed) {
+      results[t].crc_ok = (tbr[jc].par_rx == tbr[jc].par_tx && tbr[jc].par_rx) ? SRSRAN_SUCCESS : SRSRAN_ERROR; // sch.c:551
     }
-  }
-  if (!tbj.empty()) {
-    std::vector<rm::TbCrcResult> r(tbj.size());
-    PHY_HIP_CHECK(hipMemcpyAsync(d_tbj, tbj.data(), tbj.size() * sizeof(rm::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)tbj.size(), CRC24A, d_tbr, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(r.data(), d_tbr, r.size() * sizeof(rm::TbCrcResult), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
-    for (size_t j = 0; j < r.size(); j++) {
-      results[tbi[j]].crc_ok = (r[j].par_rx == r[j].par_tx && r[j].par_rx) ? SRSRAN_SUCCESS : SRSRAN_ERROR; // sch.c:551
-    }
+    jc++;
   }
   return SRSRAN_SUCCESS;
 }

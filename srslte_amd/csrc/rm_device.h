@@ -22,6 +22,7 @@ struct TbCrcJob {
   // the block's code blocks in THIS launch: two runs of consecutive entries of the decoder's per-block verdicts (blocks of K1, blocks of K2);
   // the parity is only computed when all of them are good (`need` = their number; blocks decoded in earlier HARQ rounds are not listed)
   uint32_t run_start[2], run_len[2], need;
+  uint32_t mult; // which 256-entry row of the multiplier table belongs to this tbs: x^(8 * bytes behind lane l's chunk) mod g
 };
 struct TbCrcResult {
   uint32_t par_rx;   // CRC24A of the payload
@@ -29,8 +30,11 @@ struct TbCrcResult {
   uint32_t computed; // 0: some code block of the transport block failed, no parity taken (sch.c:473-477)
 };
 // d_cb_ok: the decoder's verdict per code block of the launch (1 = CRC good)
-hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, TbCrcResult* d_res,
-                         hipStream_t stream);
+// d_mult: rows of 256 multipliers (tb_crc_multipliers(), one row per distinct tbs of the launch)
+hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, const uint32_t* d_mult,
+                         TbCrcResult* d_res, hipStream_t stream);
+// the kernel's split of a block of tbs / 8 bytes over its 256 lanes, and what lane l multiplies its chunk's remainder with
+void tb_crc_multipliers(uint32_t tbs, uint32_t poly, uint32_t out[256]);
 
 // d_jobs: device array of n_jobs descriptors.  elem8: int8 soft bits (wrapping), else int16.
 hipError_t launch_rx(const void* d_in, void* d_out, const uint16_t* d_tables, const RxJob* d_jobs, int n_jobs, bool elem8,

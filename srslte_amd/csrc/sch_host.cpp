@@ -67,6 +67,10 @@ struct srsran_hip_sch {
   void*  d_scratch = nullptr; // job / descriptor / result arrays
   void*  h_scratch = nullptr; // ... and their pinned host image: descriptors go up and verdicts come down with one asynchronous copy each
   size_t scratch_cap = 0;
+  // transport-block CRC: one row of 256 lane multipliers per block size seen so far (rm::tb_crc_multipliers), resident on the device
+  std::map<uint32_t, uint32_t> crc_row; // tbs -> row
+  uint32_t*                    d_crc_mult = nullptr;
+  uint32_t                     crc_rows_cap = 0;
 };
 
 extern "C" int srsran_hip_sch_create(srsran_hip_sch_t** hh)
@@ -92,6 +96,7 @@ extern "C" void srsran_hip_sch_free(srsran_hip_sch_t* h)
   }
   (void)hipFree(h->d_scratch);
   (void)hipHostFree(h->h_scratch);
+  (void)hipFree(h->d_crc_mult);
   delete h;
 }
 
@@ -256,6 +261,35 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   const uint8_t*         ok  = hb + o_ok;
   const rm::TbCrcResult* tbr = reinterpret_cast<const rm::TbCrcResult*>(hb + o_tbr);
 
+  // row of the CRC multiplier table for a block size: computed and uploaded the first time the size is seen by this object
+  auto crc_row_of = [&](uint32_t tbs_bits) -> uint32_t {
+    auto it = h->crc_row.find(tbs_bits);
+    if (it != h->crc_row.end()) {
+      return it->second;
+    }
+    const uint32_t row = (uint32_t)h->crc_row.size();
+    if (row >= h->crc_rows_cap) {
+      const uint32_t cap = h->crc_rows_cap ? 2 * h->crc_rows_cap : 16;
+      uint32_t*      nd  = nullptr;
+      if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
+          (h->d_crc_mult && hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess)) {
+        (void)hipFree(nd);
+        set_error("sch decode: device allocation of the CRC multiplier table failed");
+        return 0xffffffffu;
+      }
+      (void)hipFree(h->d_crc_mult);
+      h->d_crc_mult   = nd;
+      h->crc_rows_cap = cap;
+    }
+    uint32_t m[256];
+    rm::tb_crc_multipliers(tbs_bits, CRC24A, m);
+    if (hipMemcpy(h->d_crc_mult + (size_t)row * 256, m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("sch decode: upload of the CRC multiplier table failed");
+      return 0xffffffffu;
+    }
+    h->crc_row[tbs_bits] = row;
+    return row;
+  };
   // pass 2: jobs and descriptors in launch order; per transport block the CRC job with the two runs of verdicts that are its code blocks
   size_t n_crc = 0;
   for (uint32_t t = 0; t < n_tb; t++) {
@@ -293,7 +327,11 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
       descs[j] = {slot * (uint32_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE, tb.data_offset + i * rlen / 8, (i + 1 == cs.C) ? K / 8 : rlen / 8, 0};
       g.max_in = std::max(g.max_in, n_e2);
     }
-    tbj[n_crc++] = {tb.data_offset, cs.tbs, {plan[t].start[0], plan[t].start[1]}, {plan[t].pend[0], plan[t].pend[1]}, plan[t].pend[0] + plan[t].pend[1]};
+    tbj[n_crc++] = {tb.data_offset, cs.tbs, {plan[t].start[0], plan[t].start[1]}, {plan[t].pend[0], plan[t].pend[1]}, plan[t].pend[0] + plan[t].pend[1],
+                    crc_row_of(cs.tbs)};
+    if (tbj[n_crc - 1].mult == 0xffffffffu) {
+      return SRSRAN_ERROR;
+    }
   }
   if (n || n_crc) {
     PHY_HIP_CHECK(hipMemcpyAsync(base, hb, o_tbj + n_crc * sizeof(rm::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
@@ -326,7 +364,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   }
   // transport-block CRC (sch.c:473-477,540-560) of the blocks whose code blocks are all good, straight behind the decoders
   if (n_crc) {
-    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)n_crc, CRC24A, d_ok, d_tbr, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)n_crc, CRC24A, d_ok, h->d_crc_mult, d_tbr, st), SRSRAN_ERROR);
   }
   if (n || n_crc) {
     PHY_HIP_CHECK(hipMemcpyAsync(hb + o_noi, base + o_noi, o_tbr + n_crc * sizeof(rm::TbCrcResult) - o_noi, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);

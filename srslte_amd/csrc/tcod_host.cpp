@@ -335,48 +335,25 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
     set_error("sch encode: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  hipStream_t                 st = (hipStream_t)stream;
-  std::vector<tcod::TbCbJob>  cbs;
-  std::vector<tcod::TbCrcJob> crcs(n_tb);
+  hipStream_t st = (hipStream_t)stream;
+  // Two passes with nothing allocated per code block (32 k of them per call in the benches): pass 1 segments and validates the transport
+  // blocks and counts the code blocks, pass 2 writes the jobs straight into the pinned image of the device array.  Interleaver parameters and
+  // rate-matching tables are looked up once per (block size, rv) of a transport block, not once per code block.
+  std::vector<srsran_cbsegm_t> seg(n_tb);
+  size_t                       n_cb = 0;
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
-    srsran_cbsegm_t        cs;
-    if (srsran_cbsegm(&cs, tb.tbs) || tb.Qm == 0 || tb.rv > 3 || (tb.tbs & 7) || tb.tbs == 0 || tb.nof_e_bits % tb.Qm) {
+    if (srsran_cbsegm(&seg[t], tb.tbs) || tb.Qm == 0 || tb.rv > 3 || (tb.tbs & 7) || tb.tbs == 0 || tb.nof_e_bits % tb.Qm) {
       set_error("sch encode: transport block %u: invalid tbs / Qm / rv / nof_e_bits", t);
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
-    if (cs.F) {
+    if (seg[t].F) {
       fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // sch.c:249-252
       return SRSRAN_ERROR_INVALID_INPUTS;
     }
-    crcs[t] = {tb.data_offset, tb.tbs / 8};
-    // sch.c:254-330: bits per block and rate-matched lengths
-    const uint32_t Gp = tb.nof_e_bits / tb.Qm, gamma = Gp % cs.C;
-    uint32_t       src = 8 * tb.data_offset, wp = tb.e_offset;
-    for (uint32_t i = 0; i < cs.C; i++) {
-      tcod::TbCbJob j{};
-      j.K             = i < cs.C2 ? cs.K2 : cs.K1; // sch.c:284-290: the transmit side puts the C2 smaller blocks first (the receive side, sch.c:392, the C1 larger ones; valid LTE block sizes never mix the two)
-      const uint32_t rlen = cs.C == 1 ? j.K : j.K - 24; // bits of the block without its own CRC
-      const bool     last = i + 1 == cs.C;
-      j.src_bit       = src;
-      j.n_src_bits    = last ? rlen - 24 : rlen; // the last block ends with the 24 transport-block CRC bits
-      j.tb_crc        = last ? t : 0xffffffffu;
-      j.crc24b        = cs.C > 1 ? 1u : 0u;
-      j.E             = tb.Qm * (Gp / cs.C) + ((i <= cs.C - gamma - 1) ? 0u : tb.Qm); // sch.c:296-300
-      j.out_bit       = wp;
-      if (!qpp_params(j.K, &j.f1, &j.f2)) {
-        return SRSRAN_ERROR_INVALID_INPUTS;
-      }
-      j.table = rm::device_fwd_table(j.K, tb.rv, &j.table_len);
-      if (!j.table) {
-        return SRSRAN_ERROR;
-      }
-      src += j.n_src_bits;
-      wp += j.E;
-      cbs.push_back(j);
-    }
+    n_cb += seg[t].C;
   }
-  const size_t bytes = cbs.size() * sizeof(tcod::TbCbJob) + n_tb * (sizeof(tcod::TbCrcJob) + 4) + 64;
+  const size_t bytes = n_cb * sizeof(tcod::TbCbJob) + n_tb * (sizeof(tcod::TbCrcJob) + 4) + 64;
   if (h->pending) {
     PHY_HIP_CHECK(hipEventSynchronize(h->done), SRSRAN_ERROR);
     h->pending = false;
@@ -390,18 +367,76 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
     PHY_HIP_CHECK(hipHostMalloc(&h->h_scratch, bytes * 2), SRSRAN_ERROR);
     h->cap = bytes * 2;
   }
-  uint8_t* hb = static_cast<uint8_t*>(h->h_scratch);
-  memcpy(hb, cbs.data(), cbs.size() * sizeof(tcod::TbCbJob));
-  memcpy(hb + cbs.size() * sizeof(tcod::TbCbJob), crcs.data(), n_tb * sizeof(tcod::TbCrcJob));
+  uint8_t* hb   = static_cast<uint8_t*>(h->h_scratch);
+  auto*    cbs  = reinterpret_cast<tcod::TbCbJob*>(hb);
+  auto*    crcs = reinterpret_cast<tcod::TbCrcJob*>(hb + n_cb * sizeof(tcod::TbCbJob));
+  struct KInfo { // what every code block of one size and rv shares; the last look-up is kept (a batch is mostly one block size)
+    uint32_t        K = 0, rv = 0xffffffffu, f1 = 0, f2 = 0, table_len = 0;
+    const uint16_t* table = nullptr;
+  };
+  KInfo cache[2];
+  int  err  = SRSRAN_SUCCESS;
+  auto info = [&](uint32_t K, uint32_t rv, int slot) -> const KInfo* {
+    KInfo& c = cache[slot];
+    if (c.K != K || c.rv != rv) {
+      c.K  = K;
+      c.rv = 0xffffffffu; // (not valid until both look-ups have succeeded)
+      if (!qpp_params(K, &c.f1, &c.f2)) {
+        err = SRSRAN_ERROR_INVALID_INPUTS;
+        return nullptr;
+      }
+      c.table = rm::device_fwd_table(K, rv, &c.table_len);
+      if (!c.table) {
+        err = SRSRAN_ERROR;
+        return nullptr;
+      }
+      c.rv = rv;
+    }
+    return &c;
+  };
+  size_t at = 0;
+  for (uint32_t t = 0; t < n_tb; t++) {
+    const srsran_hip_tb_t& tb = tbs[t];
+    const srsran_cbsegm_t& cs = seg[t];
+    crcs[t]                   = {tb.data_offset, tb.tbs / 8};
+    // sch.c:254-330: bits per block and rate-matched lengths
+    const uint32_t Gp = tb.nof_e_bits / tb.Qm, gamma = Gp % cs.C;
+    uint32_t       src = 8 * tb.data_offset, wp = tb.e_offset;
+    for (uint32_t i = 0; i < cs.C; i++) {
+      // sch.c:284-290: the transmit side puts the C2 smaller blocks first (the receive side, sch.c:392, the C1 larger ones; valid LTE block sizes never mix the two)
+      const bool   small = i < cs.C2;
+      const KInfo* ki    = info(small ? cs.K2 : cs.K1, tb.rv, small ? 1 : 0);
+      if (!ki) {
+        return err;
+      }
+      tcod::TbCbJob  j{};
+      j.K                 = ki->K;
+      const uint32_t rlen = cs.C == 1 ? j.K : j.K - 24; // bits of the block without its own CRC
+      const bool     last = i + 1 == cs.C;
+      j.src_bit           = src;
+      j.n_src_bits        = last ? rlen - 24 : rlen; // the last block ends with the 24 transport-block CRC bits
+      j.tb_crc            = last ? t : 0xffffffffu;
+      j.crc24b            = cs.C > 1 ? 1u : 0u;
+      j.E                 = tb.Qm * (Gp / cs.C) + ((i <= cs.C - gamma - 1) ? 0u : tb.Qm); // sch.c:296-300
+      j.out_bit           = wp;
+      j.f1                = ki->f1;
+      j.f2                = ki->f2;
+      j.table             = ki->table;
+      j.table_len         = ki->table_len;
+      src += j.n_src_bits;
+      wp += j.E;
+      cbs[at++] = j;
+    }
+  }
   uint8_t* db = static_cast<uint8_t*>(h->d_scratch);
-  PHY_HIP_CHECK(hipMemcpyAsync(db, hb, cbs.size() * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipMemcpyAsync(db, hb, n_cb * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
   tcod::TbParams p{};
   p.data   = d_data;
   p.e_bits = d_e_bits;
   p.cbs    = reinterpret_cast<const tcod::TbCbJob*>(db);
-  p.tbs    = reinterpret_cast<const tcod::TbCrcJob*>(db + cbs.size() * sizeof(tcod::TbCbJob));
-  p.tb_crc = reinterpret_cast<uint32_t*>(db + cbs.size() * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob));
-  p.n_cb   = (uint32_t)cbs.size();
+  p.tbs    = reinterpret_cast<const tcod::TbCrcJob*>(db + n_cb * sizeof(tcod::TbCbJob));
+  p.tb_crc = reinterpret_cast<uint32_t*>(db + n_cb * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob));
+  p.n_cb   = (uint32_t)n_cb;
   p.n_tb   = n_tb;
   // the code blocks OR their partial bytes into the output: clear every transport block's range first (adjacent ranges merged)
   std::vector<std::pair<uint32_t, uint32_t>> rng;

@@ -75,6 +75,7 @@ struct CbFin {       // one code block that has just been through the decoder
 };
 struct TbFin {
   uint32_t first_cb, C, Kp, L_cb, L_tb, tbs, payload_off;
+  uint32_t mult; // row of the CRC multiplier table (tb_finish_multipliers) for this block's chunk size and CRC
 };
 struct TbFinRes {
   int32_t all_decoded; // every code block of the transport block has its flag set
@@ -83,8 +84,13 @@ struct TbFinRes {
 // flag = (iterations != 0) && !all_zeros (:633-639); flagged blocks are packed MSB first into their data row (:650-652)
 hipError_t launch_cb_finish(const uint8_t* d_msg, uint32_t msg_stride, const CbFin* d_jobs, const int* d_n_iter, uint32_t n, uint8_t* d_flags,
                             uint8_t* d_cb_data, uint32_t data_stride, hipStream_t stream);
+// d_mult: rows of 256 lane multipliers, one per (chunk size, CRC order) of the launch
 hipError_t launch_tb_finish(const uint8_t* d_cb_data, uint32_t data_stride, const uint8_t* d_flags, const TbFin* d_jobs, uint32_t n, uint8_t* d_payload,
-                            TbFinRes* d_res, hipStream_t stream);
+                            const uint32_t* d_mult, TbFinRes* d_res, hipStream_t stream);
+// The kernel gives each of its 256 lanes `chunk` = ceil(bytes / 256) bytes of the payload PADDED IN FRONT with zeros (they do not change a CRC that
+// starts at zero), so that lane l always has (255 - l) * chunk bytes behind it: out[l] = x^(8 chunk (255 - l)) mod g.
+uint32_t tb_finish_chunk(uint32_t tbs_bits);
+void     tb_finish_multipliers(uint32_t chunk, uint32_t order, uint32_t out[256]);
 
 } // namespace nrsch
 } // namespace phyhip

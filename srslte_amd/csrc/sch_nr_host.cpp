@@ -128,6 +128,10 @@ struct srsran_hip_sch_nr {
   size_t        tbf_cap = 0;
   nrsch::TbFinRes *d_res = nullptr, *h_res = nullptr;
   size_t           res_cap = 0;
+  // transport-block CRC: one row of 256 lane multipliers per (chunk size, CRC order) seen so far (nrsch::tb_finish_multipliers)
+  std::map<uint32_t, uint32_t> crc_row; // chunk | order << 24 -> row
+  uint32_t*                    d_crc_mult = nullptr;
+  uint32_t                     crc_rows_cap = 0;
   // transmit side
   uint8_t*      d_cw = nullptr; // max_cb x CW_STRIDE code words (one bit per byte, filler marks kept)
   nrsch::TbEnc *d_tbe = nullptr, *h_tbe = nullptr;
@@ -179,11 +183,44 @@ extern "C" void srsran_hip_sch_nr_free(srsran_hip_sch_nr_t* h)
   (void)hipFree(h->d_cbf), (void)hipHostFree(h->h_cbf);
   (void)hipFree(h->d_tbf), (void)hipHostFree(h->h_tbf);
   (void)hipFree(h->d_res), (void)hipHostFree(h->h_res);
+  (void)hipFree(h->d_crc_mult);
   (void)hipFree(h->d_cw);
   (void)hipFree(h->d_tbe), (void)hipHostFree(h->h_tbe);
   (void)hipFree(h->d_cbe), (void)hipHostFree(h->h_cbe);
   (void)hipFree(h->d_tbcrc);
   delete h;
+}
+
+// row of the CRC multiplier table for a transport block: computed and uploaded the first time its (chunk size, CRC order) is seen
+static uint32_t crc_row_of(srsran_hip_sch_nr_t* h, uint32_t tbs_bits, uint32_t order)
+{
+  const uint32_t chunk = nrsch::tb_finish_chunk(tbs_bits), key = chunk | (order << 24);
+  auto           it    = h->crc_row.find(key);
+  if (it != h->crc_row.end()) {
+    return it->second;
+  }
+  const uint32_t row = (uint32_t)h->crc_row.size();
+  if (row >= h->crc_rows_cap) {
+    const uint32_t cap = h->crc_rows_cap ? 2 * h->crc_rows_cap : 16;
+    uint32_t*      nd  = nullptr;
+    if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
+        (h->d_crc_mult && hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess)) {
+      (void)hipFree(nd);
+      set_error("sch_nr decode: device allocation of the CRC multiplier table failed");
+      return 0xffffffffu;
+    }
+    (void)hipFree(h->d_crc_mult);
+    h->d_crc_mult   = nd;
+    h->crc_rows_cap = cap;
+  }
+  uint32_t m[256];
+  nrsch::tb_finish_multipliers(chunk, order, m);
+  if (hipMemcpy(h->d_crc_mult + (size_t)row * 256, m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("sch_nr decode: upload of the CRC multiplier table failed");
+    return 0xffffffffu;
+  }
+  h->crc_row[key] = row;
+  return row;
 }
 
 extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
@@ -331,10 +368,14 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
       return SRSRAN_ERROR;
     }
     for (uint32_t t = 0; t < n_tb; t++) {
-      h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset};
+      h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset,
+                                 crc_row_of(h, cfg[t].A, cfg[t].L_tb)};
+      if (h->h_tbf[t].mult == 0xffffffffu) {
+        return SRSRAN_ERROR;
+      }
     }
     PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_res, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMemcpyAsync(h->h_flags + cb_lo, h->d_flags + cb_lo, cb_hi - cb_lo, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
@@ -359,10 +400,14 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
     return SRSRAN_ERROR;
   }
   for (uint32_t t = 0; t < n_tb; t++) {
-    h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset};
+    h->h_tbf[t] = nrsch::TbFin{tbs[t].first_cb, cfg[t].C, cfg[t].Kp, cfg[t].L_cb, cfg[t].L_tb, cfg[t].A, tbs[t].payload_offset,
+                               crc_row_of(h, cfg[t].A, cfg[t].L_tb)};
+    if (h->h_tbf[t].mult == 0xffffffffu) {
+      return SRSRAN_ERROR;
+    }
   }
   PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_res, st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
   for (uint32_t t = 0; t < n_tb; t++) {

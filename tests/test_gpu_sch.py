@@ -295,6 +295,12 @@ def test_harq_retransmission_and_errors(hiplib):
     assert res[0].crc_ok == capi.SRSRAN_SUCCESS and np.all(cb_crc == 1)
     assert np.array_equal(data[:tbs // 8 + 3], payload)
     assert abs(res[0].avg_iterations - o_avg2) < 1e-6
+    # a third call finds every code block decoded: no decoder is launched, the transport-block CRC runs over the bytes that are still in
+    # d_data and passes again, no iteration is counted.  (Not a case the reference is ever in -- a decoded block's soft buffer is reset --
+    # and not comparable with it: sch.c:478-485 saves a block's good code blocks for the next round only when the block FAILED.)
+    res, data3, _ = _decode(S, capi, lib, h, tb, e2, softbuf, cb_crc, tbs // 8 + 6, 6, d_data)
+    assert res[0].crc_ok == capi.SRSRAN_SUCCESS and res[0].avg_iterations == 0.0 and res[0].nof_cb == s["C"]
+    assert np.array_equal(data3, data) and np.all(cb_crc == 1)
     # errors: filler bits (non-standard TBS), bad arguments
     d = S.DeviceBuffer(1 << 20)
     r = (capi.HipTbResult * 1)()

@@ -9,6 +9,7 @@
 #include "tables/nr_ldpc_lsindex.h"
 
 #include <atomic>
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -242,11 +243,20 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
     PHY_HIP_CHECK(hipMemcpy(h->d_col_edges, ce.data(), ce.size() * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
   }
   {
-    // one slab of check-to-variable messages per resident workgroup slot and code word it holds (<= 256 / Z words)
+    // slabs of check-to-variable messages, one per workgroup slot and code word it holds (<= 256 / Z words)
     const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
     const size_t cpb = (size_t)choose_cpb(ls, (size_t)d.N * ls * (dtype == ldpc::DT_F32 ? 4 : 2));
     size_t       slots = ((size_t)(max_nof_cw ? max_nof_cw : 1) + cpb - 1) / cpb;
-    slots              = slots < 2048 ? slots : 2048; // resident workgroups (256 CUs x at most 4) and, for early stop, as many queued behind them
+    // One slab per code word of the largest batch, as far as 4 GiB go (BG1 Z = 384, int8: 121 KB per word, 2 GB for 16,384 words).  Round 2 measured
+    // (16,384 words, 20 iterations, 1280 workgroups resident at a time): 1280 slabs rewritten by persistent workgroups 25.4 ms, 4096 slabs 23.7,
+    // 8192 22.5, 16,384 -- every word on a slab nobody has touched since the last launch -- 22.0 ms.  Same arithmetic, same bytes at the L2
+    // boundary; what differs is where they go: 155 MB of slabs rewritten in place stay in the 256 MB Infinity Cache, 2 GB of them stream
+    // through HBM (profiles/r02_ldpc_experiments.txt).
+    {
+      const size_t per_slot = cpb * d.E * ls * es;
+      const size_t cap      = std::max<size_t>(1, ((size_t)4 << 30) / per_slot);
+      slots                 = slots < cap ? slots : cap;
+    }
     h->cpb             = (int)cpb;
     h->slots           = (int)slots;
     PHY_HIP_CHECK(hipMalloc(&h->d_c2v, slots * cpb * d.E * ls * es), SRSRAN_ERROR);

@@ -345,6 +345,12 @@ int grid_slots_packed(const Params& p)
     // early stop: code words take different times, and workgroups queued behind the resident ones even the load out
     // (BG1 Z = 384, 8192 words at 3 iterations on average: 1280 slots 2.08 ms, 1536 1.95 ms, 2048 1.90 ms)
     slots = p.max_slots;
+  } else if (2 * p.max_slots >= 5 * slots) {
+    // Fixed iterations: every slab slot the object owns as well, once that is 2.5 x the resident workgroups or more.  Measured, not
+    // expected (BG1 Z = 384, 16,384 words, 20 iterations, 1280 resident): 1280 workgroups of 12.8 words 25.4 ms, 2560 25.1, 3072 24.2,
+    // 3328 ... 4096 23.5 - 23.9 ms -- the same arithmetic per word, 7 % faster in short-lived workgroups on fresh slabs than in persistent
+    // ones that rewrite theirs (two half-size launches on two streams show the same: 24.3 ms; two processes on one GPU: 23.1 ms each way).
+    slots = p.max_slots;
   }
   slots            = slots > p.max_slots ? p.max_slots : slots;
   if (const char* e = getenv("LDPC_SLOTS")) { // development knob

@@ -70,8 +70,8 @@ SRSRAN_API int  srsran_hip_tdec_batch_last_llr(srsran_hip_tdec_batch_t* h, int16
 /* ---- LDPC: srsran_ldpc_decoder_decode_c (ldpc_decoder.c:657-685, int8 layered) over n_cw words ---- */
 typedef struct srsran_hip_ldpc_batch srsran_hip_ldpc_batch_t;
 
-/* Device memory of an object: one slab of check-to-variable messages per code word of the largest batch, edges x ls bytes each for the int8
- * decoders (121 KB for BG1 ls = 384: 2 GB for max_nof_cw = 16,384), capped at 4 GiB per object -- words beyond the cap share slabs. */
+/* Device memory of an object: up to 2048 slabs of check-to-variable messages, edges x ls bytes per code word each for the int8 decoders
+ * (121 KB for BG1 ls = 384), one per workgroup of a launch. */
 SRSRAN_API int  srsran_hip_ldpc_batch_create(srsran_hip_ldpc_batch_t** h, srsran_basegraph_t bg, uint16_t ls,
                                              float scaling_fctr, uint32_t max_nof_iter, uint32_t max_nof_cw);
 /* type: SRSRAN_LDPC_DECODER_F (float LLRs, ldpc_dec_f.c), _S (int16, ldpc_dec_s.c) or the int8 family _C / _C_AVX2 /

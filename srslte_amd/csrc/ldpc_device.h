@@ -28,7 +28,8 @@ struct Params {
   int             max_slots; // c2v slabs behind c2v_ws: upper bound of the grid
   int             dtype;
   float           sf_f;     // scaling factor of the float decoder
-  void*           c2v_ws;   // max_slots x cpb x n_edges x Z check-to-variable messages (HBM, L2 / Infinity Cache resident)
+  void*           c2v_ws;   // max_slots x cpb x n_edges x Z check-to-variable messages: one slab per workgroup of the launch
+  unsigned int*   work_counter; // packed kernel: zeroed before the launch; workgroups take their next code words from it (nullptr: static shares)
   void*           soft_out; // optional: n_cw x bgN*Z a-posteriori soft bits (parity aid)
   // flooded schedule (int8 only): edges of every variable node in row order over ALL rows; word = edge index | shift << 16
   int             flood;

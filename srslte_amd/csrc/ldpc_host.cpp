@@ -130,7 +130,8 @@ struct srsran_hip_ldpc_batch {
   // x^((Z-1-c) bgK) mod g per generator used with this object (CRC early stop): one device table each, filled on first use and kept --
   // a batch that alternates CRC24A / CRC24B / CRC16 code words (sch_nr.c:606-619) never re-uploads or synchronises
   std::map<uint64_t, uint32_t*> crc_mult;
-  void*    d_c2v    = nullptr;     // int16 / float: check-to-variable messages, max_cw x E x Z
+  void*    d_c2v    = nullptr;     // check-to-variable messages: slots x cpb slabs of E x Z messages
+  unsigned int* d_work = nullptr;  // packed kernel: the counter its workgroups take their code words from
   uint32_t max_cw   = 0;
   std::vector<uint16_t> row_start;
   int* d_row_start = nullptr;
@@ -247,19 +248,11 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
     const size_t es  = dtype == ldpc::DT_F32 ? 4 : (dtype == ldpc::DT_I16 ? 2 : 1);
     const size_t cpb = (size_t)choose_cpb(ls, (size_t)d.N * ls * (dtype == ldpc::DT_F32 ? 4 : 2));
     size_t       slots = ((size_t)(max_nof_cw ? max_nof_cw : 1) + cpb - 1) / cpb;
-    // One slab per code word of the largest batch, as far as 4 GiB go (BG1 Z = 384, int8: 121 KB per word, 2 GB for 16,384 words).  Round 2 measured
-    // (16,384 words, 20 iterations, 1280 workgroups resident at a time): 1280 slabs rewritten by persistent workgroups 25.4 ms, 4096 slabs 23.7,
-    // 8192 22.5, 16,384 -- every word on a slab nobody has touched since the last launch -- 22.0 ms.  Same arithmetic, same bytes at the L2
-    // boundary; what differs is where they go: 155 MB of slabs rewritten in place stay in the 256 MB Infinity Cache, 2 GB of them stream
-    // through HBM (profiles/r02_ldpc_experiments.txt).
-    {
-      const size_t per_slot = cpb * d.E * ls * es;
-      const size_t cap      = std::max<size_t>(1, ((size_t)4 << 30) / per_slot);
-      slots                 = slots < cap ? slots : cap;
-    }
+    slots = slots < 2048 ? slots : 2048; // resident workgroups (256 CUs x at most 5 ... 8) with room to spare; words are handed out by a counter
     h->cpb             = (int)cpb;
     h->slots           = (int)slots;
     PHY_HIP_CHECK(hipMalloc(&h->d_c2v, slots * cpb * d.E * ls * es), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipMalloc(&h->d_work, sizeof(unsigned int)), SRSRAN_ERROR);
   }
   *hh = h;
   return SRSRAN_SUCCESS;
@@ -278,6 +271,7 @@ extern "C" void srsran_hip_ldpc_batch_free(srsran_hip_ldpc_batch_t* h)
     hipFree(kv.second);
   }
   hipFree(h->d_c2v);
+  hipFree(h->d_work);
   delete h;
 }
 
@@ -357,6 +351,7 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.dtype      = h->dtype;
   p.sf_f       = h->sf_f;
   p.c2v_ws     = h->d_c2v;
+  p.work_counter = nullptr;
   p.soft_out   = d_soft;
   p.crc_poly   = 0;
   p.crc_order  = 0;
@@ -423,6 +418,8 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
     p.cpb       = pcpb;
     p.max_slots = cap / pcpb;
     p.packed    = 1;
+    p.work_counter = h->d_work;
+    PHY_HIP_CHECK(hipMemsetAsync(h->d_work, 0, sizeof(unsigned int), (hipStream_t)stream), SRSRAN_ERROR);
   }
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;

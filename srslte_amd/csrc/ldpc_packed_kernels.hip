@@ -174,7 +174,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   const cint_p ec = (cint_p)p.edges, row_start = (cint_p)p.row_start;
   const unsigned short m9 = (unsigned short)p.sf_m9;
 
-  for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
+  // Code words are handed out by a counter, not in fixed shares: a workgroup takes words blockIdx.x * cpb ... first and asks for more when
+  // it is done.  The CUs do not all run at the same speed (with 1280 persistent workgroups and 12.8 words each by a fixed stride the launch
+  // took 25.4 ms for 16,384 words, with one workgroup per word -- the dispatcher hands the next word to whoever is free -- 22.1 ms; same
+  // code, same bytes, and a fresh slab per word in the persistent version changes nothing: profiles/r02_ldpc_experiments.txt).
+  __shared__ int s_next;
+  for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw;) {
     const int  cw      = cw0 + cwl;
     const bool present = (cwl < p.cpb) && (cw < p.n_cw);
     const int  cwi     = (present && p.cw_map) ? (int)p.cw_map[cw] : cw; // row of the LLR / message arrays
@@ -312,6 +317,16 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
       }
     }
+    // the next share (the barrier at the top of the loop keeps s_next from being overwritten before everybody has read it)
+    if (p.work_counter) {
+      if (t == 0) {
+        s_next = (int)((unsigned)gridDim.x * (unsigned)p.cpb + atomicAdd(p.work_counter, (unsigned)p.cpb));
+      }
+      __syncthreads();
+      cw0 = s_next;
+    } else {
+      cw0 += (int)gridDim.x * p.cpb;
+    }
   }
 }
 
@@ -341,16 +356,11 @@ int grid_slots_packed(const Params& p)
   per_cu           = per_cu < by_lds ? per_cu : by_lds;
   per_cu           = per_cu < 1 ? 1 : per_cu;
   int slots        = cus * per_cu;
-  if (p.crc_order) {
-    // early stop: code words take different times, and workgroups queued behind the resident ones even the load out
-    // (BG1 Z = 384, 8192 words at 3 iterations on average: 1280 slots 2.08 ms, 1536 1.95 ms, 2048 1.90 ms)
-    slots = p.max_slots;
-  } else if (2 * p.max_slots >= 5 * slots) {
-    // Fixed iterations: every slab slot the object owns as well, once that is 2.5 x the resident workgroups or more.  Measured, not
-    // expected (BG1 Z = 384, 16,384 words, 20 iterations, 1280 resident): 1280 workgroups of 12.8 words 25.4 ms, 2560 25.1, 3072 24.2,
-    // 3328 ... 4096 23.5 - 23.9 ms -- the same arithmetic per word, 7 % faster in short-lived workgroups on fresh slabs than in persistent
-    // ones that rewrite theirs (two half-size launches on two streams show the same: 24.3 ms; two processes on one GPU: 23.1 ms each way).
-    slots = p.max_slots;
+  if (!p.work_counter) {
+    // static shares (no counter): with early stop code words take different times, and workgroups queued behind the resident ones even the load
+    // out (BG1 Z = 384, 8192 words at 3 iterations on average: 1280 slots 2.08 ms, 1536 1.95 ms, 2048 1.90 ms); with fixed iterations more,
+    // shorter-lived workgroups do the same for CUs of different speed (16,384 words: 1280 workgroups 25.4 ms, 4096 23.7, 16,384 22.1)
+    slots = (p.crc_order || 2 * p.max_slots >= 5 * slots) ? p.max_slots : slots;
   }
   slots            = slots > p.max_slots ? p.max_slots : slots;
   if (const char* e = getenv("LDPC_SLOTS")) { // development knob

@@ -53,9 +53,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    # 5040 subframes = 65,520 code blocks = 8190 waves of 8 blocks: four full rounds of the 2048 waves the turbo kernel keeps resident
-    # (4096 subframes = 3.25 rounds leave the chip three quarters empty for the last round: 30.2 instead of 33.0 Gbit/s)
-    ap.add_argument("--sf", type=int, default=5040, help="subframes per rank per step")
+    # 10,080 subframes = 131,040 code blocks = 16,380 waves of 8 blocks: eight full rounds of the 2048 waves the turbo kernel keeps resident.
+    # The CUs do not finish their rounds together, so the end of a launch runs on a part of the chip: 4096 subframes (3.25 rounds) 30.2 Gbit/s,
+    # 5040 (4 rounds) 33.5, 10,080 (8 rounds) 34.5, 20,160 (16 rounds) 35.2 on one box (DESIGN.md par. 3.2)
+    ap.add_argument("--sf", type=int, default=10080, help="subframes per rank per step")
     ap.add_argument("--cpu-sample", type=int, default=48, help="code blocks decoded on the CPU for baseline + parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip every cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no extra.ldpc / cellsearch / uplink)")

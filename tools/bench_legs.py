@@ -264,7 +264,7 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
         return None
     cap_bytes = frame * 8
     tj = load_traffic()
-    tr, src = traffic_of(tj, "pss_block_kernel", caps, "captures_per_launch")
+    tr, src = traffic_of(tj, "pss_wave_kernel", caps, "captures_per_launch")
     out = {"metric": "cell search Msamples/s (10 ms captures at 30.72 Msps, 3 PSS hypotheses + SSS = 504 PCI hypotheses per capture)",
            "value": ctx.world * caps * frame * steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": "f32", "scaling": "weak",

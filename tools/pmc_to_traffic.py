@@ -7,10 +7,10 @@ import glob, json, os, sqlite3, sys
 from collections import defaultdict
 
 UNITS = {  # kernel name fragment -> (key in the JSON, units per launch key, units per launch of bench.py's default shapes)
-    "tdec_win_kernel<8, phyhip::turbo::Ar16, false>": ("tdec_win_kernel", "code_blocks_per_launch", 65520),
-    "ofdm_kernel<phyhip::fft::Plan<2048": ("ofdm_kernel", "subframes_per_launch", 5040),
+    "tdec_win_kernel<8, phyhip::turbo::Ar16, false>": ("tdec_win_kernel", "code_blocks_per_launch", 131040),
+    "ofdm_kernel<phyhip::fft::Plan<2048": ("ofdm_kernel", "subframes_per_launch", 10080),
     "ldpc_packed_kernel<false>": ("ldpc_packed_kernel", "code_words_per_launch", 16384),
-    "pss_block_kernel": ("pss_block_kernel", "captures_per_launch", 256),
+    "pss_wave_kernel": ("pss_wave_kernel", "captures_per_launch", 256),
 }
 
 

@@ -298,11 +298,14 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
 
 # ------------------------------------------------------------------------------------------------ configs[3]: multi-UE uplink
 
-def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=46, snr=19.0, iters=8):
+def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, iters=8):
     """64 independent 20 MHz UEs per GPU x `sf` subframes each, every stage of the PUSCH receive path that is on the hot path:
     OFDM demodulation -> single-tap equaliser -> SC-FDMA transform de-precoding (1200-point IDFT) -> 64-QAM soft demodulation +
     descrambling -> rate de-matching + turbo decoding with CRC early stop + transport-block CRC.  The signal comes from the library's
-    own transmit side; channel estimation (out of scope) is replaced by the known flat channel."""
+    own transmit side; channel estimation (out of scope) is replaced by the known flat channel.
+    sf = 184: 64 x 184 x 11 code blocks are eight rounds of the 2048 waves the early-stop decoder keeps resident.  The end of a launch runs
+    on a part of the chip (waves take 2 ... 8 half iterations, CUs differ in speed): 46 subframes (two rounds) 44.8 Gbit/s, 92 50.6, 184 53.6
+    on one box (tools/dbg/uplink_sf.py)."""
     import torch
 
     import srslte_amd as S

@@ -351,7 +351,8 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
   p.dtype      = h->dtype;
   p.sf_f       = h->sf_f;
   p.c2v_ws     = h->d_c2v;
-  p.work_counter = nullptr;
+  p.work_counter = h->d_work; // code words are handed out by a counter (both kernels)
+  PHY_HIP_CHECK(hipMemsetAsync(h->d_work, 0, sizeof(unsigned int), (hipStream_t)stream), SRSRAN_ERROR);
   p.soft_out   = d_soft;
   p.crc_poly   = 0;
   p.crc_order  = 0;
@@ -418,8 +419,6 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
     p.cpb       = pcpb;
     p.max_slots = cap / pcpb;
     p.packed    = 1;
-    p.work_counter = h->d_work;
-    PHY_HIP_CHECK(hipMemsetAsync(h->d_work, 0, sizeof(unsigned int), (hipStream_t)stream), SRSRAN_ERROR);
   }
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;

@@ -244,7 +244,9 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : PO
   const int* row_start = graph;
   const int* edges     = graph + 48;
 
-  for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw; cw0 += gridDim.x * p.cpb) { // uniform trip count per workgroup
+  // code words are handed out by a counter when the host provides one (Params::work_counter, see ldpc_packed_kernels.hip): fixed shares wait for the slowest CU
+  __shared__ int s_next;
+  for (int cw0 = blockIdx.x * p.cpb; cw0 < p.n_cw;) {
   const int  cw     = cw0 + cwl;
   const bool present = (cwl < p.cpb) && (cw < p.n_cw);
   const int  cwi     = (present && p.cw_map) ? (int)p.cw_map[cw] : cw; // row of the LLR / message arrays
@@ -427,6 +429,15 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(ES ? 4 : PO
       }
     }
   }
+  if (p.work_counter) { // (the barrier at the top of the loop keeps s_next from being overwritten before everybody has read it)
+    if (threadIdx.x == 0) {
+      s_next = (int)((unsigned)gridDim.x * (unsigned)p.cpb + atomicAdd(p.work_counter, (unsigned)p.cpb));
+    }
+    __syncthreads();
+    cw0 = s_next;
+  } else {
+    cw0 += (int)gridDim.x * p.cpb;
+  }
   } // code words of this workgroup
 }
 
@@ -454,8 +465,8 @@ int grid_slots(const Params& p)
   per_cu           = per_cu < by_lds ? per_cu : by_lds;
   per_cu           = per_cu < 1 ? 1 : per_cu;
   int slots        = cus * per_cu;
-  if (p.crc_order) {
-    // early stop: code words take different times, and workgroups queued behind the resident ones even the load out
+  if (p.crc_order && !p.work_counter) {
+    // early stop with fixed shares: code words take different times, and workgroups queued behind the resident ones even the load out
     // (BG1 Z = 384, 8192 words at 3 iterations on average: 1280 slots 2.08 ms, 1536 1.95 ms, 2048 1.90 ms)
     slots = p.max_slots;
   }

@@ -324,3 +324,21 @@ def test_batch_crc_early_stop(hiplib, bg, Z, typ):
             assert len(seen) >= 2  # the batch really mixes early and late / failed code words
     bad = S.LdpcBatch(bg, Z, 0.8, 4, 1, capi.LDPC_S)
     assert lib.srsran_hip_ldpc_batch_run_crc(bad._h, d_llr.ptr, N, d_msg.ptr, K, 1, N, 0x1800063, 24, d_it.ptr, None) == capi.SRSRAN_ERROR_INVALID_INPUTS
+
+@pytest.mark.parametrize("bg,Z", [(0, 384), (1, 208), (0, 36), (1, 16), (0, 320)])
+def test_extreme_and_full_range_inputs(hiplib, bg, Z):
+    """channel LLRs made of nothing but the values around the decoder's special cases (-128, +-127 = infinity, +-64, +-63, 0), uniform noise over
+    the whole int8 range, and weak LLRs salted with -128: the packed kernel keeps infinity as +-64 and its bytes biased by 128 inside, none of
+    which may show (ldpc_dec_c.c:170-188, 308-315, 338-363)"""
+    import srslte_amd as S
+
+    rng = np.random.default_rng(5 + Z)
+    g = O.ldpc_graph(bg, Z)
+    n = g.bgN * Z - 2 * Z
+    llrs = np.stack([rng.choice(np.array([-128, -127, -64, -63, 63, 64, 127, 0], np.int8), n) for _ in range(4)] +
+                    [rng.integers(-128, 128, n).astype(np.int8) for _ in range(4)] +
+                    [np.where(rng.random(n) < 0.1, -128, rng.integers(-30, 31, n)).astype(np.int8) for _ in range(4)])
+    for nit in (1, 3, 10):
+        want, _ = O.ldpc_decode(bg, Z, llrs, 0.8, nit)
+        got = S.LdpcBatch(bg, Z, 0.8, nit, llrs.shape[0]).decode(llrs)
+        assert np.array_equal(np.asarray(got), np.asarray(want)), (bg, Z, nit)

@@ -1,0 +1,107 @@
+"""The reference's OWN test programs, unmodified, on top of the product library.
+
+tests/ref_link/Makefile compiles the reference's test mains and the FFT-free rest of its PHY library from the sources
+where they lie (dev container only; flags only) and links them against srslte_amd/lib/libsrsran_phy_hip.so IN PLACE OF
+ofdm.c / dft_fftw.c / dft_precoding.c / turbodecoder*.c / tc_interl_lte.c / ldpc_decoder.c / ldpc_dec_*.c / base_graph.c /
+pss.c / sss.c / find_sss.c / gen_sss.c / sync.c / cfo.c / cp.c / cexptab.c.  Each case below is a
+test line of the reference's CMake files (cited) and is judged by the reference's own pass criterion: the exit code the
+program computes from a KNOWN ANSWER (the MIB bits of signal.1.92M.dat, CFI 2 of signal.10M.dat, the DCI of
+signal.1.92M.amar.dat, the PDSCH / PMCH transport-block CRC, the loop-back error of ofdm_test, the golden code words of
+examplesBG{1,2}.dat, the PSS position / subframe / CP of sync_test).  The file tests run srsran_ofdm_rx_sf on recorded
+captures: with them OFDM rx is pinned to known answers the reference holds, not only to a float64 DFT.
+
+Data files are re-materialised from tests/golden/{sync_captures,ref_link_data}.npz (tools/gen_golden.py: the reference's
+data files as they are).  Nothing here reads /root/reference at run time.
+"""
+import re
+
+import pytest
+from ref_link_common import make_data_dir, run_program
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data_dir(tmp_path_factory, hiplib):
+    return make_data_dir(tmp_path_factory.mktemp("ref_link_data"))
+
+
+def _run(name, args, cwd, timeout=600):
+    return run_program("bin", name, args, cwd, timeout)
+
+
+# ---- dft/test/CMakeLists.txt:28-33 : loop-back RMS error < 1e-4 for 6 ... 110 PRB (ofdm_test.c:176) -------------------------
+@pytest.mark.parametrize("args", ["-r 1", "-e -r 1", "-s 0.5 -r 1", "-o 0.5 -r 1", "-N 4096 -r 1", "-e -o 0.5 -s 0.5 -N 4096 -r 1"])
+def test_ofdm_test(args, data_dir):
+    rc, out = _run("ofdm_test", args.split(), data_dir)
+    assert rc == 0, out[-2000:]
+    mse = [float(m) for m in re.findall(r"MSE=([0-9.]+)", out)]
+    assert len(mse) == 105 and max(mse) < 1e-4, out[-2000:]
+
+
+# ---- fec/turbo/test/CMakeLists.txt:45-48 (exit 0 = "Done"); plus a high-SNR line that must be error free -----------------------
+@pytest.mark.parametrize("args", ["-n 100 -s 1 -l 504 -e 1.0 -t", "-n 100 -s 1 -l 504 -e 2.0 -t", "-n 100 -s 1 -l 6144 -e 1.5 -t",
+                                  "-n 1 -s 1 -k -e 0.5"])
+def test_turbodecoder_test(args, data_dir):
+    rc, out = _run("turbodecoder_test", args.split(), data_dir)
+    assert rc == 0 and "Done" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("length", [40, 504, 1024, 6144])
+def test_turbodecoder_test_error_free_at_high_snr(length, data_dir):
+    rc, out = _run("turbodecoder_test", ("-n 30 -s 1 -l %d -e 6.0" % length).split(), data_dir)
+    assert rc == 0 and "Done" in out and "Errors" not in out, out[-2000:]
+    assert re.search(r"30/30\s+BER: 0\.00e\+00", out), out[-2000:]
+
+
+# ---- fec/ldpc/test: golden message / code-word pairs of examplesBG{1,2}.dat, exact (ldpc_dec_c_test.c:224-229) -----------------
+@pytest.mark.parametrize("bg,Z,sched", [(1, 2, 0), (1, 36, 0), (1, 208, 0), (1, 384, 0), (2, 9, 0), (2, 15, 0), (2, 208, 0), (2, 384, 0),
+                                        (1, 384, 1), (2, 208, 1)])
+def test_ldpc_dec_c_test(bg, Z, sched, data_dir):
+    rc, out = _run("ldpc_dec_c_test", ["-b%d" % bg, "-l%d" % Z, "-x%d" % sched], data_dir)
+    assert rc == 0 and "Test completed successfully" in out, out[-2000:]
+
+
+# ---- sync/test/CMakeLists.txt:69-77 : srsran_sync_find on a generated PSS/SSS subframe (sync_test.c:164-176) --------------------
+@pytest.mark.parametrize("args", ["-o 100 -c 501", "-o 400 -c 2", "-o 100 -e -c 150", "-o 400 -e -c 151", "-o 100 -p 50 -c 501",
+                                  "-o 400 -p 50 -c 500", "-o 100 -e -p 50 -c 133", "-o 400 -e -p 50 -c 123"])
+def test_sync_test(args, data_dir):
+    rc, out = _run("sync_test", args.split(), data_dir)
+    assert rc == 0 and out.strip().endswith("Ok"), out[-2000:]
+
+
+# ---- phch/test/CMakeLists.txt:433-443 : recorded captures -> srsran_ofdm_rx_sf -> reference channel decoders -> known answers ---
+def test_pbch_file_test(data_dir):
+    """MIB of signal.1.92M.dat (pbch_file_test.c:45-46,226-232: 2 ports, SFN offset 0, the 24 payload bits)"""
+    rc, out = _run("pbch_file_test", ["-i", data_dir / "signal.1.92M.dat"], data_dir)
+    assert rc == 0 and "This is the signal.1.92M.dat file" in out, out[-2000:]
+
+
+def test_pcfich_file_test(data_dir):
+    """CFI 2 with correlation > 2.8 from signal.10M.dat (pcfich_file_test.c:251-255)"""
+    rc, out = _run("pcfich_file_test", ["-c", 150, "-n", 50, "-p", 2, "-i", data_dir / "signal.10M.dat"], data_dir)
+    m = re.search(r"cfi: (\d+), distance: ([0-9.]+)", out)
+    assert rc == 0 and m and int(m.group(1)) == 2 and float(m.group(2)) > 2.8, out[-2000:]
+
+
+def test_phich_file_test(data_dir):
+    rc, out = _run("phich_file_test", ["-c", 150, "-n", 50, "-p", 2, "-i", data_dir / "signal.10M.dat"], data_dir)
+    assert rc == 0, out[-2000:]
+
+
+def test_pdcch_file_test(data_dir):
+    """the SI-RNTI DCI of signal.1.92M.amar.dat: format 1A, RIV 11, mcs 2 (pdcch_file_test.c:267-272)"""
+    rc, out = _run("pdcch_file_test", ["-c", 1, "-f", 3, "-n", 6, "-p", 1, "-i", data_dir / "signal.1.92M.amar.dat"], data_dir)
+    assert rc == 0 and "This is the file signal.1.92M.amar.dat" in out, out[-2000:]
+
+
+def test_pdsch_pdcch_file_test(data_dir):
+    """srsran_ue_dl_find_and_decode: OFDM rx -> PDCCH -> PDSCH -> reference sch.c -> srsran_tdec_* of the product -> TB CRC"""
+    rc, out = _run("pdsch_pdcch_file_test", ["-c", 1, "-f", 3, "-n", 6, "-p", 1, "-i", data_dir / "signal.1.92M.amar.dat"], data_dir)
+    assert rc == 0 and "PDSCH Decoded OK!" in out, out[-2000:]
+
+
+def test_pmch_file_test(data_dir):
+    """100 PRB (N = 1536) MBSFN subframe: srsran_ofdm_rx_sf in MBSFN mode -> PMCH -> turbo decoder -> CRC (pmch_file_test.c:216-231)"""
+    rc, out = _run("pmch_file_test", ["-i", data_dir / "pmch_100prbs_MCS2_SR0.bin"], data_dir)
+    assert rc == 0 and "PMCH Decoded OK!" in out, out[-2000:]

@@ -26,6 +26,9 @@ No reference source text is stored.
   tests/golden/sch_nr_ref.npz  NR transport blocks through the reference's blocks in the order of sch_nr.c (segmentation, CRCs, LDPC encoder,
                                rate matcher both ways, decoder with CRC early stop): LLRs in, verdicts / iterations / payload out
   tests/golden/ldpc_examples.npz  subset of the reference's golden message/code-word pairs
+  tests/golden/ref_link_data.npz  DATA files the reference's own test programs read (tests/ref_link runs those programs, unmodified,
+                               on top of the product library): phch/test/pmch_100prbs_MCS2_SR0.bin (pmch_file_test) and the ten
+                               message / code-word pairs of fec/ldpc/test/examplesBG{1,2}.dat for a few lifting sizes (ldpc_dec_c_test)
   tests/golden/sync_captures.npz  the recorded air captures the reference's own tests hold for the PSS / SSS path
                                (phch/test/signal.1.92M.dat: pbch_file_test, cell 150; signal.1.92M.amar.dat: pdcch_file_test -c 1;
                                signal.10M.dat: pcfich_file_test -c 150 -n 50) with the cell ids those tests are given
@@ -246,6 +249,33 @@ def sync_captures():
     d["cases"] = np.array(["pbch_1_92M", "amar_1_92M_sf0", "pcfich_10M"])
     np.savez_compressed(os.path.join(OUT, "sync_captures.npz"), **d)
     print("sync_captures.npz", os.path.getsize(os.path.join(OUT, "sync_captures.npz")))
+
+
+def ref_link():
+    """inputs of the reference's test programs that tests/ref_link re-materialises on the GPU box (data only)."""
+    d = {}
+    d["pmch_100prb_x"] = np.fromfile(os.path.join(REF, "src/phy/phch/test/pmch_100prbs_MCS2_SR0.bin"), dtype=np.complex64)
+    conv = lambda s: np.array([2 if c == "-" else int(c) for c in s], dtype=np.uint8)
+    for bg, sizes in ((0, (2, 36, 208, 384)), (1, (9, 15, 208, 384))):
+        lines = open(os.path.join(REF, "src/phy/fec/ldpc/test/examplesBG%d.dat" % (bg + 1))).read().split("\n")
+        sect, cur = {}, None
+        for ln in lines:
+            if ln.startswith("ls"):
+                cur = ln.strip()
+                sect[cur] = []
+            elif ln.strip() and cur:
+                sect[cur].append(ln.strip())
+        for Z in sizes:
+            for part in ("msgs", "cwds"):
+                rows = np.stack([conv(x) for x in sect["ls%d%s" % (Z, part)]])
+                assert rows.shape[0] == 10
+                # 0 / 1 / filler ('-') -> two bit planes
+                d["bg%d_z%d_%s" % (bg, Z, part)] = np.packbits(rows == 1, axis=1)
+                d["bg%d_z%d_%s_fill" % (bg, Z, part)] = np.packbits(rows == 2, axis=1)
+                d["bg%d_z%d_%s_len" % (bg, Z, part)] = np.array([rows.shape[1]], dtype=np.int32)
+    d["ldpc_sizes"] = np.array([[0, 2], [0, 36], [0, 208], [0, 384], [1, 9], [1, 15], [1, 208], [1, 384]], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "ref_link_data.npz"), **d)
+    print("ref_link_data.npz", os.path.getsize(os.path.join(OUT, "ref_link_data.npz")))
 
 
 def ldpc():
@@ -682,6 +712,6 @@ def sch_nr():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr", "sync_captures"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr", "sync_captures", "ref_link"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr, "sync_captures": sync_captures}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr, "sync_captures": sync_captures, "ref_link": ref_link}[name]()

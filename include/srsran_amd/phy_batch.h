@@ -37,6 +37,12 @@ SRSRAN_API const char* srsran_hip_build_info(void);
  * private stream again.  srsran_hip_coalesce_stats: batches launched and calls carried so far (either pointer may be NULL). */
 SRSRAN_API void srsran_hip_set_coalescing(int enable);
 SRSRAN_API void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_units);
+/* submission queues alive right now: one per kernel shape, at most 12 -- the least recently used idle one is released (streams, pinned
+ * staging, batch engine) when a new shape arrives, so a long-running process that walks through many block / lifting sizes stays bounded */
+SRSRAN_API uint32_t srsran_hip_coalesce_shapes(void);
+/* development knobs (measured kernel alternatives kept behind SRSRAN_HIP_TDEC_VARIANT / SRSRAN_HIP_PSS_VARIANT and a few sizing overrides):
+ * their environment variables are read once; this overrides one at run time (value NULL = unset).  Never needed by an application. */
+SRSRAN_API int      srsran_hip_dev_knob(const char* env_name, const char* value);
 
 /* Batch objects (every srsran_hip_*_batch_t, srsran_hip_sch_t, srsran_hip_sch_nr_t, srsran_hip_cellsearch_t ...) own device workspace
  * (decoder state, message slabs, correlation buffers): ONE stream per object at a time.  Calls on the same object are ordered by that

@@ -84,6 +84,10 @@ typedef struct SRSRAN_API {
   uint32_t F, C, K1, K2, K1_idx, K2_idx, C1, C2, tbs, L_tb, L_cb, Z;
 } srsran_cbsegm_t;
 SRSRAN_API int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs);
+/* cbsegm.h:59-67, cbsegm.c:142-150,201-285: valid turbo block size; NR (LDPC) segmentation for base graph 1 / 2 */
+SRSRAN_API bool srsran_cbsegm_cbsize_isvalid(uint32_t size);
+SRSRAN_API int  srsran_cbsegm_ldpc_bg1(srsran_cbsegm_t* s, uint32_t tbs);
+SRSRAN_API int  srsran_cbsegm_ldpc_bg2(srsran_cbsegm_t* s, uint32_t tbs);
 
 /* ---- transmit side: turbo encoder (lib/include/srsran/phy/fec/turbo/turbocoder.h:46-58, turbocoder.c:40-185) ----
  * srsran_tcod_encode: input long_cb bits (one per byte; 100 = SRSRAN_TX_NULL filler, encoded as 0 and passed through on the

@@ -234,6 +234,8 @@ def lib():
             "srsran_hip_build_info": (C.c_char_p, []),
             "srsran_hip_set_coalescing": (None, [i32]),
             "srsran_hip_coalesce_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "srsran_hip_coalesce_shapes": (C.c_uint32, []),
+            "srsran_hip_dev_knob": (C.c_int, [C.c_char_p, C.c_char_p]),
             "srsran_hip_tdec_batch_create": (i32, [C.POINTER(vp), u32, u32, i32]),
             "srsran_hip_tdec_batch_create_8bit": (i32, [C.POINTER(vp), u32, u32, i32]),
             "srsran_hip_tdec_batch_free": (None, [vp]),

@@ -3,7 +3,11 @@
 #include "hip_common.h"
 
 #include <atomic>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <vector>
 
 namespace phyhip {
 
@@ -57,11 +61,52 @@ bool device_available()
   return ok;
 }
 
+// ---- development knobs (hip_common.h)
+namespace {
+const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED"};
+std::atomic<int>  g_knob[KNOB_COUNT];
+std::atomic<bool> g_knob_read[KNOB_COUNT];
+
+int knob_parse(int k, const char* v)
+{
+  if (!v) {
+    return -1;
+  }
+  switch (k) {
+    case KNOB_TDEC_VARIANT:
+      return !strcmp(v, "waves1") ? 1 : (!strcmp(v, "persistent") ? 2 : 0);
+    case KNOB_PSS_VARIANT:
+      return !strcmp(v, "pair") ? 1 : (!strcmp(v, "block") ? 2 : 0);
+    case KNOB_TDEC_EXTRACT_ONLY:
+      return 1;
+    default:
+      return atoi(v);
+  }
+}
+} // namespace
+
+int knob(Knob k)
+{
+  if (!g_knob_read[k].load(std::memory_order_acquire)) {
+    g_knob[k].store(knob_parse(k, getenv(kKnobEnv[k])), std::memory_order_relaxed);
+    g_knob_read[k].store(true, std::memory_order_release);
+  }
+  return g_knob[k].load(std::memory_order_relaxed);
+}
+
 // ---- submission queues under the handle API (coalesce.h)
 namespace {
+struct Entry {
+  std::mutex                 mu; // creation of this shape's queue
+  std::shared_ptr<Coalescer> q;
+  bool                       tried = false;
+  uint64_t                   last_use = 0;
+};
 struct Registry {
-  std::mutex                        mu;
-  std::map<std::string, Coalescer*> byKey;
+  std::mutex                                    mu;
+  std::map<std::string, std::shared_ptr<Entry>> byKey;
+  uint64_t                                      tick = 0;
+  uint64_t                                      dead_batches = 0, dead_units = 0; // statistics of evicted queues
 };
 Registry& registry()
 {
@@ -82,21 +127,64 @@ bool coalescing_enabled()
   return v == 1;
 }
 
-Coalescer* coalescer_for(const std::string& key, const std::function<Coalescer*()>& make)
+std::shared_ptr<Coalescer> coalescer_for(const std::string& key, const std::function<Coalescer*()>& make)
+{
+  Registry&                           r = registry();
+  std::shared_ptr<Entry>              e;
+  std::vector<std::shared_ptr<Entry>> evicted;
+  {
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto                        it = r.byKey.find(key);
+    if (it == r.byKey.end()) {
+      // a new shape: make room first -- least recently used entries that only the registry holds
+      while (r.byKey.size() >= kMaxShapes) {
+        auto victim = r.byKey.end();
+        for (auto jt = r.byKey.begin(); jt != r.byKey.end(); ++jt) {
+          const bool idle = jt->second.use_count() == 1 && (!jt->second->q || jt->second->q.use_count() == 1);
+          if (idle && (victim == r.byKey.end() || jt->second->last_use < victim->second->last_use)) {
+            victim = jt;
+          }
+        }
+        if (victim == r.byKey.end()) {
+          break; // everything is in use right now: grow past the bound rather than block
+        }
+        if (victim->second->q) {
+          uint64_t b = 0, u = 0;
+          victim->second->q->stats(&b, &u);
+          r.dead_batches += b;
+          r.dead_units += u;
+        }
+        evicted.push_back(victim->second);
+        r.byKey.erase(victim);
+      }
+      it = r.byKey.emplace(key, std::make_shared<Entry>()).first;
+    }
+    e           = it->second;
+    e->last_use = ++r.tick;
+  }
+  evicted.clear(); // releases the evicted queues' device resources outside the registry lock
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->tried) {
+    e->tried     = true;
+    Coalescer* c = make();
+    if (c && !c->ok()) {
+      delete c;
+      c = nullptr;
+    }
+    e->q.reset(c);
+  }
+  return e->q; // may be empty: creation failed before, callers fall back to their private path
+}
+
+size_t coalescer_shapes()
 {
   Registry&                   r = registry();
   std::lock_guard<std::mutex> lk(r.mu);
-  auto                        it = r.byKey.find(key);
-  if (it != r.byKey.end()) {
-    return it->second; // may be nullptr: creation failed before, callers fall back to their private path
+  size_t                      n = 0;
+  for (auto& kv : r.byKey) {
+    n += kv.second->q ? 1 : 0;
   }
-  Coalescer* c = make();
-  if (c && !c->ok()) {
-    delete c;
-    c = nullptr;
-  }
-  r.byKey[key] = c;
-  return c;
+  return n;
 }
 
 } // namespace phyhip
@@ -110,13 +198,13 @@ extern "C" void srsran_hip_set_coalescing(int enable)
 
 extern "C" void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_units)
 {
-  uint64_t  b = 0, u = 0;
-  Registry& r = registry();
+  Registry&                   r = registry();
   std::lock_guard<std::mutex> lk(r.mu);
+  uint64_t                    b = r.dead_batches, u = r.dead_units;
   for (auto& kv : r.byKey) {
-    if (kv.second) {
+    if (kv.second->q) {
       uint64_t bb = 0, uu = 0;
-      kv.second->stats(&bb, &uu);
+      kv.second->q->stats(&bb, &uu);
       b += bb;
       u += uu;
     }
@@ -127,6 +215,23 @@ extern "C" void srsran_hip_coalesce_stats(uint64_t* nof_batches, uint64_t* nof_u
   if (nof_units) {
     *nof_units = u;
   }
+}
+
+extern "C" int srsran_hip_dev_knob(const char* env_name, const char* value)
+{
+  for (int k = 0; env_name && k < KNOB_COUNT; k++) {
+    if (!strcmp(env_name, kKnobEnv[k])) {
+      g_knob[k].store(knob_parse(k, value), std::memory_order_relaxed);
+      g_knob_read[k].store(true, std::memory_order_release);
+      return SRSRAN_SUCCESS;
+    }
+  }
+  return SRSRAN_ERROR_INVALID_INPUTS;
+}
+
+extern "C" uint32_t srsran_hip_coalesce_shapes(void)
+{
+  return (uint32_t)coalescer_shapes();
 }
 
 extern "C" int srsran_hip_device_count(void)

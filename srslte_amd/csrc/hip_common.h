@@ -47,6 +47,20 @@ bool device_available();
 // device before they touch a stream (a thread-local compare after the first call).
 void bind_thread();
 
+// development knobs: launch-shape alternatives kept in the tree for measurement (profiles/r02_turbo_variants.txt, r02_pss_variants.txt) and a few
+// sizing overrides.  The environment variable of a knob is read ONCE (first use); srsran_hip_dev_knob() overrides a knob at run time,
+// which is how tests/test_gpu_variants.py switches kernels inside one process.  -1 = not set.
+enum Knob {
+  KNOB_TDEC_VARIANT = 0,  // SRSRAN_HIP_TDEC_VARIANT: 0 product, 1 "waves1", 2 "persistent"
+  KNOB_PSS_VARIANT,       // SRSRAN_HIP_PSS_VARIANT: 0 product ("wave"), 1 "pair", 2 "block"
+  KNOB_TDEC_EXTRACT_ONLY, // TDEC_DBG_EXTRACT_ONLY
+  KNOB_LDPC_PCPB,         // LDPC_PCPB
+  KNOB_LDPC_SLOTS,        // LDPC_SLOTS
+  KNOB_LDPC_PACKED,       // LDPC_PACKED
+  KNOB_COUNT
+};
+int knob(Knob k);
+
 static inline uint32_t ceil_div(uint32_t a, uint32_t b)
 {
   return (a + b - 1) / b;

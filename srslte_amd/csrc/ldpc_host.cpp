@@ -412,8 +412,7 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
     // workgroup, 25.6 ms with one; Z = 256: the same either way)
     int       pcpb = ((crc_order && Z > 128) || (Z >= 256 && (Z / 2) % 64 == 0)) ? 1 : choose_cpb((int)Z / 2, (size_t)h->N * (Z / 2) * 2);
     pcpb           = pcpb > cap ? cap : pcpb;
-    if (const char* e = getenv("LDPC_PCPB")) { // development knob
-      const int v = atoi(e);
+    if (const int v = knob(KNOB_LDPC_PCPB); v > 0) { // development knob
       pcpb        = (v > 0 && v <= cap && v * (int)(Z / 2) <= 768 && (size_t)v * h->N * Z <= 150 * 1024) ? v : pcpb;
     }
     p.cpb       = pcpb;
@@ -549,10 +548,12 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
     const uint32_t nit_off = (liftK + 3u) & ~3u;
     const uint32_t poly = crc ? (uint32_t)crc->polynom : 0u, order = crc ? (uint32_t)crc->order : 0u;
     char           key[160];
-    snprintf(key, sizeof(key), "ldpc:t%d:bg%d:z%u:sf%a:it%u:rm%u:crc%x,%u", c->dec_type, (int)q->bg, (unsigned)q->ls, (double)q->scaling_fctr,
-             q->max_nof_iter, cdwd_rm_length, poly, order);
+    // the engine depends on decoder type, base graph, lifting size, scaling and iteration budget; the rate-matched length and the CRC
+    // change with every grant and are run-time parameters of a launch: they travel as the request's grouping tag
+    snprintf(key, sizeof(key), "ldpc:t%d:bg%d:z%u:sf%a:it%u", c->dec_type, (int)q->bg, (unsigned)q->ls, (double)q->scaling_fctr, q->max_nof_iter);
+    const uint64_t tag = (uint64_t)cdwd_rm_length | ((uint64_t)order << 16) | ((uint64_t)poly << 24);
     const size_t esz  = c->esz;
-    Coalescer*   co   = coalescer_for(key, [&]() -> Coalescer* {
+    std::shared_ptr<Coalescer> co = coalescer_for(key, [&]() -> Coalescer* {
       const uint32_t                   cap = 32;
       const srsran_basegraph_t         bgq = q->bg;
       const uint16_t                   lsq = q->ls;
@@ -560,13 +561,17 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
       const uint32_t                   itq = q->max_nof_iter;
       const srsran_ldpc_decoder_type_t tyq = (srsran_ldpc_decoder_type_t)c->dec_type;
       const uint32_t in_stride = (uint32_t)(Coalescer::stride_of(n_llr * esz) / esz), out_stride = (uint32_t)Coalescer::stride_of(nit_off + 4);
-      return new Coalescer(n_llr * esz, nit_off + 4, cap, 1, [=](int) -> Coalescer::RunFn {
+      return new Coalescer(n_llr * esz, nit_off + 4, cap, 1, [=](int) -> Coalescer::Engine {
         srsran_hip_ldpc_batch_t* b     = nullptr;
         int*                     d_nit = nullptr;
         if (srsran_hip_ldpc_batch_create_typed(&b, bgq, lsq, sfq, itq, cap, tyq) != SRSRAN_SUCCESS || hipMalloc(&d_nit, cap * sizeof(int)) != hipSuccess) {
-          return Coalescer::RunFn();
+          if (b) {
+            srsran_hip_ldpc_batch_free(b);
+          }
+          return Coalescer::Engine();
         }
-        return [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) -> int {
+        auto run = [=](const void* d_in, void* d_out, uint32_t n, uint64_t t, hipStream_t st) -> int {
+          const uint32_t cdwd_rm_length = (uint32_t)(t & 0xffffu), order = (uint32_t)((t >> 16) & 0xffu), poly = (uint32_t)(t >> 24);
           if (order) {
             if (srsran_hip_ldpc_batch_run_crc(b, static_cast<const int8_t*>(d_in), in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length,
                                               poly, order, d_nit, st)) {
@@ -578,12 +583,16 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
           }
           return srsran_hip_ldpc_batch_run_typed(b, d_in, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, cdwd_rm_length, nullptr, st);
         };
+        return Coalescer::Engine{run, [=]() {
+                                   srsran_hip_ldpc_batch_free(b);
+                                   (void)hipFree(d_nit);
+                                 }};
       });
     });
     if (co) {
       std::vector<uint8_t>& rec = c->rec;
       rec.resize(nit_off + 4);
-      if (co->submit(llrs, rec.data()) != SRSRAN_SUCCESS) {
+      if (co->submit(llrs, rec.data(), tag) != SRSRAN_SUCCESS) {
         fprintf(stderr, "[srsran_phy_hip] srsran_ldpc_decoder: %s\n", get_error());
         return -1;
       }

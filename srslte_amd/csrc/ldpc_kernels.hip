@@ -471,8 +471,8 @@ int grid_slots(const Params& p)
     slots = p.max_slots;
   }
   slots            = slots > p.max_slots ? p.max_slots : slots;
-  if (const char* e = getenv("LDPC_SLOTS")) { // development knob
-    slots = atoi(e) > 0 && atoi(e) <= p.max_slots ? atoi(e) : slots;
+  if (const int v = knob(KNOB_LDPC_SLOTS); v > 0) { // development knob
+    slots = v <= p.max_slots ? v : slots;
   }
   const int groups = (p.n_cw + p.cpb - 1) / p.cpb;
   return groups < slots ? groups : slots;

@@ -336,8 +336,8 @@ bool packed_applies(const Params& p)
   if (p.dtype != DT_I8 || p.flood || p.iter_msgs || p.soft_out || (p.Z & 1) || p.Z < 8 || p.sf_m9 <= 0) {
     return false;
   }
-  if (const char* e = getenv("LDPC_PACKED")) { // development knob: 0 = plain kernel
-    return atoi(e) != 0;
+  if (const int v = knob(KNOB_LDPC_PACKED); v >= 0) { // development knob: 0 = plain kernel
+    return v != 0;
   }
   return true;
 }
@@ -363,8 +363,8 @@ int grid_slots_packed(const Params& p)
     slots = (p.crc_order || 2 * p.max_slots >= 5 * slots) ? p.max_slots : slots;
   }
   slots            = slots > p.max_slots ? p.max_slots : slots;
-  if (const char* e = getenv("LDPC_SLOTS")) { // development knob
-    slots = atoi(e) > 0 && atoi(e) <= p.max_slots ? atoi(e) : slots;
+  if (const int v = knob(KNOB_LDPC_SLOTS); v > 0) { // development knob
+    slots = v <= p.max_slots ? v : slots;
   }
   const int groups = (p.n_cw + p.cpb - 1) / p.cpb;
   return groups < slots ? groups : slots;

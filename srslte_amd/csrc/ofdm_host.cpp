@@ -67,6 +67,25 @@ extern "C" int srsran_symbol_sz(uint32_t nof_prb)
   return SRSRAN_ERROR;
 }
 
+// The "standard symbol size" switch is PROCESS state of the reference's phy_common.c (srsran_use_standard_symbol_size, phy_common.c:31-35,
+// 322-325), and an application that links this library keeps that file: it has a hundred other functions.  The library is linked
+// -Bsymbolic, so a plain call from in here would bind to the copy above and its own flag -- and an application that switched its own
+// copy to standard rates (pmch_file_test.c, sync_sl_test.c: 25 PRB -> 512 in the program, 384 in here) would get an OFDM object of another
+// size than it asked for.  The default symbol size is therefore asked of the first definition in the process's global scope (the
+// application's, when it has one; this library's otherwise -- e.g. when it was loaded privately by ctypes).
+#include <dlfcn.h>
+static int process_symbol_sz(uint32_t nof_prb)
+{
+  using fn_t        = int (*)(uint32_t);
+  static const fn_t f = []() -> fn_t {
+    // (through the main program's handle: RTLD_DEFAULT looked up from inside a -Bsymbolic library finds the library's own definition first)
+    void* self = dlopen(nullptr, RTLD_LAZY);
+    void* p    = self ? dlsym(self, "srsran_symbol_sz") : nullptr;
+    return p ? reinterpret_cast<fn_t>(p) : &srsran_symbol_sz;
+  }();
+  return f(nof_prb);
+}
+
 // SRSRAN_CP_LEN (phy_common.h:125): float arithmetic on purpose
 static int cp_len(uint32_t symbol_sz, int c)
 {
@@ -215,7 +234,7 @@ static int geometry_from_cfg(const srsran_ofdm_cfg_t* cfg, Geometry* g, uint32_t
 {
   uint32_t symbol_sz = cfg->symbol_sz;
   if (symbol_sz == 0) {
-    int s = srsran_symbol_sz(cfg->nof_prb);
+    int s = process_symbol_sz(cfg->nof_prb);
     if (s <= SRSRAN_SUCCESS) {
       fprintf(stderr, "Invalid number of PRB %d\n", cfg->nof_prb);
       return SRSRAN_ERROR;
@@ -393,7 +412,7 @@ void ctx_free(OfdmCtx* c)
 int ofdm_init_(srsran_ofdm_t* q, srsran_ofdm_cfg_t* cfg, srsran_dft_dir_t dir)
 {
   if (cfg->symbol_sz == 0) {
-    int s = srsran_symbol_sz(cfg->nof_prb);
+    int s = process_symbol_sz(cfg->nof_prb);
     if (s <= SRSRAN_SUCCESS) {
       fprintf(stderr, "Invalid number of PRB %d\n", cfg->nof_prb);
       return SRSRAN_ERROR;

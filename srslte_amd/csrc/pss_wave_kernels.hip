@@ -540,8 +540,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 hipError_t launch_pss_wave_blocks(const PssParams& p, hipStream_t stream)
 {
-  const char* ve   = getenv("SRSRAN_HIP_PSS_VARIANT"); // development knob: "pair" = the measured alternative with two waves per block
-  const bool  pair = ve && !strcmp(ve, "pair");
+  const bool pair = knob(KNOB_PSS_VARIANT) == 1; // development knob: "pair" = the measured alternative with two waves per block
   if (pair) {
     hipLaunchKernelGGL(pss_pair_kernel, dim3(p.n_blocks, p.n_cap), dim3(128), 0, stream, p);
   } else {

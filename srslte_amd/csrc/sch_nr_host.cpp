@@ -12,6 +12,7 @@
 #include "srsran_amd/phy_batch.h"
 #include "srsran_amd/phy_modem_abi.h"
 #include "srsran_amd/phy_nr_sch_abi.h"
+#include "srsran_amd/phy_sch_abi.h"
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -29,15 +30,10 @@ struct TbCfg { // srsran_sch_nr_tb_info_t
   uint32_t Qm, A, L_tb, L_cb, B, Bp, Kp, Kr, F, Z, G, Nl, Nref, C, N;
 };
 
-// srsran_sch_nr_fill_tb_info with cbsegm_ldpc; false where the reference fails
-bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
+// TS 38.212 5.2.2 as srsran_cbsegm_ldpc (cbsegm.c:201-275): transport CRC length, number of code blocks, lifting size
+bool nr_segment(int bg, uint32_t tbs, uint32_t* L_tb, uint32_t* C_out, uint32_t* Z_out)
 {
-  static const uint32_t qm[5] = {1, 2, 4, 6, 8};
-  if (tb.tbs == 0 || tb.mod > 4 || tb.N_L == 0 || (tb.rv & ~SRSRAN_HIP_NR_TB_NEW_DATA) > 3) {
-    return false;
-  }
-  c->bg = ((tb.tbs <= 292) || (tb.tbs <= 3824 && tb.R <= 0.67) || (tb.R <= 0.25)) ? 1 : 0; // sch_nr.c:35-45
-  const uint32_t L = tb.tbs <= 3824 ? 16 : 24, K_cb = c->bg == 0 ? 8448 : 3840, B = tb.tbs + L;
+  const uint32_t L = tbs <= 3824 ? 16 : 24, K_cb = bg == 0 ? 8448 : 3840, B = tbs + L;
   uint32_t       C, Bp;
   if (B <= K_cb) { // cbsegm_cb_size, cbsegm.c:51-60
     C  = 1;
@@ -48,7 +44,7 @@ bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
   }
   const uint32_t Kp  = Bp / C;
   uint32_t       K_b = 22;
-  if (c->bg == 1) {
+  if (bg == 1) {
     K_b = B > 640 ? 10 : (B > 560 ? 9 : (B > 192 ? 8 : 6));
   }
   uint32_t Z = (Kp + K_b - 1) / K_b;
@@ -58,6 +54,42 @@ bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
   if (Z > 384) {
     return false;
   }
+  *L_tb = L, *C_out = C, *Z_out = Z;
+  return true;
+}
+
+int cbsegm_ldpc(srsran_cbsegm_t* s, int bg, uint32_t tbs)
+{
+  if (!s) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  memset(s, 0, sizeof(*s));
+  if (tbs == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  uint32_t L, C, Z;
+  if (!nr_segment(bg, tbs, &L, &C, &Z)) {
+    return SRSRAN_ERROR;
+  }
+  const uint32_t K = Z * (bg == 0 ? 22u : 10u);
+  s->tbs = tbs, s->L_tb = L, s->L_cb = C > 1 ? 24 : 0, s->C = C, s->C1 = C, s->K1 = K, s->F = K * C; // F = K C as the reference has it
+  s->K1_idx = LSindex[Z], s->Z = Z;
+  return SRSRAN_SUCCESS;
+}
+
+// srsran_sch_nr_fill_tb_info with cbsegm_ldpc; false where the reference fails
+bool tb_cfg(const srsran_hip_nr_tb_t& tb, TbCfg* c)
+{
+  static const uint32_t qm[5] = {1, 2, 4, 6, 8};
+  if (tb.tbs == 0 || tb.mod > 4 || tb.N_L == 0 || (tb.rv & ~SRSRAN_HIP_NR_TB_NEW_DATA) > 3) {
+    return false;
+  }
+  c->bg = ((tb.tbs <= 292) || (tb.tbs <= 3824 && tb.R <= 0.67) || (tb.R <= 0.25)) ? 1 : 0; // sch_nr.c:35-45
+  uint32_t L, C, Z;
+  if (!nr_segment(c->bg, tb.tbs, &L, &C, &Z)) {
+    return false;
+  }
+  const uint32_t B = tb.tbs + L;
   c->Qm   = qm[tb.mod];
   c->A    = tb.tbs;
   c->L_tb = L;
@@ -109,6 +141,17 @@ bool ensure(T** d, T** h, size_t* cap, size_t n)
 }
 
 } // namespace
+
+// cbsegm.h:59-67 / cbsegm.c:277-285: NR segmentation for the two base graphs (srsran_sch_nr_fill_tb_info and the reference's own NR
+// objects call them when cbsegm.c is dropped from the link)
+extern "C" int srsran_cbsegm_ldpc_bg1(srsran_cbsegm_t* s, uint32_t tbs)
+{
+  return cbsegm_ldpc(s, 0, tbs);
+}
+extern "C" int srsran_cbsegm_ldpc_bg2(srsran_cbsegm_t* s, uint32_t tbs)
+{
+  return cbsegm_ldpc(s, 1, tbs);
+}
 
 struct srsran_hip_sch_nr {
   float    scaling = 0.8f;

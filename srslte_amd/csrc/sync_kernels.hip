@@ -475,9 +475,8 @@ hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream)
     }
     attr_set = true;
   }
-  // development knob, read at every launch (tests/test_gpu_variants.py switches it): "block" = the workgroup-per-block kernel of round 1
-  const char* ve           = getenv("SRSRAN_HIP_PSS_VARIANT");
-  const bool  by_workgroup = ve && !strcmp(ve, "block");
+  // development knob (tests/test_gpu_variants.py switches it through srsran_hip_dev_knob): "block" = the workgroup-per-block kernel of round 1
+  const bool by_workgroup = knob(KNOB_PSS_VARIANT) == 2;
   if (by_workgroup) {
     hipLaunchKernelGGL(pss_block_kernel, dim3(p.n_blocks, p.n_cap), dim3(256), lds, stream, p);
   } else {

@@ -4,6 +4,7 @@
 // tc_interl_umts.c:51-90 (init/free) and lib/src/phy/fec/cbsegm.c:119-140 of the reference.
 #include "coalesce.h"
 #include "hip_common.h"
+#include "srsran_amd/phy_sch_abi.h"
 #include "tables/lte_qpp_table.h"
 #include "turbo_device.h"
 
@@ -28,6 +29,12 @@ extern "C" int srsran_cbsegm_cbindex(uint32_t long_cb)
 extern "C" int srsran_cbsegm_cbsize(uint32_t index)
 {
   return (index < LTE_QPP_NOF_SIZES) ? (int)lte_qpp_table[index][0] : SRSRAN_ERROR;
+}
+
+extern "C" bool srsran_cbsegm_cbsize_isvalid(uint32_t size) // cbsegm.c:142-150
+{
+  const int idx = srsran_cbsegm_cbindex(size);
+  return idx >= 0 && (uint32_t)srsran_cbsegm_cbsize((uint32_t)idx) == size;
 }
 
 extern "C" int srsran_tc_interl_init(srsran_tc_interl_t* h, uint32_t max_long_cb)
@@ -149,6 +156,9 @@ struct srsran_hip_tdec_batch {
   short* d_dec_llr = nullptr;
   // early stop on CRC: multipliers x^(W (nb-1-d)) mod g for the generators used so far
   std::map<uint32_t, uint32_t*> crc_mult;
+  // the "persistent" launch variant's unit counter (development knob) and the CU count of the object's device
+  uint32_t* d_unit_counter = nullptr;
+  int       cus            = 0;
 };
 
 // which decoder the reference runs: sub-block count and arithmetic (turbodecoder.c:381-441,455-512)
@@ -344,24 +354,24 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     p.n_cb       = (int)n_cb;
     p.sb_layout  = sb_layout;
     p.in_is8     = in_is8 ? 1 : 0;
-    if (getenv("TDEC_DBG_EXTRACT_ONLY")) {
+    if (knob(KNOB_TDEC_EXTRACT_ONLY) > 0) {
       p.n_end = 0; // development aid: input extraction + decision only
     }
     // launch-shape alternatives kept for measurement (profiles/r02_turbo_variants.txt); the product path is variant 0
-    // (read at every launch: tests/test_gpu_variants.py switches it inside one process)
-    const char* ve      = getenv("SRSRAN_HIP_TDEC_VARIANT");
-    const int   variant = !ve ? 0 : (!strcmp(ve, "waves1") ? 1 : (!strcmp(ve, "persistent") ? 2 : 0));
+    const int variant = knob(KNOB_TDEC_VARIANT) > 0 ? knob(KNOB_TDEC_VARIANT) : 0;
     if (variant == 2 && n_begin == 0 && h->nb == 16 && !h->arith8) {
-      static uint32_t* d_counter = nullptr;
-      static int       cus       = 0;
-      if (!d_counter) {
-        PHY_HIP_CHECK(hipMalloc(&d_counter, sizeof(uint32_t)), SRSRAN_ERROR);
-        PHY_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0), SRSRAN_ERROR);
+      // the unit counter belongs to the batch object (launches of different objects / streams must not share one) and lives on
+      // the device the object was created on
+      if (!h->d_unit_counter) {
+        int dev = 0;
+        PHY_HIP_CHECK(hipGetDevice(&dev), SRSRAN_ERROR);
+        PHY_HIP_CHECK(hipMalloc(&h->d_unit_counter, sizeof(uint32_t)), SRSRAN_ERROR);
+        PHY_HIP_CHECK(hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, dev), SRSRAN_ERROR);
       }
-      PHY_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), stream), SRSRAN_ERROR);
+      PHY_HIP_CHECK(hipMemsetAsync(h->d_unit_counter, 0, sizeof(uint32_t), stream), SRSRAN_ERROR);
       p.n_units      = ceil_div(n_cb, 8);
-      p.max_resident = (uint32_t)cus * 8u; // 4 SIMDs x 2 waves
-      p.unit_counter = d_counter;
+      p.max_resident = (uint32_t)h->cus * 8u; // 4 SIMDs x 2 waves
+      p.unit_counter = h->d_unit_counter;
     }
     p.variant = variant;
     PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
@@ -729,6 +739,9 @@ static bool tdec_run_all_queued(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
   if (!c || !coalescing_enabled() || (uint32_t)srsran_cbsegm_cbsize(h->current_cbidx) != K) {
     return false;
   }
+  // handles are often initialised on one thread and run on another: the queue's lanes (streams, staging buffers, engines) must be
+  // created on the process's device even when this worker thread has not touched the device yet
+  bind_thread();
   int  nb     = 0;
   bool arith8 = false;
   if (impl_to_cfg(h->dec_type, in8, K, &nb, &arith8) || (nb && (K % nb || K / nb <= 40))) {
@@ -739,20 +752,22 @@ static bool tdec_run_all_queued(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
   const size_t in_len    = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
   char         key[96];
   snprintf(key, sizeof(key), "tdec:K%u:nb%d:a%d:sb%d:e%d:it%u", K, nb, arith8 ? 1 : 0, sb_layout, in8 ? 1 : 0, nit);
-  Coalescer* q = coalescer_for(key, [&]() -> Coalescer* {
+  std::shared_ptr<Coalescer> q = coalescer_for(key, [&]() -> Coalescer* {
     const uint32_t cap  = 64;
     const int      impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)
                                  : (nb == 16 ? SRSRAN_TDEC_AVX_WINDOW : (nb == 8 ? SRSRAN_TDEC_SSE_WINDOW : SRSRAN_TDEC_GENERIC));
     const uint32_t in_stride  = (uint32_t)(Coalescer::stride_of(in_len * sizeof(ELEM)) / sizeof(ELEM));
     const uint32_t out_stride = (uint32_t)Coalescer::stride_of(K / 8);
-    return new Coalescer(in_len * sizeof(ELEM), K / 8, cap, 4, [=](int) -> Coalescer::RunFn {
+    return new Coalescer(in_len * sizeof(ELEM), K / 8, cap, 4, [=](int) -> Coalescer::Engine {
       srsran_hip_tdec_batch_t* b = nullptr;
       if (srsran_hip_tdec_batch_create(&b, K, cap, impl)) {
-        return Coalescer::RunFn();
+        return Coalescer::Engine();
       }
-      return [=](const void* d_in, void* d_out, uint32_t n, hipStream_t st) {
-        return tdec_batch_run_range(b, d_in, in8, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, 0, nit, sb_layout, false, st);
-      };
+      return Coalescer::Engine{[=](const void* d_in, void* d_out, uint32_t n, uint64_t, hipStream_t st) {
+                                 return tdec_batch_run_range(b, d_in, in8, in_stride, static_cast<uint8_t*>(d_out), out_stride, n, 0, nit, sb_layout,
+                                                             false, st);
+                               },
+                               [=]() { srsran_hip_tdec_batch_free(b); }};
     });
   });
   if (!q) {

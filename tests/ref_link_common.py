@@ -47,3 +47,11 @@ def run_program(kind, name, args, cwd, timeout=600):
     r = subprocess.run([program(kind, name)] + [str(a) for a in args], cwd=str(cwd), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, errors="replace", timeout=timeout)
     return r.returncode, r.stdout
+
+
+def add_ctest_data(d):
+    """the data files the reference's ctest lines name (tests/golden/ref_ctest_data.npz, written by tools/ref_ctest_manifest.py)"""
+    z = np.load(os.path.join(GOLD, "ref_ctest_data.npz"))
+    for i, name in enumerate(z["names"]):
+        z["f%03d" % i].tofile(d / str(name))
+    return d

@@ -228,3 +228,78 @@ def test_same_shape_calls_are_merged_and_resumable(hiplib):
     lib.srsran_tdec_iteration(C.byref(h), O.P(x), O.P(out))
     assert np.array_equal(out, O.turbo_decode(llr[3:4], 5, K)[0])
     lib.srsran_tdec_free(C.byref(h))
+
+
+def test_handle_initialised_on_one_thread_runs_on_another(hiplib):
+    """handles are initialised on the main thread, srsran_hip_set_device is called, and the first run comes from a FRESH worker thread
+    (no HIP call made on it yet): the queue's lanes must be created after the thread is bound to the process's device
+    (turbo_host.cpp: tdec_run_all_queued; the LDPC path binds in ldpc_decode_any)"""
+    from srslte_amd import capi
+
+    lib = hiplib
+    lib.srsran_hip_set_coalescing(1)
+    K, nit = 2048, 6  # a shape no other test has queued before
+    _, llr = O.turbo_llrs(K, 2, 1.0, 5)
+    ref = O.turbo_decode(llr, nit, K)
+    h = capi.Tdec()
+    assert lib.srsran_tdec_init(C.byref(h), K) == 0
+    lib.srsran_tdec_force_not_sb(C.byref(h))
+    assert lib.srsran_hip_set_device(0) == 0
+    out = np.zeros((2, K // 8), np.uint8)
+
+    def run():
+        for i in range(2):
+            assert lib.srsran_tdec_run_all(C.byref(h), O.P(llr[i].copy()), O.P(out[i]), nit, K) == 0
+
+    _run_threads([run])
+    assert np.array_equal(out, ref)
+    lib.srsran_tdec_free(C.byref(h))
+
+
+def test_submission_queue_registry_is_bounded(hiplib):
+    """a long-running process walks through many kernel shapes (block sizes, iteration budgets, LDPC rate-matched lengths): the registry
+    keeps at most 12 queues (least recently used idle ones are released) and LDPC calls that differ only in rate-matched length / CRC
+    share ONE queue (they are grouped per batch by a tag, not by the registry key); results stay equal to the oracle's throughout"""
+    from srslte_amd import capi
+
+    lib = hiplib
+    lib.srsran_hip_set_coalescing(1)
+    sizes = [512, 576, 640, 704, 768, 832, 896, 960, 1024, 1088, 1152, 1216, 1280, 1344, 1408, 1472]
+    for rep in range(2):
+        for K in sizes:
+            _, llr = O.turbo_llrs(K, 1, 2.0, K)
+            ref = O.turbo_decode(llr, 4, K)
+            h = capi.Tdec()
+            assert lib.srsran_tdec_init(C.byref(h), K) == 0
+            lib.srsran_tdec_force_not_sb(C.byref(h))
+            out = np.zeros(K // 8, np.uint8)
+            assert lib.srsran_tdec_run_all(C.byref(h), O.P(llr[0].copy()), O.P(out), 4, K) == 0
+            assert np.array_equal(out, ref[0]), K
+            lib.srsran_tdec_free(C.byref(h))
+            assert lib.srsran_hip_coalesce_shapes() <= 12
+    # LDPC: 8 threads, four rate-matched lengths at once -> one queue for the (type, bg, Z, sf, iterations) engine
+    bg, Z, nit, n_thr, calls = 1, 96, 6, 8, 5
+    g = O.ldpc_graph(bg, Z)
+    N = g.bgN * Z
+    lens = [N - 2 * Z, (g.bgK + 9) * Z + 3, (g.bgK + 20) * Z, (g.bgK + 5) * Z]
+    _, llrs = O.ldpc_llrs(bg, Z, n_thr, 2.0, seed=11)
+    shapes0 = lib.srsran_hip_coalesce_shapes()
+    b0, u0 = _stats(lib)
+
+    def worker(t):
+        def run():
+            rm = lens[t % len(lens)]
+            ref, _ = O.ldpc_decode(bg, Z, llrs[t:t + 1], 0.8, nit, rm)
+            q = capi.LdpcDecoder()
+            a = capi.LdpcDecoderArgs(capi.LDPC_C_AVX2, bg, Z, 0.8, nit)
+            assert lib.srsran_ldpc_decoder_init(C.byref(q), C.byref(a)) == 0
+            out = np.zeros(g.bgK * Z, np.uint8)
+            for _ in range(calls):
+                assert lib.srsran_ldpc_decoder_decode_c(C.byref(q), O.P(llrs[t]), O.P(out), rm) == nit
+                assert np.array_equal(out, ref[0]), (t, rm)
+            lib.srsran_ldpc_decoder_free(C.byref(q))
+        return run
+
+    _run_threads([worker(t) for t in range(n_thr)])
+    assert lib.srsran_hip_coalesce_shapes() <= max(shapes0 + 1, 12)
+    assert lib.srsran_hip_coalesce_shapes() <= 12

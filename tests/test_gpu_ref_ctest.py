@@ -1,0 +1,48 @@
+"""The reference's ctest lines for its PHY test programs, run on top of the product library.
+
+tests/ref_link/Makefile target `ext` links EVERY test program of lib/src/phy/**/test that builds against libsrsran_phy_hip.so with the WHOLE
+table of INTEGRATION.md section 1 removed from the reference side (OFDM, DFT, transform precoding, turbo decoder + encoder, QPP, code-block
+segmentation, LDPC decoder + encoder + rate matcher, base graphs, PSS, SSS, sync, CFO, CP, soft demodulator).  tests/ref_link/ctest_manifest.json
+(tools/ref_ctest_manifest.py) lists the ctest lines of the reference's CMake files for the programs that bind product symbols; ctest's
+criterion is the exit code, and so is this test's.  Programs cover the LTE / NB-IoT / sidelink / NR channels whose objects call the
+replaced entry points (PDSCH / PUSCH / PMCH through sch.c and the turbo coder pair, PRACH and channel estimation through srsran_dft_*,
+NR PDSCH / PUSCH through sch_nr.c and the LDPC objects, NPSS / NSSS / PSSS through the DFT plans, ...).
+
+By default one line per program plus every line of the programs on the hot path proper runs (a few minutes of process start-ups);
+REF_CTEST_FULL=1 runs all of them (profiles/r03_ref_ctest_full.log is such a run).
+"""
+import json
+import os
+
+import pytest
+from ref_link_common import HERE, add_ctest_data, make_data_dir, run_program
+
+pytestmark = pytest.mark.gpu
+
+MANIFEST = json.load(open(os.path.join(HERE, "ref_link", "ctest_manifest.json")))["entries"]
+ALL_LINES_OF = {"ofdm_test", "dft_test", "turbodecoder_test", "turbocoder_test", "rm_turbo_test", "sync_test", "cfo_test", "ldpc_chain_test",
+                "ldpc_rm_chain_test", "ldpc_dec_test", "ldpc_dec_s_test", "ldpc_dec_avx2_test", "ldpc_enc_test", "ldpc_enc_avx2_test",
+                "ldpc_rm_test", "pusch_test", "sch_nr_test", "pusch_nr_test", "pdsch_nr_test", "pmch_test", "pbch_file_test", "pcfich_file_test",
+                "phich_file_test", "pdcch_file_test", "pdsch_pdcch_file_test", "pmch_file_test", "modem_test", "prach_test"}
+
+
+def _selected():
+    full = os.environ.get("REF_CTEST_FULL", "0") == "1"
+    seen = {}
+    for e in MANIFEST:
+        n = seen.get(e["program"], 0)
+        seen[e["program"]] = n + 1
+        if full or e["program"] in ALL_LINES_OF or n % 8 == 0:
+            yield e
+
+
+@pytest.fixture(scope="module")
+def data_dir(tmp_path_factory, hiplib):
+    return add_ctest_data(make_data_dir(tmp_path_factory.mktemp("ref_ctest_data")))
+
+
+@pytest.mark.parametrize("entry", list(_selected()), ids=lambda e: "%s:%s" % (e["program"], e["name"]))
+def test_ctest_line(entry, data_dir):
+    args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
+    rc, out = run_program("bin_full", entry["program"], args, data_dir, timeout=900)
+    assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])

@@ -1,7 +1,6 @@
 """The measured alternatives kept in the tree behind development knobs (DESIGN.md par. 3.2 and 3.4: the turbo decoder's launch
 shapes, the three PSS correlation kernels) must stay CORRECT -- a variants table whose rows compute different things says nothing.
-The knobs are read at every launch, so one process switches between them."""
-import os
+The knobs' environment variables are read once; srsran_hip_dev_knob overrides them at run time, so one process switches between them."""
 
 import numpy as np
 import pytest
@@ -14,19 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
-def knob():
-    saved = {}
+def knob(hiplib):
+    touched = set()
 
     def set_(name, value):
-        saved.setdefault(name, os.environ.get(name))
-        os.environ[name] = value
+        touched.add(name)
+        assert hiplib.srsran_hip_dev_knob(name.encode(), value.encode()) == 0
 
     yield set_
-    for name, value in saved.items():
-        if value is None:
-            os.environ.pop(name, None)
-        else:
-            os.environ[name] = value
+    for name in touched:
+        assert hiplib.srsran_hip_dev_knob(name.encode(), None) == 0
 
 
 @pytest.mark.parametrize("variant", ["wave", "pair", "block"])

@@ -134,8 +134,7 @@ class Ctx:
         self.rank, self.world, self.local, self.dev, self.cdev, self.dist, self.stream = rank, world, local, dev, cdev, dist, stream
 
     def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
+        self.dist.barrier()
 
     def max_over_ranks(self, values):
         from srslte_amd import sharding
@@ -302,41 +301,23 @@ def worker(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if share_gpu else dev  # where collective payloads live
-    backend = None
-    if world > 1:
-        import datetime
+    from srslte_amd import sharding
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            backend = "gloo (ranks share one GPU)"
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            # RCCL carries the job's only collectives (one configuration broadcast, barriers, a max of three timings).  If its
-            # bootstrap fails on this node the run still measures what it is meant to measure -- the ranks exchange no data --
-            # so the same few bytes go over gloo instead, and the JSON line says so.
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
-                t = torch.zeros(1, device=dev)
-                dist.all_reduce(t)  # the first collective builds the communicator: fail here, not in the timed region
-                torch.cuda.synchronize()
-                backend = "nccl (RCCL)"
-            except Exception as e:  # noqa: BLE001
-                sys.stderr.write("bench.py rank %d: RCCL process group failed (%s); falling back to gloo for the control collectives\n" % (rank, e))
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
-                cdev = torch.device("cpu")
-                backend = "gloo (RCCL init failed: %s)" % str(e)[:120]
+    # The job's only collectives -- one configuration broadcast, barriers, a max of a few timings -- go through RCCL, at world size 1
+    # as well: a 1-GPU run executes the same bootstrap (librccl, communicator on this rank's device, first all-reduce) an 8-GPU run needs.
+    # If RCCL cannot be brought up the ranks AGREE on gloo through the rendezvous store before anyone re-initialises
+    # (sharding.init_collectives) -- the ranks exchange no data, so the measurement stands -- and the JSON line says so.
+    backend, cdev = sharding.init_collectives(rank, world, dev, prefer="gloo" if share_gpu else "nccl")
+    if share_gpu:
+        backend = "gloo (ranks share one GPU)"
+    seen = sharding.ranks_seen(local, dev, cdev)
 
     import srslte_amd as S
-    from srslte_amd import capi, sharding
+    from srslte_amd import capi
 
     S.capi.check(S.lib().srsran_hip_set_device(local), "set_device")
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = Ctx(rank, world, local, dev, cdev, dist if world > 1 else None, stream)
+    ctx = Ctx(rank, world, local, dev, cdev, dist, stream)
 
     # ---- the only collective of the job: rank 0 broadcasts the cell / decoder configuration
     cfg = sharding.broadcast_config({"n_prb": N_PRB, "n_fft": N_FFT, "k_cb": K_CB, "nit": NIT, "cb_per_sf": CB_PER_SF, "sf": a.sf}
@@ -409,7 +390,7 @@ def worker(a):
             "metric": "turbo decoded Mbit/s (LTE 20 MHz, K=6144, 8 half-iterations) incl. OFDM demod of the same subframes",
             "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16", "data": "synthetic", "collective_backend": backend,
+            "dtype": "int16", "data": "synthetic", "collective_backend": backend, "ranks_seen": seen,
             "config": {"workload": "LTE 20 MHz (BASELINE configs[1]): ofdm_rx_sf N=2048 100 PRB + tdec_run_all K=6144 nof_iterations=8, "
                                    "%d subframes + %d code blocks per GPU per step; the code blocks are %d distinct noisy code words "
                                    "(device encoder + AWGN: half at Es/N0 3 dB, half at -1 dB) tiled %dx -- a fixed-iteration decoder "
@@ -481,8 +462,7 @@ def worker(a):
             res["extra"] = extra
     if rank == 0:
         emit(res)
-    if world > 1:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 def main():

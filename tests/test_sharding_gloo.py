@@ -81,3 +81,64 @@ def test_bench_launcher_propagates_a_failing_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"],
                        env=dict(env, RANK="0", WORLD_SIZE="3", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr
+
+
+AGREE_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from srslte_amd import sharding
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+label, dev = sharding.init_collectives(rank, world, torch.device("cpu"), prefer="nccl", timeout_s=60)
+cfg = sharding.broadcast_config({"k_cb": 6144} if rank == 0 else None, dev)
+seen = sharding.ranks_seen(rank, None, dev)
+t = sharding.max_over_ranks(float(rank + 1), dev)
+print(json.dumps({"rank": rank, "label": label, "cfg": cfg, "seen": seen, "t": t, "backend": dist.get_backend()}), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def _run_agree(tmp_path, world):
+    import json
+
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_WORKER % ROOT)
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    return sorted((json.loads([l for l in o[0].splitlines() if l.startswith("{")][-1]) for o in outs), key=lambda d: d["rank"])
+
+
+def test_collective_backend_is_agreed_by_all_ranks(tmp_path):
+    """no GPU here, so the RCCL attempt fails on BOTH ranks: they must hear of each other's failure through the rendezvous store, rebuild
+    the group on gloo over the same store (no second port) and say so -- nobody stays behind on the other backend, nobody waits for a timeout"""
+    import time
+
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("needs a box where RCCL cannot come up")
+    t0 = time.time()
+    res = _run_agree(tmp_path, 2)
+    assert time.time() - t0 < 60
+    for r in res:
+        assert r["backend"] == "gloo" and r["label"].startswith("gloo (RCCL failed on ranks [0, 1]"), r
+        assert r["cfg"] == {"k_cb": 6144} and r["t"] == 2.0
+        assert [x["rank"] for x in r["seen"]] == [0, 1]
+
+
+def test_collectives_are_initialised_at_world_size_1(tmp_path):
+    """a 1-rank job builds its process group too (on the GPU box: RCCL at world size 1; here: the agreed fallback)"""
+    res = _run_agree(tmp_path, 1)
+    assert len(res) == 1 and res[0]["cfg"] == {"k_cb": 6144} and res[0]["t"] == 1.0 and len(res[0]["seen"]) == 1

@@ -66,7 +66,7 @@ int upload_twiddles(float2** d, int N)
   (void)hipFree(*d);
   *d = nullptr;
   PHY_HIP_CHECK(hipMalloc(d, N * sizeof(float2)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(*d, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(upload(*d, tw.data(), N * sizeof(float2)), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }
 
@@ -146,7 +146,7 @@ int ctx_set_size(DftCtx* c, int N)
   (void)hipFree(c->d_tw);
   c->d_tw = nullptr;
   PHY_HIP_CHECK(hipMalloc(&c->d_tw, N * sizeof(float2)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(c->d_tw, tw.data(), N * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(upload(c->d_tw, tw.data(), N * sizeof(float2)), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }
 

@@ -47,6 +47,17 @@ bool device_available();
 // device before they touch a stream (a thread-local compare after the first call).
 void bind_thread();
 
+// Table uploads (object creation, first use of a new block size / generator).  A hipMemcpy from pageable memory returns when the HOST
+// buffer may be reused; a small copy is staged and reaches the device in null-stream order -- and every kernel of this library runs on
+// hipStreamNonBlocking streams, which do not order themselves against the null stream.  Seen once under the reference's
+// turbodecoder_test: the first srsran_tdec_run_all(K = 40) of a process ran with a not-yet-written interleaver table (10 wrong bits in the
+// first block, none after).  upload() returns when the device has the data, whichever stream reads it next.
+inline hipError_t upload(void* dst, const void* src, size_t bytes)
+{
+  const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+
 // development knobs: launch-shape alternatives kept in the tree for measurement (profiles/r02_turbo_variants.txt, r02_pss_variants.txt) and a few
 // sizing overrides.  The environment variable of a knob is read ONCE (first use); srsran_hip_dev_knob() overrides a knob at run time,
 // which is how tests/test_gpu_variants.py switches kernels inside one process.  -1 = not set.

@@ -224,8 +224,8 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
   }
   PHY_HIP_CHECK(hipMalloc(&h->d_row_start, (d.M + 1) * sizeof(int)), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMalloc(&h->d_edges, d.E * sizeof(int)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_edges, ed.data(), d.E * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(upload(h->d_row_start, rs.data(), (d.M + 1) * sizeof(int)), SRSRAN_ERROR);
+  PHY_HIP_CHECK(upload(h->d_edges, ed.data(), d.E * sizeof(int)), SRSRAN_ERROR);
   if (flood) {
     // edges of every variable node in row order (update_ldpc_soft_bits_c_flood walks the rows, ldpc_dec_c_flood.c:322-346)
     std::vector<int> cs(d.N + 1, 0), ce;
@@ -240,8 +240,8 @@ extern "C" int srsran_hip_ldpc_batch_create_typed(srsran_hip_ldpc_batch_t** hh, 
     cs[d.N] = (int)ce.size();
     PHY_HIP_CHECK(hipMalloc(&h->d_col_start, cs.size() * sizeof(int)), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_col_edges, ce.size() * sizeof(int)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_col_start, cs.data(), cs.size() * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_col_edges, ce.data(), ce.size() * sizeof(int), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_col_start, cs.data(), cs.size() * sizeof(int)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_col_edges, ce.data(), ce.size() * sizeof(int)), SRSRAN_ERROR);
   }
   {
     // slabs of check-to-variable messages, one per workgroup slot and code word it holds (<= 256 / Z words)
@@ -377,8 +377,8 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
         }
       }
       PHY_HIP_CHECK(hipMalloc(&d_mult, Z * sizeof(uint32_t)), SRSRAN_ERROR);
-      // once per (object, generator); hipMemcpy (not Async) orders itself against the caller's stream work that follows
-      PHY_HIP_CHECK(hipMemcpy(d_mult, m.data(), Z * sizeof(uint32_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+      // once per (object, generator); upload() returns when the device has the table (hip_common.h)
+      PHY_HIP_CHECK(upload(d_mult, m.data(), Z * sizeof(uint32_t)), SRSRAN_ERROR);
     }
     p.crc_poly   = crc_poly;
     p.crc_order  = crc_order;

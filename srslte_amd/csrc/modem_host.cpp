@@ -59,8 +59,8 @@ bool seq_tables(const uint32_t** x1, const uint32_t** x2)
       }
     }
     if (hipMalloc(&g_seq.d_x1, x1.size() * 4) != hipSuccess || hipMalloc(&g_seq.d_x2, x2.size() * 4) != hipSuccess ||
-        hipMemcpy(g_seq.d_x1, x1.data(), x1.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(g_seq.d_x2, x2.data(), x2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        upload(g_seq.d_x1, x1.data(), x1.size() * 4) != hipSuccess ||
+        upload(g_seq.d_x2, x2.data(), x2.size() * 4) != hipSuccess) {
       set_error("modem: cannot allocate the sequence tables on the device");
       g_seq.failed = true;
     }

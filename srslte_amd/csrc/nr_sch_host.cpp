@@ -144,8 +144,8 @@ bool build_graph(int bg, int Z, Graph* g)
     return false;
   }
   if (hipMalloc(&g->d_row_start, rs.size() * sizeof(int)) != hipSuccess || hipMalloc(&g->d_edges, ed.size() * sizeof(int)) != hipSuccess ||
-      hipMemcpy(g->d_row_start, rs.data(), rs.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(g->d_edges, ed.data(), ed.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      upload(g->d_row_start, rs.data(), rs.size() * sizeof(int)) != hipSuccess ||
+      upload(g->d_edges, ed.data(), ed.size() * sizeof(int)) != hipSuccess) {
     set_error("nr_sch: cannot put the base graph on the device");
     return false;
   }

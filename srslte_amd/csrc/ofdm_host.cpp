@@ -216,14 +216,14 @@ static int batch_build(srsran_hip_ofdm_batch_t** hh, const Geometry& g, bool tx,
   std::vector<std::complex<float>> tw;
   make_twiddles(g.N, tw);
   PHY_HIP_CHECK(hipMalloc(&h->d_tw, g.N * sizeof(float2)), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpy(h->d_tw, tw.data(), g.N * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+  PHY_HIP_CHECK(upload(h->d_tw, tw.data(), g.N * sizeof(float2)), SRSRAN_ERROR);
   if (g.shift_on) {
     PHY_HIP_CHECK(hipMalloc(&h->d_shift, g.sf_sz * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_shift, shift_tab, g.sf_sz * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_shift, shift_tab, g.sf_sz * sizeof(float2)), SRSRAN_ERROR);
   }
   if (!tx && g.win_n) {
     PHY_HIP_CHECK(hipMalloc(&h->d_ramp, g.N * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_ramp, ramp_tab, g.N * sizeof(float2), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_ramp, ramp_tab, g.N * sizeof(float2)), SRSRAN_ERROR);
   }
   *hh = h;
   return SRSRAN_SUCCESS;

@@ -98,7 +98,7 @@ const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
   }
   uint16_t* d = nullptr;
   if (hipMalloc(&d, t.size() * sizeof(uint16_t)) != hipSuccess ||
-      hipMemcpy(d, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+      upload(d, t.data(), t.size() * sizeof(uint16_t)) != hipSuccess) {
     set_error("rm_turbo: cannot place the table of K=%u rv=%u on the device", K, rv);
     (void)hipFree(d);
     return nullptr;
@@ -120,7 +120,7 @@ const uint16_t* fwd_table_on_device(uint32_t K, uint32_t rv, uint32_t* len)
   const std::vector<uint16_t> fwd = build_table(K, rv, 0);
   uint16_t*                   d   = nullptr;
   if (hipMalloc(&d, fwd.size() * sizeof(uint16_t)) != hipSuccess ||
-      hipMemcpy(d, fwd.data(), fwd.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+      upload(d, fwd.data(), fwd.size() * sizeof(uint16_t)) != hipSuccess) {
     set_error("rm_turbo: cannot place the transmit table of K=%u rv=%u on the device", K, rv);
     (void)hipFree(d);
     return nullptr;

@@ -272,7 +272,8 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
       const uint32_t cap = h->crc_rows_cap ? 2 * h->crc_rows_cap : 16;
       uint32_t*      nd  = nullptr;
       if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
-          (h->d_crc_mult && hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess)) {
+          (h->d_crc_mult && (hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+                             hipDeviceSynchronize() != hipSuccess))) { // nothing may still read the old table when it is freed below
         (void)hipFree(nd);
         set_error("sch decode: device allocation of the CRC multiplier table failed");
         return 0xffffffffu;
@@ -283,7 +284,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
     }
     uint32_t m[256];
     rm::tb_crc_multipliers(tbs_bits, CRC24A, m);
-    if (hipMemcpy(h->d_crc_mult + (size_t)row * 256, m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess) {
+    if (upload(h->d_crc_mult + (size_t)row * 256, m, sizeof(m)) != hipSuccess) {
       set_error("sch decode: upload of the CRC multiplier table failed");
       return 0xffffffffu;
     }

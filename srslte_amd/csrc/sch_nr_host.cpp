@@ -247,7 +247,8 @@ static uint32_t crc_row_of(srsran_hip_sch_nr_t* h, uint32_t tbs_bits, uint32_t o
     const uint32_t cap = h->crc_rows_cap ? 2 * h->crc_rows_cap : 16;
     uint32_t*      nd  = nullptr;
     if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
-        (h->d_crc_mult && hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess)) {
+        (h->d_crc_mult && (hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+                             hipDeviceSynchronize() != hipSuccess))) { // nothing may still read the old table when it is freed below
       (void)hipFree(nd);
       set_error("sch_nr decode: device allocation of the CRC multiplier table failed");
       return 0xffffffffu;
@@ -258,7 +259,7 @@ static uint32_t crc_row_of(srsran_hip_sch_nr_t* h, uint32_t tbs_bits, uint32_t o
   }
   uint32_t m[256];
   nrsch::tb_finish_multipliers(chunk, order, m);
-  if (hipMemcpy(h->d_crc_mult + (size_t)row * 256, m, sizeof(m), hipMemcpyHostToDevice) != hipSuccess) {
+  if (upload(h->d_crc_mult + (size_t)row * 256, m, sizeof(m)) != hipSuccess) {
     set_error("sch_nr decode: upload of the CRC multiplier table failed");
     return 0xffffffffu;
   }

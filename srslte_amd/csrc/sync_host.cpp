@@ -246,13 +246,13 @@ PssEngine* pss_engine_new(uint32_t frame_size, uint32_t fft_size, int cfo_i, uin
             hipMalloc(&e->d_part_idx, (size_t)max_caps * 3 * e->n_blocks * sizeof(int)) == hipSuccess &&
             hipMalloc(&e->d_spec, (size_t)max_caps * e->n_blocks * e->block_n * sizeof(float2)) == hipSuccess &&
             hipMalloc(&e->d_res, (size_t)max_caps * 3 * sizeof(sync::PssResult)) == hipSuccess &&
-            hipMemcpy(e->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(e->d_filt, filt.data(), 3 * (size_t)BN * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+            upload(e->d_tw, tw.data(), tw.size() * sizeof(float2)) == hipSuccess &&
+            upload(e->d_filt, filt.data(), 3 * (size_t)BN * sizeof(float2)) == hipSuccess &&
             hipMemset(e->d_corr, 0, (size_t)max_caps * 3 * e->corr_stride * sizeof(float)) == hipSuccess;
   if (ok && e->direct) {
     ok = hipMalloc(&e->d_rep, 3 * (size_t)fft_size * sizeof(float2)) == hipSuccess;
     for (uint32_t h = 0; h < 3 && ok; h++) {
-      ok = hipMemcpy(e->d_rep + (size_t)h * fft_size, e->time[h].data(), fft_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+      ok = upload(e->d_rep + (size_t)h * fft_size, e->time[h].data(), fft_size * sizeof(float2)) == hipSuccess;
     }
   }
   if (!ok) {
@@ -339,8 +339,8 @@ SssEngine* sss_engine_new(uint32_t fft_size)
     seq[62 + i] = (float)zt[i];
   }
   bool ok = hipMalloc(&e->d_tw, fft_size * sizeof(float2)) == hipSuccess && hipMalloc(&e->d_seq, sizeof(seq)) == hipSuccess &&
-            hipMemcpy(e->d_tw, tw.data(), fft_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(e->d_seq, seq, sizeof(seq), hipMemcpyHostToDevice) == hipSuccess;
+            upload(e->d_tw, tw.data(), fft_size * sizeof(float2)) == hipSuccess &&
+            upload(e->d_seq, seq, sizeof(seq)) == hipSuccess;
   if (!ok) {
     set_error("SSS: device allocation failed");
     sss_engine_free(e);

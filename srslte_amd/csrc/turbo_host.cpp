@@ -280,15 +280,15 @@ static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uin
     PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * ceil_div(max_nof_cb, cpw) * cpw * sizeof(uint32_t)), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_deint, tb), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_inter, tb), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_deint, deint.data(), tb, hipMemcpyHostToDevice), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_inter, inter.data(), tb, hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_deint, deint.data(), tb), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_inter, inter.data(), tb), SRSRAN_ERROR);
   } else {
     size_t nwaves = ceil_div(max_nof_cb, 64);
     PHY_HIP_CHECK(hipMalloc(&h->d_ws_gen, turbo::gen_ws_shorts(K) * nwaves * sizeof(short)), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_inter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMalloc(&h->d_deinter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_inter16, f.data(), K * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(h->d_deinter16, r.data(), K * sizeof(uint16_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_inter16, f.data(), K * sizeof(uint16_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(h->d_deinter16, r.data(), K * sizeof(uint16_t)), SRSRAN_ERROR);
   }
   *hh = h;
   return SRSRAN_SUCCESS;
@@ -507,7 +507,7 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
       m[d] = xpow_mod(W * (uint64_t)(h->nb - 1 - d), crc_poly);
     }
     PHY_HIP_CHECK(hipMalloc(&d_mult, m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpy(d_mult, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice), SRSRAN_ERROR);
+    PHY_HIP_CHECK(upload(d_mult, m.data(), m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
   }
   turbo::WinParams p = {};
   p.input      = static_cast<const short*>(d_input);

@@ -14,10 +14,12 @@
  *     signal.1.92M.amar.dat, signal.10M.dat with the cell ids of phch/test/CMakeLists.txt:433,439-442: 150, 1, 150):
  *     tests/golden/sync_captures.npz, tests/test_oracle_golden.py::test_sync_oracle_on_reference_captures; all 504 SSS
  *     sequences bit-equal to gen_sss.c (part of oracle/_ref).
- *   - OFDM / DFT: the reference needs FFTW3, absent from this image -> unbuildable here.
- *     The restatement is pinned by the reference's own acceptance criteria (ofdm_test.c:176 loop-back
- *     RMS < 1e-4; sync_test.c:164 peak position) and a float64 direct DFT.  FFT VALUES themselves are
- *     "parity unpinned" beyond 1e-4, exactly as in the reference (FFTW is an unpinned system library).
+ *   - OFDM / DFT: the reference's dft_fftw.c needs FFTW3, absent from this image -> ofdm.c / dft_fftw.c are unbuildable here.
+ *     Pinned through the reference's OWN callers instead: tests/ref_link links the reference's unmodified test programs against this
+ *     oracle (tests/ref_link/oracle_shim.c) and they must reach the known answers the reference holds for srsran_ofdm_rx_sf -- the MIB of
+ *     signal.1.92M.dat, CFI 2 of signal.10M.dat, the DCI and PDSCH CRC of signal.1.92M.amar.dat, the PMCH CRC of the 100-PRB MBSFN
+ *     subframe -- plus ofdm_test's loop-back criterion (ofdm_test.c:176) for 6 ... 110 PRB: tests/test_ref_link_oracle.py (CPU).
+ *     FFT VALUES beyond 1e-4 stay unpinned, exactly as in the reference (FFTW is an unpinned system library).
  */
 #ifndef ORACLE_H
 #define ORACLE_H

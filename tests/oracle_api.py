@@ -655,3 +655,62 @@ def sch_nr_decode_tb(cfg, rv, scaling_fctr, max_iter, llr, softbuf, cb_crc, cb_d
     assert f(C.byref(cfg), rv, scaling_fctr, max_iter, P(llr) if llr.size else None, P(softbuf), softbuf.shape[1], P(cb_crc), P(cb_data),
              cb_data.shape[1], P(out), C.byref(ok), C.byref(avg)) == 0
     return out, ok.value, avg.value
+
+
+class RefSchChain:
+    """The reference's OWN receive-side FEC chain (oracle/_ref: rm_turbo.c, turbodecoder*.c, crc.c compiled where they lie), driven in the
+    order decode_tb_cb drives it (sch.c:389-466: per code block srsran_rm_turbo_rx_lut{,_8bit} into the soft buffer, srsran_tdec_new_cb,
+    srsran_tdec_iteration{,_8bit} + srsran_crc_checksum_byte until the CRC matches or max_iterations).  CPU baseline of kind
+    "reference" for the transport-block legs and a second check of the oracle's decode_tb restatement.  Needs have_ref()."""
+
+    def __init__(self, llr8=False, max_iterations=10):
+        self.ref = C.CDLL(REF_LIB)
+        self.llr8, self.max_it = llr8, max_iterations
+        self.ref.srsran_rm_turbo_gentables()
+        self.tdec = C.create_string_buffer(64 * 1024)
+        assert self.ref.srsran_tdec_init(self.tdec, 6144) == 0
+        self.crc_tb, self.crc_cb = C.create_string_buffer(4096), C.create_string_buffer(4096)
+        assert self.ref.srsran_crc_init(self.crc_tb, 0x1864CFB, 24) == 0 and self.ref.srsran_crc_init(self.crc_cb, 0x1800063, 24) == 0
+        self.ref.srsran_crc_checksum_byte.restype = C.c_uint32
+        self.ref.srsran_crc_checksum_byte.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.rx = self.ref.srsran_rm_turbo_rx_lut_8bit if llr8 else self.ref.srsran_rm_turbo_rx_lut
+        self.rx.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        self.it = self.ref.srsran_tdec_iteration_8bit if llr8 else self.ref.srsran_tdec_iteration
+        self.it.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.it.restype = None
+
+    SOFT_STRIDE = 18624  # >= 18600 elements (SRSRAN_HIP_SOFTBUFFER_CB_SIZE) and a multiple of 64 bytes for both LLR widths
+
+    def new_softbuffer(self, n_cb):
+        """soft buffers the way the reference allocates them: every code block's row 64-byte aligned (its decoders use aligned loads)"""
+        dt = np.int8 if self.llr8 else np.int16
+        return aligned_empty(n_cb * self.SOFT_STRIDE, dt).reshape(n_cb, self.SOFT_STRIDE)
+
+    def decode_tb(self, tbs, Qm, rv, e_bits, softbuf, cb_crc):
+        """first transmission or HARQ round on `softbuf` (from new_softbuffer, zeroed by the caller for new data) / `cb_crc` [C];
+        returns (ok, payload bytes incl. CRC24A, avg half iterations)"""
+        seg = cbsegm(tbs)
+        Cn, esz = seg["C"], e_bits.dtype.itemsize
+        data = np.zeros(tbs // 8 + 16, np.uint8)
+        Gp = e_bits.size // Qm
+        gamma, n_e = Gp % Cn, Qm * (Gp // Cn)
+        noi = 0
+        for cb in range(Cn):
+            if cb_crc[cb]:
+                continue
+            K = seg["K1"] if cb < seg["C1"] else seg["K2"]
+            rlen = K if Cn == 1 else K - 24
+            rp, n_e2 = cb * n_e, n_e
+            if cb > Cn - gamma:
+                n_e2 = n_e + Qm
+                rp = (Cn - gamma) * n_e + (cb - (Cn - gamma)) * n_e2
+            assert self.rx(e_bits.ctypes.data + rp * esz, softbuf[cb].ctypes.data, n_e2, orc().orc_tc_cb_index(K), rv) == 0
+            assert self.ref.srsran_tdec_new_cb(self.tdec, K) == 0
+            out = data.ctypes.data + cb * rlen // 8
+            for _ in range(self.max_it):
+                self.it(self.tdec, softbuf[cb].ctypes.data, out)
+                noi += 1
+                if self.ref.srsran_crc_checksum_byte(self.crc_cb if Cn > 1 else self.crc_tb, out, K if Cn > 1 else tbs + 24) == 0:
+                    cb_crc[cb] = 1
+                    break
+        return bool(cb_crc.all()), data, noi / Cn

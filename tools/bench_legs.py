@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0
 
 def load_traffic():
     """HBM traffic per launch from the PMC passes of the round (profiles/rNN_traffic.json, newest round first)"""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)
@@ -81,12 +81,16 @@ def _timed(ctx, torch, step, steps, warmup):
     return time.perf_counter() - t0
 
 
-def _host_has_avx2():
+def _host_has(flag):
     try:
         with open("/proc/cpuinfo") as f:
-            return " avx2 " in f.read().replace("\n", " ")
+            return (" %s " % flag) in f.read().replace("\n", " ")
     except OSError:
         return False
+
+
+def _host_has_avx2():
+    return _host_has("avx2")
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]: NR LDPC + OFDM 4096
@@ -103,9 +107,13 @@ def ldpc_cpu_baseline(bg, Z, llrs, iters, sf=0.8, budget_s=4.0):
     K = (22 if bg == 0 else 10) * Z
     n = llrs.shape[0]
     if O.have_ref() and _host_has_avx2():
-        ref = C.CDLL(O.REF_LIB)
+        # the decoder type the reference's own dispatch would pick on this host (ldpc_decoder.c:609-646): AVX-512 where the host has it
+        lib512 = os.path.join(os.path.dirname(O.REF_LIB), "libsrsran_ref_avx512.so")
+        use512 = _host_has("avx512f") and _host_has("avx512bw") and os.path.exists(lib512)
+        ref = C.CDLL(lib512 if use512 else O.REF_LIB)
+        tname = "C_AVX512" if use512 else "C_AVX2"
         dec = C.create_string_buffer(4096)
-        args = _RefLdpcArgs(4, bg, Z, sf, iters)  # 4 = SRSRAN_LDPC_DECODER_C_AVX2 (ldpc_decoder.h:41-53)
+        args = _RefLdpcArgs(6 if use512 else 4, bg, Z, sf, iters)  # SRSRAN_LDPC_DECODER_C_AVX512 / C_AVX2 (ldpc_decoder.h:41-53)
         assert ref.srsran_ldpc_decoder_init(dec, C.byref(args)) == 0
         out = np.zeros((n, K), np.uint8)
         t0 = time.perf_counter()
@@ -124,7 +132,8 @@ def ldpc_cpu_baseline(bg, Z, llrs, iters, sf=0.8, budget_s=4.0):
         ref.srsran_ldpc_decoder_free(dec)
         return out[:done], {"value": (done + again) * K / dt / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "reference",
                             "sample": "%d code words BG%d Z=%d (%d distinct, compared with the device), %d iterations, reference "
-                                      "srsran_ldpc_decoder_decode_c type C_AVX2 (oracle/_ref), %.1f s on a single thread" % (done + again, bg + 1, Z, done, iters, dt)}
+                                      "srsran_ldpc_decoder_decode_c type %s (oracle/_ref; the type its own dispatch picks on this host), %.1f s on a single thread"
+                                      % (done + again, bg + 1, Z, done, iters, tname, dt)}
     m = min(n, 8)
     t0 = time.perf_counter()
     out, _ = O.ldpc_decode(bg, Z, llrs[:m], sf, iters)
@@ -186,6 +195,7 @@ def leg_ldpc(ctx, steps=3, warmup=1, want_cpu=True, cw=16384, slots=2048, iters=
     sf_bytes = 8 * (15 * 4096 + 14 * 12 * 273)
     tj = load_traffic()
     tr_l, src = traffic_of(tj, "ldpc_packed_kernel", cw, "code_words_per_launch")
+    tr_o, _ = traffic_of(tj, "ofdm_kernel_n4096", slots, "slots_per_launch")
     out = {"metric": "LDPC decoded Mbit/s (info bits, NR BG1 Z=384, %d iterations) incl. OFDM demod N=4096 of %d slots" % (iters, slots),
            "value": ctx.world * cw * K * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": "int8", "scaling": "weak",
@@ -198,7 +208,7 @@ def leg_ldpc(ctx, steps=3, warmup=1, want_cpu=True, cw=16384, slots=2048, iters=
                         "avg_launch_ms": t_l * 1e3, "algorithmic_bytes_per_launch": cw * cw_bytes,
                         "note": "20 iterations over on-chip soft bits + a check-to-variable store: the honest bound is VALU issue (DESIGN.md par. 3.3)"},
            "roofline_ofdm": {"kernel": "ofdm_kernel<Plan<4096,...>,rx>", "bound": "hbm", "achieved": slots * sf_bytes / t_o / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": slots * sf_bytes / t_o / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": slots * sf_bytes / t_o / 1e9 / HBM_PEAK_GBS, "traffic": tr_o, "traffic_source": src,
                              "avg_launch_ms": t_o * 1e3, "algorithmic_bytes_per_launch": slots * sf_bytes}}
     if want_cpu:
         host = pool.cpu().numpy()
@@ -413,6 +423,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
     good = all(np.array_equal(got[i][:tbs // 8], payload[i]) for i in range(pool_n) if res[i].crc_ok == 0)
     unit_bytes = otx.sf_sz * 8 + tbs // 8  # time samples of one UE-subframe in, payload bytes out
     t_step = dt / steps
+    tr_u, src_u = traffic_of(load_traffic(), "uplink_chain", n_tb, "ue_subframes_per_step")
     out = {"metric": "multi-UE LTE uplink, PUSCH receive path from time samples to transport blocks, Mbit/s of TBS (all GPUs)",
            "value": ctx.world * n_tb * tbs * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
            "ms_per_step": t_step * 1e3, "dtype": "f32 / int16", "scaling": "weak",
@@ -425,7 +436,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                         "demod_descramble": float(pm[3]), "dematch_turbo_crc": float(pm[4])},
            "roofline": {"kernel": "whole chain (dominant: tdec_win_kernel<8, Ar16, true> inside dematch_turbo_crc)", "bound": "hbm",
                         "achieved": n_tb * unit_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": n_tb * unit_bytes / t_step / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": t_step * 1e3,
+                        "frac": n_tb * unit_bytes / t_step / 1e9 / HBM_PEAK_GBS, "traffic": tr_u, "traffic_source": src_u, "avg_launch_ms": t_step * 1e3,
                         "algorithmic_bytes_per_launch": n_tb * unit_bytes,
                         "note": "algorithmic = time samples in (245,760 B) + payload out (7,972 B) per UE-subframe; wall time of the step, host work included"}}
     if want_cpu:
@@ -447,10 +458,123 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
         ret, data, avg = O.sch_decode_tb(tbs, Qm, 0, llr, soft, crc, iters)
         tc = time.perf_counter() - t0
         par = par and ret == res[0].crc_ok and abs(avg - res[0].avg_iterations) < 1e-6 and np.array_equal(data[:tbs // 8], got[0][:tbs // 8])
-        out["cpu_baseline"] = {"value": tbs / tc / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "port",
-                               "sample": "one UE-subframe through the restated chain (scipy.fft OFDM + IDFT, C restatement of demodulator, de-matcher, "
-                                         "scalar-C window turbo decoder, CRCs), single thread",
-                               "parity_vs_gpu": "1e-4 on the de-precoded symbols, identical LLRs / verdict / iterations / bytes" if par else "MISMATCH"}
+        port = {"value": tbs / tc / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "port",
+                "sample": "one UE-subframe through the restated chain (scipy.fft OFDM + IDFT, C restatement of demodulator, de-matcher, "
+                          "scalar-C window turbo decoder, CRCs), single thread",
+                "parity_vs_gpu": "1e-4 on the de-precoded symbols, identical LLRs / verdict / iterations / bytes" if par else "MISMATCH"}
+        out["cpu_baseline"] = port
+        if O.have_ref() and _host_has_avx2():
+            # the reference's OWN objects for everything that is not an FFT (oracle/_ref: demod_soft.c, sequence.c, rm_turbo.c, turbodecoder*.c,
+            # crc.c, driven in the order of pusch.c:419-443 / sch.c:389-466); the two FFT stages by the scipy port (the reference's need FFTW)
+            import ctypes as CC
+
+            ref = CC.CDLL(O.REF_LIB)
+            chain = O.RefSchChain(False, iters)
+            n_s = 0
+            llr_r = O.aligned_empty(G, np.int16)
+            sym = O.aligned_empty(2 * n_re, np.float32)
+            softr, same = chain.new_softbuffer(ncb), True
+            t0 = time.perf_counter()
+            while n_s < 4 or time.perf_counter() - t0 < 3.0:
+                i = n_s % min(n_tb, 64)
+                ts_i = d_time[i].cpu().numpy().view(np.complex64).reshape(-1)
+                gi = O.ofdm_rx_fft(cfg, ts_i[None])[0].reshape(14, nsc)[data_sym].astype(np.complex128) / gain
+                sym[:] = (F.ifft(gi, axis=1, workers=1) * np.sqrt(nsc)).reshape(-1).astype(np.complex64).view(np.float32)
+                assert ref.srsran_demod_soft_demodulate_s(mod, O.P(sym), O.P(llr_r), n_re) == 0
+                ref.srsran_sequence_apply_s(O.P(llr_r), O.P(llr_r), CC.c_uint32(G), CC.c_uint32(seeds[i % pool_n]))
+                softr[:] = 0
+                crc_r = np.zeros(ncb, np.uint8)
+                okr, data_r, avg_r = chain.decode_tb(tbs, Qm, 0, llr_r, softr, crc_r)
+                if i == 0:
+                    same = (0 if okr else -1) == res[0].crc_ok and abs(avg_r - res[0].avg_iterations) < 1e-6 and np.array_equal(data_r[:tbs // 8], got[0][:tbs // 8])
+                n_s += 1
+            tr = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_s * tbs / tr / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "reference",
+                                   "sample": "%d UE-subframes in %.1f s on one thread: the reference's own demod_soft / sequence / rm_turbo / turbodecoder (AUTO -> avx16 "
+                                             "window) / crc objects (oracle/_ref) in the order of pusch.c:419-443 and sch.c:389-466; OFDM rx and the 1200-point IDFT by "
+                                             "the scipy.fft port (the reference's dft_fftw.c needs FFTW, absent)" % (n_s, tr),
+                                   "parity_vs_gpu": "identical verdict / iterations / bytes on the compared subframe" if same else "MISMATCH",
+                                   "port_scalar_c": port}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     lib.srsran_hip_sch_free(sch)
+    return out
+
+
+def leg_uplink_waterfall(ctx, steps=3, warmup=1, want_cpu=False):
+    """the same chain at a waterfall operating point (Es/N0 16.4 dB: about 4 half iterations on average, some transport blocks fail) --
+    the 19 dB point of `uplink` is the cheap regime (1.8 half iterations, every block decodes).  No CPU leg: `uplink` carries it."""
+    out = leg_uplink(ctx, steps=steps, warmup=warmup, want_cpu=False, snr=16.4)
+    if out is not None:
+        out["metric"] += " -- waterfall operating point"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ configs[1] through the 8-bit API
+
+def leg_turbo8(ctx, steps=3, warmup=1, want_cpu=True, n_cb=131040, K=6144, nit=8):
+    """BASELINE configs[1]'s decoder through the 8-bit API -- srsran_tdec_run_all_8bit is what srsenb and srsue run (cc_worker.cc sets
+    llr_is_8bit in both): int8 LLRs, AUTO -> the 32-sub-block avx8 window decoder for K = 6144, 8 half iterations, natural-order input.
+    CPU beside it: the reference's srsran_tdec_run_all_8bit (oracle/_ref) on one core, which is also the parity check."""
+    import torch
+
+    import srslte_amd as S
+    from srslte_amd import capi
+    import oracle_api as O
+
+    lib, dev, st = S.lib(), ctx.dev, ctx.stream
+    pool_n = 64
+    _, hi = O.turbo_llrs_8bit(K, pool_n // 2, 3.0, seed=21 + ctx.rank)
+    _, lo = O.turbo_llrs_8bit(K, pool_n // 2, -1.0, seed=22 + ctx.rank)
+    pool = np.concatenate([hi, lo])
+    reps = (n_cb + pool_n - 1) // pool_n
+    d_llr = torch.from_numpy(pool).to(dev).repeat(reps, 1)[:n_cb].contiguous()
+    d_bits = torch.zeros((n_cb, K // 8), dtype=torch.uint8, device=dev)
+    dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO, llr8=True)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+
+    def step(i):
+        if i is not None:
+            evs[i][0].record()
+        capi.check(lib.srsran_hip_tdec_batch_run_8bit(dec._h, d_llr.data_ptr(), 3 * K + 12, d_bits.data_ptr(), K // 8, n_cb, nit, 0, st), "run8")
+        if i is not None:
+            evs[i][1].record()
+
+    dt = _timed(ctx, torch, step, steps, warmup)
+    t_k = sum(e[0].elapsed_time(e[1]) for e in evs) / steps * 1e-3
+    dt, t_k = ctx.max_over_ranks([dt, t_k])
+    if ctx.rank != 0:
+        return None
+    unit = 3 * K + 12 + K // 8  # SURVEY 8(d), int8 API: 19,212 B per block
+    tr, src = traffic_of(load_traffic(), "tdec_win_kernel_8bit", n_cb, "code_blocks_per_launch")
+    out = {"metric": "turbo decoded Mbit/s through the 8-bit API (LTE 20 MHz, K=6144, 8 half iterations; what srsenb / srsue run)",
+           "value": ctx.world * n_cb * K * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "dtype": "int8", "scaling": "weak",
+           "config": {"workload": "srsran_hip_tdec_batch_run_8bit: %d blocks K=%d, nof_iterations=%d, AUTO -> avx8 window (32 sub-blocks); %d distinct noisy "
+                                  "code words (half at Es/N0 3 dB, half at -1 dB) tiled %dx, per GPU" % (n_cb, K, nit, pool_n, reps)},
+           "roofline": {"kernel": "tdec_win_kernel<32, Ar8, false>", "bound": "hbm", "achieved": n_cb * unit / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": n_cb * unit / t_k / 1e9 / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_ms": t_k * 1e3,
+                        "algorithmic_bytes_per_launch": n_cb * unit, "note": "VALU-issue bound (per-step max-normalisation), DESIGN.md par. 3.2"}}
+    if want_cpu and O.have_ref() and _host_has_avx2():
+        ref = C.CDLL(O.REF_LIB)
+        h = C.create_string_buffer(64 * 1024)
+        assert ref.srsran_tdec_init(h, K) == 0
+        ref.srsran_tdec_force_not_sb(h)
+        n = 48
+        outs = np.zeros((n, K // 8), np.uint8)
+        t0 = time.perf_counter()
+        for i in range(n):
+            assert ref.srsran_tdec_run_all_8bit(h, O.P(pool[i].copy()), O.P(outs[i]), nit, K) == 0
+        again, scratch = 0, np.zeros(K // 8, np.uint8)
+        while time.perf_counter() - t0 < 2.0:
+            ref.srsran_tdec_run_all_8bit(h, O.P(pool[again % n].copy()), O.P(scratch), nit, K)
+            again += 1
+        tc = time.perf_counter() - t0
+        ref.srsran_tdec_free(h)
+        got = d_bits[:n].cpu().numpy()
+        out["cpu_baseline"] = {"value": (n + again) * K / tc / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "reference",
+                               "sample": "%d code blocks (%d distinct, compared with the device), reference srsran_tdec_run_all_8bit AUTO -> avx8 window "
+                                         "(oracle/_ref), %.1f s on a single thread" % (n + again, n, tc),
+                               "parity_vs_gpu": "bit-exact" if np.array_equal(outs, got) else "MISMATCH"}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del dec
     return out

@@ -11,7 +11,12 @@ UNITS = {  # kernel name fragment -> (key in the JSON, units per launch key, uni
     "ofdm_kernel<phyhip::fft::Plan<2048": ("ofdm_kernel", "subframes_per_launch", 10080),
     "ldpc_packed_kernel<false>": ("ldpc_packed_kernel", "code_words_per_launch", 16384),
     "pss_wave_kernel": ("pss_wave_kernel", "captures_per_launch", 256),
+    "ofdm_kernel<phyhip::fft::Plan<4096": ("ofdm_kernel_n4096", "slots_per_launch", 2048),
+    "tdec_win_kernel<32, phyhip::turbo::Ar8, false>": ("tdec_win_kernel_8bit", "code_blocks_per_launch", 131040),
 }
+# the kernels of one step of the uplink leg (extra.uplink: 64 UEs x 184 subframes): their bench-sized dispatches summed
+CHAIN = {"uplink_chain": (["ofdm_kernel<phyhip::fft::Plan<1536", "modem::", "dft_fixed_kernel<phyhip::fft::Plan<1200", "rm_rx_gather_lds_kernel<short>",
+                           "tdec_win_kernel<8, phyhip::turbo::Ar16, true>", "tb_crc_kernel"], "ue_subframes_per_step", 64 * 184)}
 
 
 def mean_counter(d, counter):
@@ -35,6 +40,16 @@ def main():
             continue
         fk, wk = max(f), max(w)  # the bench-sized dispatches (set-up dispatches of the same kernel are smaller)
         out[key] = {"fetch_size_kb": fk, "write_size_kb": wk, "traffic_bytes_per_launch": (2 * fk + wk) * 1024, ukey: units}
+    for key, (frags, ukey, units) in CHAIN.items():
+        tot, parts = 0.0, {}
+        for frag in frags:
+            for n in sorted(set(fetch) | set(write)):
+                if frag in n and n in fetch and n in write:
+                    b = (2 * fetch[n] + write[n]) * 1024
+                    parts[n[:90]] = b
+                    tot += b
+        if parts:
+            out[key] = {"traffic_bytes_per_launch": tot, ukey: units, "kernels": parts}
     print(json.dumps(out, indent=1))
 
 

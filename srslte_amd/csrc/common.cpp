@@ -63,7 +63,7 @@ bool device_available()
 
 // ---- development knobs (hip_common.h)
 namespace {
-const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED"};
+const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED", "SRSRAN_HIP_TDEC_LAT"};
 std::atomic<int>  g_knob[KNOB_COUNT];
 std::atomic<bool> g_knob_read[KNOB_COUNT];
 

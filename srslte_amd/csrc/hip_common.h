@@ -68,6 +68,7 @@ enum Knob {
   KNOB_LDPC_PCPB,         // LDPC_PCPB
   KNOB_LDPC_SLOTS,        // LDPC_SLOTS
   KNOB_LDPC_PACKED,       // LDPC_PACKED
+  KNOB_TDEC_LAT,          // SRSRAN_HIP_TDEC_LAT: 0 never use the latency kernel, 1 always (where it exists), unset: by batch size
   KNOB_COUNT
 };
 int knob(Knob k);

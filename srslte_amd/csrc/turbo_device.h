@@ -79,6 +79,18 @@ static inline size_t gen_ws_shorts(uint32_t K)
 }
 
 hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream);
+// latency kernel (turbo_lat_kernels.hip): one code block per wave, states across lanes; same WinParams with its own workspace layout
+// (lat_ws_dwords per code block).  Exists for 16 sub-blocks (16- and 8-bit arithmetic) and 8 sub-blocks (16-bit).
+hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t stream);
+uint32_t   lat_ws_dwords(uint32_t K, int nb);
+static inline bool lat_exists(int nb, bool arith8)
+{
+  return (nb == 16) || (nb == 8 && !arith8);
+}
+// Batches up to this many code blocks go to the latency kernel: one wave per block fills the chip's 1024 SIMDs once (a lone wave already
+// issues at the rate a SIMD sustains for packed / three-operand instructions, tools/probe/valu_issue_probe.hip), two waves per SIMD take
+// twice as long each; beyond that the throughput kernel's 8 blocks per wave win (crossover measured: profiles/r03_tti.json).
+constexpr uint32_t kLatMaxBlocks = 2048;
 } // namespace turbo
 } // namespace phyhip
 struct srsran_hip_tdec_batch;

@@ -159,7 +159,37 @@ struct srsran_hip_tdec_batch {
   // the "persistent" launch variant's unit counter (development knob) and the CU count of the object's device
   uint32_t* d_unit_counter = nullptr;
   int       cus            = 0;
+  // latency kernel (small batches): its own workspace, allocated on first use for lat_cap code blocks
+  uint32_t* d_ws_lat      = nullptr;
+  uint32_t  lat_cap       = 0;
+  bool      state_in_lat  = false; // the decoder state of the last launch lives in the latency kernel's workspace
 };
+
+// which kernel takes a launch of n_cb blocks starting at half iteration n_begin (a resumed run stays where its state is)
+static bool want_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
+{
+  if (!h->nb || !turbo::lat_exists(h->nb, h->arith8)) {
+    return false;
+  }
+  if (n_begin > 0) {
+    return h->state_in_lat;
+  }
+  const int k = knob(KNOB_TDEC_LAT);
+  return k == 0 ? false : (k > 0 ? true : n_cb <= turbo::kLatMaxBlocks);
+}
+static int ensure_lat_ws(srsran_hip_tdec_batch* h, uint32_t n_cb)
+{
+  if (n_cb <= h->lat_cap) {
+    return SRSRAN_SUCCESS;
+  }
+  (void)hipFree(h->d_ws_lat);
+  h->d_ws_lat = nullptr;
+  h->lat_cap  = 0;
+  const uint32_t cap = ((n_cb > turbo::kLatMaxBlocks ? n_cb : (h->max_cb < turbo::kLatMaxBlocks ? h->max_cb : turbo::kLatMaxBlocks)) + 1u) & ~1u;
+  PHY_HIP_CHECK(hipMalloc(&h->d_ws_lat, (size_t)turbo::lat_ws_dwords(h->K, h->nb) * cap * sizeof(uint32_t)), SRSRAN_ERROR);
+  h->lat_cap = cap;
+  return SRSRAN_SUCCESS;
+}
 
 // which decoder the reference runs: sub-block count and arithmetic (turbodecoder.c:381-441,455-512)
 static int impl_to_cfg(int impl, bool llr8_api, uint32_t K, int* nb, bool* arith8)
@@ -300,6 +330,7 @@ extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
     return;
   }
   hipFree(h->d_ws);
+  hipFree(h->d_ws_lat);
   hipFree(h->d_deint);
   hipFree(h->d_inter);
   hipFree(h->d_ws_gen);
@@ -374,7 +405,18 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
       p.unit_counter = h->d_unit_counter;
     }
     p.variant = variant;
-    PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+    if (want_lat(h, n_cb, n_begin)) {
+      if (ensure_lat_ws(h, n_cb)) {
+        return SRSRAN_ERROR;
+      }
+      p.ws        = h->d_ws_lat;
+      p.ws_stride = turbo::lat_ws_dwords(h->K, h->nb);
+      PHY_HIP_CHECK(turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+      h->state_in_lat = true;
+    } else {
+      PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+      h->state_in_lat = false;
+    }
   } else {
     turbo::GenParams p = {};
     p.input      = d_input;
@@ -527,6 +569,18 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
   p.crc_mult   = d_mult;
   p.noi        = d_noi;
   p.crc_ok     = d_crc_ok;
+  if (want_lat(h, n_cb, 0)) {
+    // a subframe's worth of code blocks: one block per wave instead of eight (turbo_lat_kernels.hip)
+    if (ensure_lat_ws(h, n_cb)) {
+      return SRSRAN_ERROR;
+    }
+    p.ws        = h->d_ws_lat;
+    p.ws_stride = turbo::lat_ws_dwords(h->K, h->nb);
+    PHY_HIP_CHECK(turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+    h->state_in_lat = true;
+    return SRSRAN_SUCCESS;
+  }
+  h->state_in_lat = false;
   PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
 }

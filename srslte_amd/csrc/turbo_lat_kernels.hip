@@ -1,0 +1,764 @@
+// turbo_lat_kernels.hip -- LATENCY kernel of the LTE turbo decoder for gfx950: one code block per wave, trellis STATES across lanes.
+//
+// Same decoders, bit for bit, as turbo_kernels.hip (the reference's window decoders: turbodecoder_win.h, turbodecoder_iter.h), another
+// mapping.  The throughput kernel gives a lane two sub-blocks and all 8 states (8 code blocks per wave): every trellis step is ~130 packed
+// instructions that ONE wave issues for its 8 blocks -- right when tens of thousands of blocks are in flight, 250 us per half iteration when
+// the batch is one subframe's worth (the reference decodes one subframe per worker call: cc_worker.cc:212-231, sch.c:389-492) and most of
+// the chip idles.  Here a code block owns 8 lanes per sub-block pair:
+//     lane = 8 * pair + state-slot        (16 sub-blocks: 64 lanes = one wave per block; 8 sub-blocks: 32 lanes, two blocks per wave)
+//   * each lane holds ONE state metric (int16x2: the two sub-blocks of its pair), so a step is ~60 instructions per wave for the block:
+//     the add-compare-select is two saturating adds and a max against the PARTNER lane's metric;
+//   * the trellis is a shift register (new state = (u, b2, b1) from (b2, b1, b0)), so the butterflies are done in place and the labelling
+//     of the 8 slots rotates with the step index: slot bits (x2 x1 x0) hold state (x2 x1 x0) at steps = 0 mod 3, (x0 x2 x1) at 1 mod 3,
+//     (x1 x0 x2) at 2 mod 3; the partner is slot ^ 1, ^ 2, ^ 4 (DPP quad_perm / row shifts), never LDS;
+//   * alpha, beta and the LLR of a step use the SAME two branch metrics per lane (the code's butterflies are symmetric), selected once per
+//     step from {0, x, y, x + y} by two lane masks that are compile-time constants per residue;
+//   * max-log-MAP output = two 8-lane max reductions (DPP), normalisation = a broadcast of slot 0 / an 8-lane max (8-bit arithmetic);
+//   * operands are fetched straight into registers by broadcast loads (the 8 lanes of a pair read the same 32 bytes), two 8-step blocks
+//     ahead; backward metrics are check-pointed every 8 steps and re-derived in registers, as in the throughput kernel;
+//   * the QPP exchange of an 8-step block is two ds_bpermute for all its 8 rows at once.
+// Everything that defines results -- saturation, normalisation schedule, 40-step warm-ups, tail trellis, extrinsic subtraction order,
+// decision source, CRC early stop -- is the throughput kernel's (shared arithmetic policies: turbo_arith.h); tests/test_gpu_turbo.py and
+// tests/test_gpu_sch.py run both kernels against the oracle.  Selected by batch size in turbo_host.cpp (or SRSRAN_HIP_TDEC_LAT).
+#include "hip_common.h"
+#include "turbo_arith.h"
+#include "turbo_device.h"
+
+#include <type_traits>
+
+namespace phyhip {
+namespace turbo {
+namespace lat {
+
+// ---- slot labelling: state held by slot s when r = step index mod 3
+__host__ __device__ constexpr int state_of(int r, int s)
+{
+  const int x0 = s & 1, x1 = (s >> 1) & 1, x2 = (s >> 2) & 1;
+  r %= 3;
+  return r == 0 ? s : (r == 1 ? ((x0 << 2) | (x2 << 1) | x1) : ((x1 << 2) | (x0 << 1) | x2));
+}
+__host__ __device__ constexpr int slot_of(int r, int state) // inverse of state_of
+{
+  for (int s = 0; s < 8; s++) {
+    if (state_of(r, s) == state) {
+      return s;
+    }
+  }
+  return 0;
+}
+// predecessor on the data-bit-0 branch of new state i (turbodecoder_win.h:753-790: m_b[i]); the data-bit-1 branch comes from PM[i] ^ 1
+__host__ __device__ constexpr int pm_of(int i)
+{
+  constexpr int PM[8] = {0, 3, 4, 7, 1, 2, 5, 6};
+  return PM[i];
+}
+// new states whose branches carry the parity LLR as {y, x} (the others: {0, x + y})
+__host__ __device__ constexpr bool type_y(int i)
+{
+  return i == 1 || i == 2 || i == 5 || i == 6;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); // (no `old` operand to initialise)
+}
+// metric of the partner slot for a step at residue R: slot ^ 1, ^ 2, ^ 4
+template <int R>
+__device__ __forceinline__ uint32_t partner(uint32_t v)
+{
+  if constexpr (R == 0) {
+    return dpp<0xB1>(v); // quad_perm [1,0,3,2]
+  } else if constexpr (R == 1) {
+    return dpp<0x4E>(v); // quad_perm [2,3,0,1]
+  } else {
+    // swap the two quads of every 8 lanes: banks 0 / 2 take from the lane 4 above, banks 1 / 3 from the lane 4 below
+    int t = __builtin_amdgcn_mov_dpp((int)v, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    t     = __builtin_amdgcn_update_dpp(t, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xA, false);
+    return (uint32_t)t;
+  }
+}
+// value of slot 0 of every 8 lanes, in all 8
+__device__ __forceinline__ uint32_t bcast_slot0(uint32_t v)
+{
+  const int t = __builtin_amdgcn_mov_dpp((int)v, 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, true);
+  return (uint32_t)__builtin_amdgcn_update_dpp(t, t, 0x114 /* row_shr:4 */, 0xf, 0xA, false);
+}
+// maximum over the 8 slots, in all 8
+__device__ __forceinline__ s2 max8(s2 v)
+{
+  v = vmax(v, from_u(partner<0>(to_u(v))));
+  v = vmax(v, from_u(partner<1>(to_u(v))));
+  v = vmax(v, from_u(partner<2>(to_u(v))));
+  return v;
+}
+
+template <class AR>
+__device__ __forceinline__ s2 normalise(s2 o)
+{
+  if constexpr (AR::kIs8) {
+    return __builtin_elementwise_sub_sat(o, max8(o)); // turbodecoder_win.h:480-498, 8-bit: re-base on the maximum
+  } else {
+    return AR::sub(o, from_u(bcast_slot0(to_u(o)))); // 16-bit: subtract the metric of state 0 (slot 0 holds state 0 at every residue)
+  }
+}
+
+// lane constants of a residue: this lane's new state carries {y, x}; this lane's own metric feeds the data-bit-0 branch
+struct LaneK {
+  bool ty[3], d0[3];
+};
+__device__ __forceinline__ LaneK lane_consts(int slot)
+{
+  LaneK c;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    bool ty = false, d0 = false;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      const int  i  = state_of(r + 1, s);
+      const bool t  = type_y(i);
+      const bool d  = state_of(r, s) == pm_of(i);
+      ty            = (slot == s) ? t : ty;
+      d0            = (slot == s) ? d : d0;
+    }
+    c.ty[r] = ty;
+    c.d0[r] = d0;
+  }
+  return c;
+}
+
+// the two branch metrics of a lane for step operands (x, y) at residue R: own -> own new state, partner -> own new state (= own -> partner's)
+template <class AR, int R>
+__device__ __forceinline__ void gammas(const LaneK& c, s2 x, s2 y, s2& g_own, s2& g_cross)
+{
+  const s2 xy = AR::add(x, y);
+  const s2 p  = c.ty[R] ? y : splat(0); // data bit 0
+  const s2 q  = c.ty[R] ? x : xy;       // data bit 1
+  g_own       = c.d0[R] ? p : q;
+  g_cross     = c.d0[R] ? q : p;
+}
+
+// one backward step at residue R: beta(k + 1) in the labelling of R + 1 -> beta(k) in the labelling of R (turbodecoder_win.h:626-652)
+template <class AR, int R>
+__device__ __forceinline__ s2 beta_step(s2 b, s2 g_own, s2 g_cross)
+{
+  const s2 pb = from_u(partner<R>(to_u(b)));
+  return AR::clean(vmax(AR::add_raw(b, g_own), AR::add_raw(pb, g_cross)));
+}
+
+// one forward step at residue R (turbodecoder_win.h:753-826); WITH_LLR: also max1 - max0 against beta(k + 1) `bn`
+template <class AR, int R, bool WITH_LLR>
+__device__ __forceinline__ s2 alpha_step(const LaneK& c, s2& a, s2 bn, s2 g_own, s2 g_cross)
+{
+  const s2 pa   = from_u(partner<R>(to_u(a)));
+  const s2 t_o  = AR::add_raw(a, g_own);
+  const s2 t_c  = AR::add_raw(pa, g_cross);
+  s2       out  = splat(0);
+  if constexpr (WITH_LLR) {
+    const s2 d0 = c.d0[R] ? t_o : t_c;
+    const s2 d1 = c.d0[R] ? t_c : t_o;
+    const s2 m0 = max8(AR::add_raw(bn, d0));
+    const s2 m1 = max8(AR::add_raw(bn, d1));
+    out         = AR::llr(AR::clean(m1), AR::clean(m0));
+  }
+  a = AR::clean(vmax(t_o, t_c));
+  return out;
+}
+
+__device__ __forceinline__ void load8(const uint32_t* q, uint32_t (&r)[8])
+{
+  const uint4 a = *reinterpret_cast<const uint4*>(q), c = *reinterpret_cast<const uint4*>(q + 4);
+  r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = c.x, r[5] = c.y, r[6] = c.z, r[7] = c.w;
+}
+
+// dwords of workspace per code block
+__host__ __device__ inline uint32_t ws_dwords(uint32_t K, int nb)
+{
+  const uint32_t lpc = nb / 2, long_sb = K / nb, nblk = (long_sb + 7) / 8;
+  return 6 * nblk * lpc * 8 + (nblk + 1) * lpc * 8 + 8;
+}
+
+template <int LPC, class AR, bool ES>
+__global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
+{
+  constexpr int NB  = 2 * LPC;
+  constexpr int G   = 8 * LPC;  // lanes per code block
+  constexpr int BPW = 64 / G;   // code blocks per wave
+  __shared__ uint8_t sbuf_all[BPW][NB * (6144 / NB / 8 + 2)]; // hard-bit image of ragged sub-blocks (decision)
+
+  const int      lane = threadIdx.x;
+  const int      grp  = lane / G, li = lane % G, pl = li >> 3, slot = li & 7;
+  const int      gbase = grp * G;
+  const int      cb_raw = (int)blockIdx.x * BPW + grp;
+  const bool     live = cb_raw < p.n_cb;
+  const int      cb   = live ? cb_raw : p.n_cb - 1;
+  const uint32_t K = p.K, long_sb = K / NB, nblk = (long_sb + 7) >> 3;
+  const uint32_t AW = nblk * LPC * 8;
+  const uint32_t crc_poly = ES ? p.crc_poly : 0u;
+  const CbDesc*  desc     = ES ? p.desc : nullptr;
+  const LaneK    lk       = lane_consts(slot);
+
+  uint32_t* ws = p.ws + (size_t)cb_raw * p.ws_stride; // dead groups own a slot too (they decode a copy of the last block, write no output)
+  uint32_t* S  = ws;
+  uint32_t* P0 = ws + AW;
+  uint32_t* P1 = ws + 2 * AW;
+  uint32_t* A1 = ws + 3 * AW;
+  uint32_t* D  = ws + 4 * AW;
+  uint32_t* A2 = ws + 5 * AW;
+  uint32_t* CK = ws + 6 * AW;                                       // (nblk + 1) check-points of G dwords
+  short*    TL = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * G); // 12 tail LLRs
+
+  // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102): element (step 8 b + j, pair pl) per lane
+  if (p.n_begin == 0) {
+    const size_t in_off = desc ? (size_t)desc[cb].in_off : (size_t)cb * p.in_stride;
+    auto         fetch  = [&](uint32_t e) -> short {
+      return p.in_is8 ? AR::conv_in((int)reinterpret_cast<const signed char*>(p.input)[in_off + e]) : AR::conv_in((int)p.input[in_off + e]);
+    };
+    for (uint32_t b = 0; b < nblk; b++) {
+      const uint32_t k  = b * 8 + slot;
+      const uint32_t kk = k < long_sb ? k : long_sb - 1;
+      uint32_t       v[3];
+#pragma unroll
+      for (int a3 = 0; a3 < 3; a3++) {
+        short lo, hi;
+        if (p.sb_layout) { // rm_turbo layout: element (step k, sub-block d) of stream a at a (K + 32) + k NB + d
+          lo = fetch(a3 * (K + 32) + kk * NB + 2 * pl);
+          hi = fetch(a3 * (K + 32) + kk * NB + 2 * pl + 1);
+        } else { // natural order [s p0 p1] x K
+          lo = fetch(3 * ((2 * pl) * long_sb + kk) + a3);
+          hi = fetch(3 * ((2 * pl + 1) * long_sb + kk) + a3);
+        }
+        v[a3] = (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16);
+      }
+      const uint32_t at = (b * LPC + pl) * 8 + slot;
+      S[at]  = v[0];
+      P0[at] = v[1];
+      P1[at] = v[2];
+    }
+    if (li < 12) {
+      const uint32_t tb = p.sb_layout ? 3 * (K + 32) : 3 * K;
+      // TL: [0..2] syst tail, [3..5] parity0 tail, [6..8] app2 tail, [9..11] parity1 tail
+      const int grp4 = li / 3, i3 = li % 3;
+      const uint32_t e = grp4 == 0 ? tb + 2 * i3 : (grp4 == 1 ? tb + 2 * i3 + 1 : (grp4 == 2 ? tb + 6 + 2 * i3 : tb + 6 + 2 * i3 + 1));
+      TL[li] = fetch(e);
+    }
+  }
+  const uint32_t wrap_row = (AR::kIs8 && (K & 31u)) ? long_sb - 1 : 0xffffffffu;
+  __syncthreads();
+
+  uint8_t*       out       = p.output + (desc ? (size_t)desc[cb].out_off : (size_t)cb * p.out_stride);
+  const uint32_t out_bytes = desc ? desc[cb].out_bytes : K / 8;
+  const int      rW        = (int)(long_sb % 3); // residue of the step index one past a sub-block
+
+  // ---- hard decision (turbodecoder.c:370-378, turbodecoder_win.h:973-993) + CRC of the K bits (sch.c:430-447) from the decision LLRs in D
+  auto decide = [&](bool write, bool final_try) -> uint32_t {
+    uint8_t*       sbuf = &sbuf_all[grp][0];
+    const uint32_t sbs  = nblk + 1;
+    const bool     whole = (long_sb & 7) == 0;
+    const uint32_t bps   = long_sb >> 3;
+    const uint32_t poly  = crc_poly & 0xffffffu;
+    short*         o16   = (p.dec_llr && live && write) ? p.dec_llr + (size_t)cb * K : nullptr;
+    uint32_t       c     = 0; // bit-serial CRC of sub-block li (lanes li < NB)
+    for (uint32_t b = 0; b < nblk; b++) {
+      const uint32_t k = b * 8 + slot;
+      const s2       v = from_u(D[(b * LPC + pl) * 8 + slot]);
+      const bool     ok = k < long_sb;
+      const unsigned long long m0 = __ballot(ok && v.x > 0), m1 = __ballot(ok && v.y > 0);
+      if (o16 && ok) {
+        o16[(2 * pl) * long_sb + k]     = AR::out16(v.x);
+        o16[(2 * pl + 1) * long_sb + k] = AR::out16(v.y);
+      }
+      if (li < NB) {
+        const unsigned long long m = (li & 1) ? m1 : m0;
+        const uint32_t bits = (uint32_t)(m >> (gbase + 8 * (li >> 1))) & 0xffu; // bit j = step 8 b + j of sub-block li
+        const uint32_t byte = __brev(bits) >> 24;                               // MSB first
+        const int      nbit = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
+        if (crc_poly) { // crc.c:92-140, MSB first, zero initial state
+          for (int t = 0; t < nbit; t++) {
+            const uint32_t x = (byte >> (7 - t)) & 1u;
+            c = ((c << 1) & 0xffffffu) ^ ((((c >> 23) ^ x) & 1u) ? poly : 0u);
+          }
+        }
+        if (!whole) {
+          sbuf[li * sbs + b] = (uint8_t)byte;
+        } else if (write && live && (uint32_t)li * bps + b < out_bytes) {
+          out[(uint32_t)li * bps + b] = (uint8_t)byte;
+        }
+      }
+    }
+    if (!whole && li < NB) {
+      sbuf[li * sbs + nblk] = 0;
+    }
+    uint32_t crc = 0;
+    if (crc_poly) {
+      auto mulmod = [&](uint32_t a, uint32_t m) { // a(x) m(x) mod g(x), all below x^24
+        uint32_t r = 0;
+#pragma unroll 4
+        for (int i = 23; i >= 0; i--) {
+          r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+          r ^= ((m >> i) & 1u) ? a : 0u;
+        }
+        return r;
+      };
+      crc = li < NB ? mulmod(c, p.crc_mult[li]) : 0u;
+#pragma unroll
+      for (int off = G / 2; off > 0; off >>= 1) {
+        crc ^= __shfl_xor(crc, off, G);
+      }
+    }
+    __syncthreads();
+    if (!whole && write && (!crc_poly || crc == 0 || final_try)) {
+      // ragged sub-blocks: cut the natural-order bytes out of the per-sub-block image
+      const uint32_t nbytes = K / 8;
+      const uint32_t lim    = out_bytes < nbytes ? out_bytes : nbytes;
+      for (uint32_t w = li; w < nbytes; w += G) {
+        uint32_t d = (w * 8) / long_sb, k = w * 8 - d * long_sb;
+        const uint8_t* q = sbuf + d * sbs + (k >> 3);
+        uint32_t       v = ((((uint32_t)q[0] << 8) | q[1]) >> (8 - (k & 7))) & 0xffu;
+        if (k + 8 > long_sb && d + 1 < (uint32_t)NB) {
+          v |= (uint32_t)sbuf[(d + 1) * sbs] >> (long_sb - k);
+        }
+        if (live && w < lim) {
+          out[w] = (uint8_t)v;
+        }
+      }
+    }
+    __syncthreads();
+    return crc;
+  };
+
+  bool     done = false;
+  uint32_t noi  = 0;
+
+  for (uint32_t n = p.n_begin; n < p.n_end; n++) {
+    const bool      dec1    = !(n & 1);
+    const bool      has_app = dec1 && n > 0;
+    const uint32_t* X       = dec1 ? S : A2;
+    const uint32_t* Y       = dec1 ? P0 : P1;
+    const short*    xt      = dec1 ? TL : TL + 6;
+    const short*    yt      = dec1 ? TL + 3 : TL + 9;
+
+    // Operands of an 8-step block live in one of THREE register sets; the block loops are unrolled by three with the sets in fixed roles
+    // (set = block index mod 3), so a set is filled two blocks before it is used and never copied: a copy of registers that a load is
+    // still filling would wait for the load (the first version of this kernel did that and spent 40 % of its time in s_waitcnt vmcnt(0)).
+    // The labelling residue of a block's first step is (8 b) mod 3 = (2 b) mod 3: a compile-time constant per set as well.
+    struct Ops {
+      uint32_t x[8], y[8], a[8];
+    };
+    Ops  buf[3];
+    auto issue = [&](uint32_t b, Ops& q) {
+      const uint32_t at = (b * LPC + pl) * 8;
+      load8(X + at, q.x);
+      load8(Y + at, q.y);
+      if (has_app) {
+        load8(A1 + at, q.a);
+      }
+    };
+    // systematic (+ a-priori) and parity operands of the 8 steps of a block; ap: the a-priori values alone (extrinsic subtraction)
+    auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        xs[j] = from_u(q.x[j]);
+        ys[j] = from_u(q.y[j]);
+        ap[j] = splat(0);
+        if (has_app) {
+          ap[j] = from_u(q.a[j]);
+          xs[j] = AR::add(ap[j], xs[j]);
+        }
+      }
+    };
+    s2 o;
+    // one backward step / one forward step without output at the residue (R0 + j) mod 3
+    auto bstep = [&](auto RES, s2 x, s2 y) {
+      constexpr int R = decltype(RES)::value;
+      s2            go, gc;
+      gammas<AR, R>(lk, x, y, go, gc);
+      o = beta_step<AR, R>(o, go, gc);
+    };
+    auto astep = [&](auto RES, s2 x, s2 y) {
+      constexpr int R = decltype(RES)::value;
+      s2            go, gc;
+      gammas<AR, R>(lk, x, y, go, gc);
+      alpha_step<AR, R, false>(lk, o, o, go, gc);
+    };
+#define LAT_RES(R0, j) std::integral_constant<int, ((R0) + (j)) % 3> {}
+
+    // ================= backward recursion (turbodecoder_win.h:551-681)
+    o = splat(-AR::kInf);
+    // pass 0: 40 steps on the head of every sub-block, all states unknown.  Blocks 4 ... 0: sets 1 0 2 1 0
+    {
+      constexpr int WB = TD_WIN_OVERLAP / 8; // 5
+      issue(WB - 1, buf[(WB - 1) % 3]);
+      issue(WB - 2, buf[(WB - 2) % 3]);
+      auto blk = [&](auto BC) {
+        constexpr int b = decltype(BC)::value, set = b % 3, R0 = (2 * b) % 3;
+        if constexpr (b >= 2) {
+          issue(b - 2, buf[(b - 2) % 3]);
+        }
+        s2 xs[8], ys[8], ap[8];
+        prep(buf[set], xs, ys, ap);
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+          if ((R0 + j) % 3 == 0) {
+            bstep(LAT_RES(0, 0), xs[j], ys[j]);
+          } else if ((R0 + j) % 3 == 1) {
+            bstep(LAT_RES(1, 0), xs[j], ys[j]);
+          } else {
+            bstep(LAT_RES(2, 0), xs[j], ys[j]);
+          }
+          if (AR::norm_at((uint32_t)b * 8 + j)) {
+            o = normalise<AR>(o);
+          }
+        }
+      };
+      static_assert(WB == 5, "warm-up of 40 steps");
+      blk(std::integral_constant<int, 4>{});
+      blk(std::integral_constant<int, 3>{});
+      blk(std::integral_constant<int, 2>{});
+      blk(std::integral_constant<int, 1>{});
+      blk(std::integral_constant<int, 0>{});
+    }
+    // hand every estimate (beta at step 0, labelling of residue 0) to the previous sub-block as its beta at step W (labelling of rW);
+    // the last sub-block starts from the tail trellis
+    {
+      short tr[8];
+      tail_trellis<AR>(xt, yt, tr);
+      const int st = state_of(rW, slot); // state this slot must hold; at residue 0 slot == state
+      short     tv = tr[0];
+#pragma unroll
+      for (int i = 1; i < 8; i++) {
+        tv = st == i ? tr[i] : tv;
+      }
+      const uint32_t u    = to_u(o);
+      const uint32_t own  = (uint32_t)__shfl((int)u, gbase + pl * 8 + st, 64);
+      const uint32_t next = (uint32_t)__shfl((int)u, gbase + ((pl + 1) % LPC) * 8 + st, 64);
+      const uint32_t lo   = own >> 16;
+      const uint32_t hi   = (pl == LPC - 1) ? (uint32_t)(uint16_t)tv : (next & 0xffffu);
+      o                   = from_u(lo | (hi << 16));
+      CK[nblk * G + li]   = to_u(o);
+    }
+    // pass 1: whole sub-block, a check-point at every block boundary; blocks nblk - 1 ... 0, block b in set b mod 3, block b - 2 requested
+    {
+      // FULL: all 8 steps of the block exist (every block but a ragged last one): no per-step conditions, one scheduling region
+      auto blk = [&](auto SET, auto FULLC, int b) {
+        constexpr int  set = decltype(SET)::value, R0 = (2 * set) % 3;
+        constexpr bool FULL = decltype(FULLC)::value;
+        if (b >= 2) {
+          issue((uint32_t)b - 2, buf[(set + 1) % 3]);
+        }
+        s2 xs[8], ys[8], ap[8];
+        prep(buf[set], xs, ys, ap);
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+          const uint32_t k = (uint32_t)b * 8 + j;
+          if (FULL || k < long_sb) {
+            if ((R0 + j) % 3 == 0) {
+              bstep(LAT_RES(0, 0), xs[j], ys[j]);
+            } else if ((R0 + j) % 3 == 1) {
+              bstep(LAT_RES(1, 0), xs[j], ys[j]);
+            } else {
+              bstep(LAT_RES(2, 0), xs[j], ys[j]);
+            }
+            if (j == 0 && b > 0) {
+              CK[(uint32_t)b * G + li] = to_u(o);
+            }
+            if (AR::norm_at(k)) {
+              o = normalise<AR>(o);
+            }
+          }
+        }
+      };
+      int b = (int)nblk - 1;
+      // (the sets of the two first blocks are only known at run time: their loads go through a switch once)
+      switch (b % 3) {
+        case 0: issue((uint32_t)b, buf[0]); issue((uint32_t)b - 1, buf[2]); break;
+        case 1: issue((uint32_t)b, buf[1]); issue((uint32_t)b - 1, buf[0]); break;
+        default: issue((uint32_t)b, buf[2]); issue((uint32_t)b - 1, buf[1]); break;
+      }
+      // the first block may be ragged (W not a multiple of 8): guarded code for that one
+      using T = std::true_type;
+      using F = std::false_type;
+      switch (b % 3) {
+        case 0: blk(std::integral_constant<int, 0>{}, F{}, b--); break;
+        case 1: blk(std::integral_constant<int, 1>{}, F{}, b--); break;
+        default: blk(std::integral_constant<int, 2>{}, F{}, b--); break;
+      }
+      if (b % 3 == 1) {
+        blk(std::integral_constant<int, 1>{}, T{}, b--);
+      }
+      if (b % 3 == 0) {
+        blk(std::integral_constant<int, 0>{}, T{}, b--);
+      }
+      for (; b >= 2; b -= 3) {
+        blk(std::integral_constant<int, 2>{}, T{}, b);
+        blk(std::integral_constant<int, 1>{}, T{}, b - 1);
+        blk(std::integral_constant<int, 0>{}, T{}, b - 2);
+      }
+    }
+    __syncthreads(); // check-point stores before their loads
+
+    // ================= forward recursion + LLR (turbodecoder_win.h:684-832)
+    o = splat(-AR::kInf);
+    {
+      // warm-up: the last 40 steps of every sub-block, blocks w0 / 8 ... (W - 1) / 8, block b in set b mod 3
+      const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
+      const uint32_t bl = (long_sb - 1) >> 3, b0 = w0 >> 3;
+      auto           blk = [&](auto SET, uint32_t b) {
+        constexpr int set = decltype(SET)::value, R0 = (2 * set) % 3;
+        if (b + 2 <= bl) {
+          issue(b + 2, buf[(set + 2) % 3]);
+        }
+        s2 xs[8], ys[8], ap[8];
+        prep(buf[set], xs, ys, ap);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t k = b * 8 + j;
+          if (k >= w0 && k < long_sb) {
+            if ((R0 + j) % 3 == 0) {
+              astep(LAT_RES(0, 0), xs[j], ys[j]);
+            } else if ((R0 + j) % 3 == 1) {
+              astep(LAT_RES(1, 0), xs[j], ys[j]);
+            } else {
+              astep(LAT_RES(2, 0), xs[j], ys[j]);
+            }
+            if (AR::norm_at(k - w0)) {
+              o = normalise<AR>(o);
+            }
+          }
+        }
+      };
+      switch (b0 % 3) {
+        case 0: issue(b0, buf[0]); issue(b0 + 1, buf[1]); break;
+        case 1: issue(b0, buf[1]); issue(b0 + 1, buf[2]); break;
+        default: issue(b0, buf[2]); issue(b0 + 1, buf[0]); break;
+      }
+      uint32_t b = b0;
+      if (b % 3 == 1) {
+        blk(std::integral_constant<int, 1>{}, b++);
+      }
+      if (b % 3 == 2 && b <= bl) {
+        blk(std::integral_constant<int, 2>{}, b++);
+      }
+      for (; b + 2 <= bl; b += 3) {
+        blk(std::integral_constant<int, 0>{}, b);
+        blk(std::integral_constant<int, 1>{}, b + 1);
+        blk(std::integral_constant<int, 2>{}, b + 2);
+      }
+      if (b <= bl) {
+        blk(std::integral_constant<int, 0>{}, b++);
+      }
+      if (b <= bl) {
+        blk(std::integral_constant<int, 1>{}, b++);
+      }
+    }
+    // hand every estimate (alpha at step W, labelling of rW) to the next sub-block as its alpha at step 0 (slot == state); the first
+    // sub-block starts in state 0
+    {
+      const int      src  = slot_of(rW, slot); // slot that holds state `slot` in the labelling of rW
+      const uint32_t u    = to_u(o);
+      const uint32_t own  = (uint32_t)__shfl((int)u, gbase + pl * 8 + src, 64);
+      const uint32_t prev = (uint32_t)__shfl((int)u, gbase + ((pl + LPC - 1) % LPC) * 8 + src, 64);
+      const uint32_t lo   = (pl == 0) ? (uint32_t)(uint16_t)(short)(slot ? -AR::kInf : 0) : (prev >> 16);
+      const uint32_t hi   = own & 0xffffu;
+      o                   = from_u(lo | (hi << 16));
+    }
+
+    const uint32_t* lut  = dec1 ? p.deint : p.inter; // per (block, destination pair, step): row | source sub-blocks (turbo_host.cpp)
+    uint32_t*       dst  = dec1 ? A2 : A1;
+    const bool      fuse = dec1 && n >= 2;
+    const bool      last = (n + 1 == p.n_end) || crc_poly;
+    {
+      uint32_t ckb[3], trb[3]; // check-point and exchange entry of a block, same three-set scheme
+      auto     issue_aux = [&](uint32_t b, int set) {
+        ckb[set] = CK[(b + 1) * G + li];
+        trb[set] = lut[(b * LPC + pl) * 8 + slot];
+      };
+      auto blk = [&](auto SET, auto FULLC, uint32_t b) {
+        constexpr int  set = decltype(SET)::value, R0 = (2 * set) % 3;
+        constexpr bool FULL = decltype(FULLC)::value;
+        const int      len = FULL ? 8 : ((long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8);
+        if (b + 2 < nblk) {
+          issue(b + 2, buf[(set + 2) % 3]);
+          issue_aux(b + 2, (set + 2) % 3);
+        }
+        s2 xs[8], ys[8], ap[8];
+        prep(buf[set], xs, ys, ap);
+        uint32_t wrapj[8]; // (8-bit only) destination rows of the 8 steps: the wrap flag of the extrinsic subtraction
+        if (AR::kIs8 && !dec1 && wrap_row != 0xffffffffu) {
+          load8(lut + (b * LPC + pl) * 8, wrapj);
+        }
+        // branch metrics of the 8 steps: shared by the re-derived beta, alpha and the LLR
+        s2 go[8], gc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if ((R0 + j) % 3 == 0) {
+            gammas<AR, 0>(lk, xs[j], ys[j], go[j], gc[j]);
+          } else if ((R0 + j) % 3 == 1) {
+            gammas<AR, 1>(lk, xs[j], ys[j], go[j], gc[j]);
+          } else {
+            gammas<AR, 2>(lk, xs[j], ys[j], go[j], gc[j]);
+          }
+        }
+        // re-derive beta(8 b + 1 ... 8 b + len) (the stored, pre-normalisation values) from the check-point
+        s2 bt[8];
+        s2 st = from_u(ckb[set]);
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+          bt[j] = st; // entry len - 1 is the check-point itself; the ones below it are overwritten
+        }
+#pragma unroll
+        for (int j = 6; j >= 0; j--) {
+          if (FULL || j <= len - 2) {
+            const uint32_t idx = b * 8 + j + 2; // step index of the stored value we start from
+            if ((FULL || idx != long_sb) && AR::norm_at(idx)) {
+              st = normalise<AR>(st);
+            }
+            if ((R0 + j + 1) % 3 == 0) {
+              st = beta_step<AR, 0>(st, go[j + 1], gc[j + 1]);
+            } else if ((R0 + j + 1) % 3 == 1) {
+              st = beta_step<AR, 1>(st, go[j + 1], gc[j + 1]);
+            } else {
+              st = beta_step<AR, 2>(st, go[j + 1], gc[j + 1]);
+            }
+            bt[j] = st;
+          }
+        }
+        s2 kept = splat(0), keptraw = splat(0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (FULL || j < len) {
+            s2 llr;
+            if ((R0 + j) % 3 == 0) {
+              llr = alpha_step<AR, 0, true>(lk, o, bt[j], go[j], gc[j]);
+            } else if ((R0 + j) % 3 == 1) {
+              llr = alpha_step<AR, 1, true>(lk, o, bt[j], go[j], gc[j]);
+            } else {
+              llr = alpha_step<AR, 2, true>(lk, o, bt[j], go[j], gc[j]);
+            }
+            const uint32_t k = b * 8 + j;
+            if (AR::norm_at(k)) {
+              o = normalise<AR>(o);
+            }
+            s2 proc = llr;
+            if (fuse) {
+              proc = AR::ex_sub(llr, ap[j], k == wrap_row);
+            } else if (!dec1) {
+              proc = AR::ex_sub(llr, xs[j], AR::kIs8 && (wrapj[j] & 0xffffu) == wrap_row);
+            }
+            kept    = slot == j ? proc : kept; // lane (pair, j) keeps the output of step j
+            keptraw = slot == j ? llr : keptraw;
+          }
+        }
+        // exchange of the block's 8 rows: lane (pair p', step j) assembles the two values of its destination sub-blocks
+        const uint32_t trl = trb[set];
+        const uint32_t row = trl & 0xffffu, jlo = (trl >> 16) & 31u, jhi = (trl >> 21) & 31u;
+        const int      a_l = gbase + (int)(jlo >> 1) * 8 + slot, c_l = gbase + (int)(jhi >> 1) * 8 + slot;
+        auto           pick = [&](uint32_t v) {
+          const uint32_t a  = (uint32_t)__shfl((int)v, a_l, 64);
+          const uint32_t c  = (uint32_t)__shfl((int)v, c_l, 64);
+          const uint32_t lo = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
+          const uint32_t hi = (jhi & 1u) ? (c >> 16) : (c & 0xffffu);
+          return lo | (hi << 16);
+        };
+        const uint32_t v   = pick(to_u(kept));
+        const uint32_t dat = ((row >> 3) * LPC + pl) * 8 + (row & 7u);
+        if (slot < len) {
+          dst[dat] = v;
+        }
+        if (last) {
+          // what tdec_decision_byte reads (turbodecoder.c:370-378), natural order: ext1 after decoder 1, the de-interleaved ext2 after decoder 2
+          if (dec1) {
+            if (slot < len) {
+              D[(b * LPC + pl) * 8 + slot] = to_u(keptraw);
+            }
+          } else {
+            const uint32_t r = pick(to_u(keptraw));
+            if (slot < len) {
+              D[dat] = r;
+            }
+          }
+        }
+      };
+      issue(0, buf[0]);
+      issue_aux(0, 0);
+      issue(1, buf[1]);
+      issue_aux(1, 1);
+      using T = std::true_type;
+      using F = std::false_type;
+      uint32_t b = 0;
+      for (; b + 3 < nblk; b += 3) { // full blocks only: the last block of the sub-block is left to the guarded code below
+        blk(std::integral_constant<int, 0>{}, T{}, b);
+        blk(std::integral_constant<int, 1>{}, T{}, b + 1);
+        blk(std::integral_constant<int, 2>{}, T{}, b + 2);
+      }
+      if (b + 1 < nblk) {
+        blk(std::integral_constant<int, 0>{}, T{}, b++);
+        if (b + 1 < nblk) {
+          blk(std::integral_constant<int, 1>{}, T{}, b++);
+        }
+      }
+      switch (b % 3) { // b == nblk - 1
+        case 0: blk(std::integral_constant<int, 0>{}, F{}, b); break;
+        case 1: blk(std::integral_constant<int, 1>{}, F{}, b); break;
+        default: blk(std::integral_constant<int, 2>{}, F{}, b); break;
+      }
+    }
+#undef LAT_RES
+    __syncthreads();
+    if (crc_poly) {
+      // decode_tb_cb (sch.c:420-454): hard bits + CRC after every half iteration; a block stops at its first match
+      const bool     fin = n + 1 == p.n_end;
+      const uint32_t crc = decide(!done, fin);
+      if (!done) {
+        noi++;
+        done = crc == 0;
+      }
+      if (__all(done || !live) || fin) {
+        break;
+      }
+    }
+  }
+  if (!crc_poly) {
+    decide(true, true);
+  } else if (p.noi && live && li == 0) {
+    p.noi[cb_raw]    = (int)noi;
+    p.crc_ok[cb_raw] = done ? 1 : 0;
+  }
+}
+
+} // namespace lat
+
+uint32_t lat_ws_dwords(uint32_t K, int nb)
+{
+  return (lat::ws_dwords(K, nb) + 3u) & ~3u;
+}
+
+// latency kernel: nb = 16 / 8 sub-blocks, 16- or 8-bit arithmetic (the 32-sub-block 8-bit decoder needs two waves per block: not built)
+hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t stream)
+{
+  const bool es  = p.crc_poly || p.desc;
+  const int  bpw = nb == 16 ? 1 : 2;
+  dim3       grid((unsigned)((p.n_cb + bpw - 1) / bpw));
+#define LAUNCH(LPC, AR)                                                                            \
+  do {                                                                                             \
+    if (es) {                                                                                      \
+      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, true>), grid, dim3(64), 0, stream, p);     \
+    } else {                                                                                       \
+      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, false>), grid, dim3(64), 0, stream, p);    \
+    }                                                                                              \
+  } while (0)
+  if (!arith8 && nb == 16) {
+    LAUNCH(8, Ar16);
+  } else if (!arith8 && nb == 8) {
+    LAUNCH(4, Ar16);
+  } else if (arith8 && nb == 16) {
+    LAUNCH(8, Ar8);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
+} // namespace turbo
+} // namespace phyhip

@@ -330,8 +330,9 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
   bool     done = false;
   uint32_t noi  = 0;
 
-  for (uint32_t n = p.n_begin; n < p.n_end; n++) {
-    const bool      dec1    = !(n & 1);
+  // one half iteration (turbodecoder_iter.h:72-141); DEC1 is a template parameter so that nothing inside the step loops branches on it
+  auto half_iteration = [&](auto DEC1C, const uint32_t n) {
+    constexpr bool  dec1    = decltype(DEC1C)::value;
     const bool      has_app = dec1 && n > 0;
     const uint32_t* X       = dec1 ? S : A2;
     const uint32_t* Y       = dec1 ? P0 : P1;
@@ -565,7 +566,6 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
 
     const uint32_t* lut  = dec1 ? p.deint : p.inter; // per (block, destination pair, step): row | source sub-blocks (turbo_host.cpp)
     uint32_t*       dst  = dec1 ? A2 : A1;
-    const bool      fuse = dec1 && n >= 2;
     const bool      last = (n + 1 == p.n_end) || crc_poly;
     {
       uint32_t ckb[3], trb[3]; // check-point and exchange entry of a block, same three-set scheme
@@ -639,10 +639,11 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
             if (AR::norm_at(k)) {
               o = normalise<AR>(o);
             }
-            s2 proc = llr;
-            if (fuse) {
+            // decoder 1: ext1 - app1 (the a-priori it just used; zero in the first half iteration); decoder 2: ext2 - its systematic input
+            s2 proc;
+            if constexpr (dec1) {
               proc = AR::ex_sub(llr, ap[j], k == wrap_row);
-            } else if (!dec1) {
+            } else {
               proc = AR::ex_sub(llr, xs[j], AR::kIs8 && (wrapj[j] & 0xffffu) == wrap_row);
             }
             kept    = slot == j ? proc : kept; // lane (pair, j) keeps the output of step j
@@ -705,6 +706,14 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
     }
 #undef LAT_RES
     __syncthreads();
+  };
+
+  for (uint32_t n = p.n_begin; n < p.n_end; n++) {
+    if (!(n & 1)) {
+      half_iteration(std::true_type{}, n);
+    } else {
+      half_iteration(std::false_type{}, n);
+    }
     if (crc_poly) {
       // decode_tb_cb (sch.c:420-454): hard bits + CRC after every half iteration; a block stops at its first match
       const bool     fin = n + 1 == p.n_end;

@@ -49,9 +49,8 @@ void bind_thread();
 
 // Table uploads (object creation, first use of a new block size / generator).  A hipMemcpy from pageable memory returns when the HOST
 // buffer may be reused; a small copy is staged and reaches the device in null-stream order -- and every kernel of this library runs on
-// hipStreamNonBlocking streams, which do not order themselves against the null stream.  Seen once under the reference's
-// turbodecoder_test: the first srsran_tdec_run_all(K = 40) of a process ran with a not-yet-written interleaver table (10 wrong bits in the
-// first block, none after).  upload() returns when the device has the data, whichever stream reads it next.
+// hipStreamNonBlocking streams, which do not order themselves against the null stream.  Nothing documents that such a copy is complete on
+// the device when hipMemcpy returns, so upload() makes it so: it returns when the device has the data, whichever stream reads it next.
 inline hipError_t upload(void* dst, const void* src, size_t bytes)
 {
   const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);

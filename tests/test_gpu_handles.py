@@ -197,6 +197,7 @@ def test_same_shape_calls_are_merged_and_resumable(hiplib):
     _, llr = O.turbo_llrs(K, n_thr, 0.0, 99)
     ref = O.turbo_decode(llr, nit, K)
     b0, u0 = _stats(lib)
+    gate = threading.Barrier(n_thr)  # every round of calls is submitted at once: 16 requests for the queue's 4 lanes
 
     def worker(t):
         def run():
@@ -205,7 +206,9 @@ def test_same_shape_calls_are_merged_and_resumable(hiplib):
             lib.srsran_tdec_force_not_sb(C.byref(h))
             out = np.zeros(K // 8, np.uint8)
             for _ in range(calls):
-                assert lib.srsran_tdec_run_all(C.byref(h), O.P(llr[t].copy()), O.P(out), nit, K) == 0
+                x = llr[t].copy()
+                gate.wait(timeout=120)
+                assert lib.srsran_tdec_run_all(C.byref(h), O.P(x), O.P(out), nit, K) == 0
                 assert np.array_equal(out, ref[t]), t
             lib.srsran_tdec_free(C.byref(h))
         return run

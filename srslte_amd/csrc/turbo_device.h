@@ -80,17 +80,23 @@ static inline size_t gen_ws_shorts(uint32_t K)
 
 hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t stream);
 // latency kernel (turbo_lat_kernels.hip): one code block per wave, states across lanes; same WinParams with its own workspace layout
-// (lat_ws_dwords per code block).  Exists for 16 sub-blocks (16- and 8-bit arithmetic) and 8 sub-blocks (16-bit).
+// (lat_ws_dwords per code block).  Exists for every window decoder: 16 / 8 sub-blocks (16-bit), 32 / 16 sub-blocks (8-bit; 32 sub-blocks = two waves per block).
 hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t stream);
 uint32_t   lat_ws_dwords(uint32_t K, int nb);
 static inline bool lat_exists(int nb, bool arith8)
 {
-  return (nb == 16) || (nb == 8 && !arith8);
+  return (nb == 16) || (nb == 8 && !arith8) || (nb == 32 && arith8);
 }
-// Batches up to this many code blocks go to the latency kernel: one wave per block fills the chip's 1024 SIMDs once (a lone wave already
-// issues at the rate a SIMD sustains for packed / three-operand instructions, tools/probe/valu_issue_probe.hip), two waves per SIMD take
-// twice as long each; beyond that the throughput kernel's 8 blocks per wave win (crossover measured: profiles/r03_tti.json).
-constexpr uint32_t kLatMaxBlocks = 2048;
+// Batches of up to this many WAVES go to the latency kernel (one wave per code block; two for the 32-sub-block 8-bit decoder): one wave per
+// SIMD fills the chip's 1024 SIMDs once -- a lone wave already issues at the rate a SIMD sustains for packed / three-operand instructions
+// (tools/probe/valu_issue_probe.hip) --, two waves per SIMD take twice as long each; beyond that the throughput kernel's 8 blocks per wave
+// win.  Measured (K = 6144, 8 half iterations, profiles/r03_lat_time.txt): 16-bit 1024 blocks 0.67 against 1.81 ms, 2048 blocks 1.30 against
+// 1.83, 4096 blocks 2.65 against 2.03; 8-bit (two waves per block) 512 blocks 0.47 against 1.18, 1024 blocks 1.01 against 1.21, 2048 blocks 2.00 against 1.31.
+constexpr uint32_t kLatMaxBlocks = 2048; // in waves
+static inline uint32_t lat_waves(int nb, uint32_t n_cb)
+{
+  return nb == 32 ? 2 * n_cb : n_cb;
+}
 } // namespace turbo
 } // namespace phyhip
 struct srsran_hip_tdec_batch;

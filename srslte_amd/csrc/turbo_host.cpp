@@ -175,7 +175,7 @@ static bool want_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
     return h->state_in_lat;
   }
   const int k = knob(KNOB_TDEC_LAT);
-  return k == 0 ? false : (k > 0 ? true : n_cb <= turbo::kLatMaxBlocks);
+  return k == 0 ? false : (k > 0 ? true : turbo::lat_waves(h->nb, n_cb) <= turbo::kLatMaxBlocks);
 }
 static int ensure_lat_ws(srsran_hip_tdec_batch* h, uint32_t n_cb)
 {

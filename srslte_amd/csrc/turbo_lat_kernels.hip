@@ -179,12 +179,14 @@ __host__ __device__ inline uint32_t ws_dwords(uint32_t K, int nb)
 }
 
 template <int LPC, class AR, bool ES>
-__global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
+__global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const WinParams p)
 {
   constexpr int NB  = 2 * LPC;
-  constexpr int G   = 8 * LPC;  // lanes per code block
-  constexpr int BPW = 64 / G;   // code blocks per wave
-  __shared__ uint8_t sbuf_all[BPW][NB * (6144 / NB / 8 + 2)]; // hard-bit image of ragged sub-blocks (decision)
+  constexpr int G   = 8 * LPC;            // lanes per code block: 32 (two blocks per wave), 64 (one wave) or 128 (two waves, 32 sub-blocks)
+  constexpr int BPW = G >= 64 ? 1 : 64 / G; // code blocks per workgroup
+  __shared__ uint8_t  sbuf_all[BPW][NB * (6144 / NB / 8 + 2)]; // hard-bit image of ragged sub-blocks (decision)
+  __shared__ uint32_t xch[2][G > 64 ? G : 1];                  // lane exchange across the two waves of a 128-lane block
+  __shared__ uint32_t xcrc[2];
 
   const int      lane = threadIdx.x;
   const int      grp  = lane / G, li = lane % G, pl = li >> 3, slot = li & 7;
@@ -207,6 +209,22 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
   uint32_t* A2 = ws + 5 * AW;
   uint32_t* CK = ws + 6 * AW;                                       // (nblk + 1) check-points of G dwords
   short*    TL = reinterpret_cast<short*>(CK + (size_t)(nblk + 1) * G); // 12 tail LLRs
+
+  // two values of `v` held by other lanes of the code block (absolute lane numbers): ds_bpermute inside a wave, an LDS image + one barrier
+  // when the block spans two waves (`par` alternates the image so that no second barrier is needed before the next use)
+  int  xpar  = 0;
+  auto read2 = [&](uint32_t v, int la, int lc, uint32_t& a, uint32_t& c) {
+    if constexpr (G <= 64) {
+      a = (uint32_t)__shfl((int)v, la, 64);
+      c = (uint32_t)__shfl((int)v, lc, 64);
+    } else {
+      xch[xpar][lane] = v;
+      __syncthreads();
+      a = xch[xpar][la];
+      c = xch[xpar][lc];
+      xpar ^= 1;
+    }
+  };
 
   // ---- phase 0: input extraction (turbodecoder_win.h:888-930 / turbodecoder_iter.h:58-70,88-102): element (step 8 b + j, pair pl) per lane
   if (p.n_begin == 0) {
@@ -268,10 +286,10 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
         o16[(2 * pl) * long_sb + k]     = AR::out16(v.x);
         o16[(2 * pl + 1) * long_sb + k] = AR::out16(v.y);
       }
-      if (li < NB) {
-        const unsigned long long m = (li & 1) ? m1 : m0;
-        const uint32_t bits = (uint32_t)(m >> (gbase + 8 * (li >> 1))) & 0xffu; // bit j = step 8 b + j of sub-block li
-        const uint32_t byte = __brev(bits) >> 24;                               // MSB first
+      if (slot < 2) { // lane (pair, slot 0 / 1) takes the bits of sub-block 2 pair / 2 pair + 1 from its own 8 lanes of the ballot
+        const unsigned long long m = slot ? m1 : m0;
+        const uint32_t bits = (uint32_t)(m >> ((lane & 63) & ~7)) & 0xffu; // bit j = step 8 b + j
+        const uint32_t byte = __brev(bits) >> 24;                          // MSB first
         const int      nbit = (int)(long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8;
         if (crc_poly) { // crc.c:92-140, MSB first, zero initial state
           for (int t = 0; t < nbit; t++) {
@@ -279,15 +297,16 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
             c = ((c << 1) & 0xffffffu) ^ ((((c >> 23) ^ x) & 1u) ? poly : 0u);
           }
         }
+        const uint32_t d = 2u * pl + slot;
         if (!whole) {
-          sbuf[li * sbs + b] = (uint8_t)byte;
-        } else if (write && live && (uint32_t)li * bps + b < out_bytes) {
-          out[(uint32_t)li * bps + b] = (uint8_t)byte;
+          sbuf[d * sbs + b] = (uint8_t)byte;
+        } else if (write && live && d * bps + b < out_bytes) {
+          out[d * bps + b] = (uint8_t)byte;
         }
       }
     }
-    if (!whole && li < NB) {
-      sbuf[li * sbs + nblk] = 0;
+    if (!whole && slot < 2) {
+      sbuf[(2u * pl + slot) * sbs + nblk] = 0;
     }
     uint32_t crc = 0;
     if (crc_poly) {
@@ -300,10 +319,17 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
         }
         return r;
       };
-      crc = li < NB ? mulmod(c, p.crc_mult[li]) : 0u;
+      crc = slot < 2 ? mulmod(c, p.crc_mult[2 * pl + slot]) : 0u;
 #pragma unroll
-      for (int off = G / 2; off > 0; off >>= 1) {
-        crc ^= __shfl_xor(crc, off, G);
+      for (int off = (G < 64 ? G : 64) / 2; off > 0; off >>= 1) {
+        crc ^= __shfl_xor(crc, off, G < 64 ? G : 64);
+      }
+      if constexpr (G > 64) { // the two waves of the block
+        if ((lane & 63) == 0) {
+          xcrc[lane >> 6] = crc;
+        }
+        __syncthreads();
+        crc = xcrc[0] ^ xcrc[1];
       }
     }
     __syncthreads();
@@ -430,9 +456,8 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
       for (int i = 1; i < 8; i++) {
         tv = st == i ? tr[i] : tv;
       }
-      const uint32_t u    = to_u(o);
-      const uint32_t own  = (uint32_t)__shfl((int)u, gbase + pl * 8 + st, 64);
-      const uint32_t next = (uint32_t)__shfl((int)u, gbase + ((pl + 1) % LPC) * 8 + st, 64);
+      uint32_t own, next;
+      read2(to_u(o), gbase + pl * 8 + st, gbase + ((pl + 1) % LPC) * 8 + st, own, next);
       const uint32_t lo   = own >> 16;
       const uint32_t hi   = (pl == LPC - 1) ? (uint32_t)(uint16_t)tv : (next & 0xffffu);
       o                   = from_u(lo | (hi << 16));
@@ -556,9 +581,8 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
     // sub-block starts in state 0
     {
       const int      src  = slot_of(rW, slot); // slot that holds state `slot` in the labelling of rW
-      const uint32_t u    = to_u(o);
-      const uint32_t own  = (uint32_t)__shfl((int)u, gbase + pl * 8 + src, 64);
-      const uint32_t prev = (uint32_t)__shfl((int)u, gbase + ((pl + LPC - 1) % LPC) * 8 + src, 64);
+      uint32_t own, prev;
+      read2(to_u(o), gbase + pl * 8 + src, gbase + ((pl + LPC - 1) % LPC) * 8 + src, own, prev);
       const uint32_t lo   = (pl == 0) ? (uint32_t)(uint16_t)(short)(slot ? -AR::kInf : 0) : (prev >> 16);
       const uint32_t hi   = own & 0xffffu;
       o                   = from_u(lo | (hi << 16));
@@ -655,8 +679,8 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
         const uint32_t row = trl & 0xffffu, jlo = (trl >> 16) & 31u, jhi = (trl >> 21) & 31u;
         const int      a_l = gbase + (int)(jlo >> 1) * 8 + slot, c_l = gbase + (int)(jhi >> 1) * 8 + slot;
         auto           pick = [&](uint32_t v) {
-          const uint32_t a  = (uint32_t)__shfl((int)v, a_l, 64);
-          const uint32_t c  = (uint32_t)__shfl((int)v, c_l, 64);
+          uint32_t a, c;
+          read2(v, a_l, c_l, a, c);
           const uint32_t lo = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
           const uint32_t hi = (jhi & 1u) ? (c >> 16) : (c & 0xffffu);
           return lo | (hi << 16);
@@ -722,7 +746,7 @@ __global__ __launch_bounds__(64) void tdec_lat_kernel(const WinParams p)
         noi++;
         done = crc == 0;
       }
-      if (__all(done || !live) || fin) {
+      if ((G > 64 ? (done || !live) : (bool)__all(done || !live)) || fin) { // (a 128-lane block is alone in its workgroup: `done` is uniform)
         break;
       }
     }
@@ -742,19 +766,19 @@ uint32_t lat_ws_dwords(uint32_t K, int nb)
   return (lat::ws_dwords(K, nb) + 3u) & ~3u;
 }
 
-// latency kernel: nb = 16 / 8 sub-blocks, 16- or 8-bit arithmetic (the 32-sub-block 8-bit decoder needs two waves per block: not built)
+// latency kernel: 16 / 8 sub-blocks with 16-bit arithmetic, 32 / 16 sub-blocks with 8-bit arithmetic (32 sub-blocks: two waves per block)
 hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t stream)
 {
   const bool es  = p.crc_poly || p.desc;
-  const int  bpw = nb == 16 ? 1 : 2;
+  const int  bpw = nb >= 16 ? 1 : 2;
   dim3       grid((unsigned)((p.n_cb + bpw - 1) / bpw));
-#define LAUNCH(LPC, AR)                                                                            \
-  do {                                                                                             \
-    if (es) {                                                                                      \
-      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, true>), grid, dim3(64), 0, stream, p);     \
-    } else {                                                                                       \
-      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, false>), grid, dim3(64), 0, stream, p);    \
-    }                                                                                              \
+#define LAUNCH(LPC, AR)                                                                                               \
+  do {                                                                                                                \
+    if (es) {                                                                                                         \
+      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, true>), grid, dim3(LPC > 8 ? 8 * LPC : 64), 0, stream, p);    \
+    } else {                                                                                                          \
+      hipLaunchKernelGGL((lat::tdec_lat_kernel<LPC, AR, false>), grid, dim3(LPC > 8 ? 8 * LPC : 64), 0, stream, p);   \
+    }                                                                                                                 \
   } while (0)
   if (!arith8 && nb == 16) {
     LAUNCH(8, Ar16);
@@ -762,6 +786,8 @@ hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t strea
     LAUNCH(4, Ar16);
   } else if (arith8 && nb == 16) {
     LAUNCH(8, Ar8);
+  } else if (arith8 && nb == 32) {
+    LAUNCH(16, Ar8);
   } else {
     return hipErrorInvalidValue;
   }

@@ -9,16 +9,17 @@ import srslte_amd as S, oracle_api as O
 from srslte_amd import capi
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 6144
 sb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+llr8 = len(sys.argv) > 3 and sys.argv[3] == "8"
 lib = S.lib(); lib.srsran_hip_set_device(0)
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
-_, pool = O.turbo_llrs(K, 16, 1.0, seed=1)
+_, pool = (O.turbo_llrs_8bit if llr8 else O.turbo_llrs)(K, 16, 1.0, seed=1)
 if sb:
-    pool = np.stack([O.natural_to_sb_layout(pool[i], K, 16) for i in range(16)])
+    pool = np.stack([O.natural_to_sb_layout(pool[i], K, 32 if llr8 else 16) for i in range(16)])
 stride = pool.shape[1]
 for n_cb in (13, 104, 832, 1024, 2048, 4096, 8192):
     d_llr = torch.from_numpy(pool).to(dev).repeat((n_cb + 15) // 16, 1)[:n_cb].contiguous()
     d_bits = torch.zeros((n_cb, K // 8), dtype=torch.uint8, device=dev)
-    dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO)
+    dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO, llr8=llr8)
     row = []
     for lat in (b"0", b"1"):
         lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", lat)
@@ -26,7 +27,12 @@ for n_cb in (13, 104, 832, 1024, 2048, 4096, 8192):
             best = 1e9
             for rep in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); dec.run(d_llr, stride, d_bits, K // 8, n_cb, nit, sb, st); e1.record(); torch.cuda.synchronize()
+                e0.record()
+                if llr8:
+                    capi.check(lib.srsran_hip_tdec_batch_run_8bit(dec._h, d_llr.data_ptr(), stride, d_bits.data_ptr(), K // 8, n_cb, nit, sb, st), 'run8')
+                else:
+                    dec.run(d_llr, stride, d_bits, K // 8, n_cb, nit, sb, st)
+                e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1))
             row.append(best)
     print("K=%d sb=%d n_cb=%5d  throughput kernel: %s   latency kernel: %s  (ms at 1/2/4/8 half iterations)" %

@@ -22,7 +22,7 @@ def pct(v, p):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=200)
-    ap.add_argument("--snrs", default="6.0,4.8")
+    ap.add_argument("--snrs", default="8.0,6.0,4.8")
     ap.add_argument("--ntb", default="1,8,64")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default="")

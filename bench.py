@@ -419,29 +419,14 @@ def worker(a):
                 res["error"] = "GPU hard decisions differ from the CPU decoder on the sampled code blocks"
             res["roofline_ofdm"]["cpu_port"] = ofdm_cpu_port(n_prb, n_fft)
 
-    # ---- PCIe-inclusive rate of the headline decoder (never `value`): pinned host LLRs -> HBM -> decode -> bytes back to the host
+    # ---- PCIe-inclusive rates (never `value`): inputs start in pinned HOST memory, results end there.  Chunks alternate between two streams
+    # (each: H2D -> decode -> D2H), so the upload of one chunk runs under the decode of the other; the H2D rate of the same bytes alone and
+    # the device-resident kernel rate bound it from above.
     if world == 1 and not a.no_extras:
-        n_q = min(n_cb, 16380)
-        h_llr = torch.empty((n_q, in_stride), dtype=torch.int16).pin_memory()
-        h_llr.copy_(d_llr[:n_q])
-        h_out = torch.empty((n_q, k_cb // 8), dtype=torch.uint8).pin_memory()
-        d_q, d_qo = torch.empty_like(d_llr[:n_q]), torch.empty_like(d_bits[:n_q])
-        tq = S.TdecBatch(k_cb, n_q, capi.TDEC_AUTO)
-        best = None
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            d_q.copy_(h_llr, non_blocking=True)
-            tq.run(d_q, in_stride, d_qo, k_cb // 8, n_q, nit, 0, stream)
-            h_out.copy_(d_qo, non_blocking=True)
-            torch.cuda.synchronize()
-            t = time.perf_counter() - t1
-            best = t if best is None else min(best, t)
-        res["pcie_inclusive"] = {"value": n_q * k_cb / best / 1e6, "unit": "Mbit/s", "ms": best * 1e3,
-                                 "what": "%d code blocks: H2D of %.0f MB of int16 LLRs from pinned memory + decode + D2H of the bytes, one stream, "
-                                         "no overlap (best of 3)" % (n_q, n_q * in_stride * 2 / 1e6),
-                                 "h2d_gb_per_s_lower_bound": n_q * in_stride * 2 / best / 1e9}
-        del tq, d_q, d_qo, h_llr, h_out
+        import bench_legs as L
+
+        res["pcie_inclusive"] = L.host_fed_turbo(S, capi, torch, dev, d_llr, in_stride, k_cb, nit, llr8=False, chunk=16380)
+        res["pcie_inclusive_8bit"] = L.host_fed_turbo(S, capi, torch, dev, None, 3 * k_cb + 12, k_cb, nit, llr8=True, chunk=8190)
 
     # ---- the other single-GPU configurations of BASELINE.json
     del tdec, d_llr, d_bits, d_time, d_re

@@ -313,7 +313,7 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
 
 # ------------------------------------------------------------------------------------------------ configs[3]: multi-UE uplink
 
-def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, iters=8):
+def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, iters=8, host_fed=True):
     """64 independent 20 MHz UEs per GPU x `sf` subframes each, every stage of the PUSCH receive path that is on the hot path:
     OFDM demodulation -> single-tap equaliser -> SC-FDMA transform de-precoding (1200-point IDFT) -> 64-QAM soft demodulation +
     descrambling -> rate de-matching + turbo decoding with CRC early stop + transport-block CRC.  The signal comes from the library's
@@ -439,6 +439,9 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                         "frac": n_tb * unit_bytes / t_step / 1e9 / HBM_PEAK_GBS, "traffic": tr_u, "traffic_source": src_u, "avg_launch_ms": t_step * 1e3,
                         "algorithmic_bytes_per_launch": n_tb * unit_bytes,
                         "note": "algorithmic = time samples in (245,760 B) + payload out (7,972 B) per UE-subframe; wall time of the step, host work included"}}
+    if host_fed and ctx.world == 1:
+        out["host_fed"] = _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, otx.sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n,
+                                           gain, iters, payload, workers=3)
     if want_cpu:
         import oracle_api as O
 
@@ -503,7 +506,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
 def leg_uplink_waterfall(ctx, steps=3, warmup=1, want_cpu=False):
     """the same chain at a waterfall operating point (Es/N0 16.4 dB: about 4 half iterations on average, some transport blocks fail) --
     the 19 dB point of `uplink` is the cheap regime (1.8 half iterations, every block decodes).  No CPU leg: `uplink` carries it."""
-    out = leg_uplink(ctx, steps=steps, warmup=warmup, want_cpu=False, snr=16.4)
+    out = leg_uplink(ctx, steps=steps, warmup=warmup, want_cpu=False, snr=16.4, host_fed=False)
     if out is not None:
         out["metric"] += " -- waterfall operating point"
     return out
@@ -578,3 +581,189 @@ def leg_turbo8(ctx, steps=3, warmup=1, want_cpu=True, n_cb=131040, K=6144, nit=8
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     del dec
     return out
+
+
+# ------------------------------------------------------------------------------------------------ host-fed operation (PCIe inside the timed region)
+
+def host_fed_turbo(S, capi, torch, dev, d_llr, in_stride, K, nit, llr8, chunk=8190, n_chunks=8, n_streams=3):
+    """headline decoder fed from pinned host memory: `n_chunks` chunks of `chunk` code blocks, two streams with a device buffer each
+    (H2D -> srsran_hip_tdec_batch_run{,_8bit} -> D2H per chunk, chunks take the streams in turn), so uploads overlap decodes.  Returns the rate, the one-stream
+    (no overlap) rate of round 2 for comparison, the H2D rate of the same bytes alone and min(kernel rate, PCIe rate)."""
+    import oracle_api as O
+
+    lib = S.lib()
+    chunk, n_streams = int(os.environ.get('HOSTFED_CHUNK', chunk)), int(os.environ.get('HOSTFED_STREAMS', n_streams))  # (tools/dbg/hostfed.py sweeps them)
+    n = chunk * n_chunks
+    if llr8:
+        _, pool = O.turbo_llrs_8bit(K, 64, 1.0, seed=5)
+        h_in = torch.from_numpy(np.tile(pool, ((n + 63) // 64, 1))[:n].copy()).pin_memory()
+        tdt = torch.int8
+    else:
+        h_in = torch.empty((n, in_stride), dtype=torch.int16).pin_memory()
+        reps = (n + d_llr.shape[0] - 1) // d_llr.shape[0]
+        h_in.copy_(d_llr.repeat(reps, 1)[:n] if reps > 1 else d_llr[:n])
+        tdt = torch.int16
+    esz = 1 if llr8 else 2
+    h_out = torch.empty((n, K // 8), dtype=torch.uint8).pin_memory()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    d_in = [torch.empty((chunk, in_stride), dtype=tdt, device=dev) for _ in range(n_streams)]
+    d_out = [torch.empty((chunk, K // 8), dtype=torch.uint8, device=dev) for _ in range(n_streams)]
+    decs = [S.TdecBatch(K, chunk, capi.TDEC_AUTO, llr8=llr8) for _ in range(n_streams)]
+
+    def decode(i, c):
+        st = streams[i].cuda_stream
+        if llr8:
+            capi.check(lib.srsran_hip_tdec_batch_run_8bit(decs[i]._h, d_in[i].data_ptr(), in_stride, d_out[i].data_ptr(), K // 8, chunk, nit, 0, st), "run8")
+        else:
+            decs[i].run(d_in[i], in_stride, d_out[i], K // 8, chunk, nit, 0, st)
+
+    def run(n_streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(n_chunks):
+            i = c % n_streams
+            with torch.cuda.stream(streams[i]):
+                d_in[i].copy_(h_in[c * chunk:(c + 1) * chunk], non_blocking=True)
+                decode(i, c)
+                h_out[c * chunk:(c + 1) * chunk].copy_(d_out[i], non_blocking=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def h2d_only():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(n_chunks):
+            i = c % n_streams
+            with torch.cuda.stream(streams[i]):
+                d_in[i].copy_(h_in[c * chunk:(c + 1) * chunk], non_blocking=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def kernel_only():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(n_chunks):
+            with torch.cuda.stream(streams[0]):
+                decode(0, c)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(n_streams)
+    t2 = min(run(n_streams) for _ in range(3))
+    t1 = min(run(1) for _ in range(2))
+    th = min(h2d_only() for _ in range(3))
+    tk = min(kernel_only() for _ in range(2))
+    bits = n * K
+    bytes_in = n * in_stride * esz
+    bound = bits / max(th, tk)
+    out = {"value": bits / t2 / 1e6, "unit": "Mbit/s", "ms": t2 * 1e3,
+           "what": "%d code blocks K=%d (%s LLRs) in %d chunks from pinned host memory: H2D of %.0f MB + decode (%d half iterations) + D2H of the bytes; %d streams, "
+                   "a chunk's upload runs under the others' decodes (best of 3)" % (n, K, "int8" if llr8 else "int16", n_chunks, bytes_in / 1e6, nit, n_streams),
+           "one_stream_no_overlap_mbit_per_s": bits / t1 / 1e6, "h2d_alone_gb_per_s": bytes_in / th / 1e9,
+           "kernel_alone_mbit_per_s": bits / tk / 1e6, "bound_mbit_per_s": bound / 1e6, "bound": "pcie" if th > tk else "kernel",
+           "frac_of_bound": (bits / t2) / bound}
+    del decs
+    return out
+
+
+def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n, gain, iters, payload,
+                     workers=3, chunks=8):
+    """the uplink chain fed from HOST memory the way the reference's PHY is driven: `workers` threads (srsenb's nof_phy_threads, default 3), each with
+    its own stream, handles and device buffers, take chunks of UE-subframes in turn: time samples pinned host -> HBM, the whole chain, payload bytes
+    back to pinned host memory.  The transport-block call waits for its results (as decode_tb does), so overlap comes from the workers."""
+    import threading
+
+    per = n_tb // chunks
+    n_use = per * chunks
+    dlen = tbs // 8 + 8
+    h_time = torch.empty((n_use, sf_sz, 2), dtype=torch.float32).pin_memory()
+    h_time.copy_(d_time[:n_use])
+    h_out = torch.empty((n_use, dlen), dtype=torch.uint8).pin_memory()
+    idx = torch.tensor(data_sym, device=dev)
+
+    class W:
+        def __init__(self):
+            self.st = torch.cuda.Stream(device=dev)
+            self.orx = S.OfdmBatch(nprb, normalize=True)
+            self.inv, self.dem, self.sch = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            capi.check(lib.srsran_hip_dft_batch_create(C.byref(self.inv), nsc, capi.DFT_BACKWARD, False, False, True), "dft inv")
+            capi.check(lib.srsran_hip_demod_create(C.byref(self.dem)), "demod")
+            capi.check(lib.srsran_hip_sch_create(C.byref(self.sch)), "sch")
+            self.d_time = torch.empty((per, sf_sz, 2), dtype=torch.float32, device=dev)
+            self.d_grid = torch.zeros((per, 14, nsc, 2), dtype=torch.float32, device=dev)
+            self.d_h = torch.zeros((per * n_re, 2), dtype=torch.float32, device=dev)
+            self.d_h[:, 0], self.d_h[:, 1] = gain.real, gain.imag
+            self.d_eq = torch.zeros((per * n_re, 2), dtype=torch.float32, device=dev)
+            self.d_sym = torch.zeros_like(self.d_eq)
+            self.d_llr = torch.zeros((per, G), dtype=torch.int16, device=dev)
+            self.d_out = torch.zeros((per, dlen), dtype=torch.uint8, device=dev)
+            self.d_soft = torch.zeros((per * ncb, capi.SOFTBUFFER_CB_SIZE), dtype=torch.int16, device=dev)
+            self.flags = np.zeros(per * ncb, np.uint8)
+            self.res = (capi.HipTbResult * per)()
+            self.rxd = (capi.HipTb * per)(*[capi.HipTb(tbs, Qm, 0x100, G, i * G, i * dlen, i * ncb) for i in range(per)])
+            self.ok = 0
+
+        def chunk(self, c):
+            st = self.st.cuda_stream
+            jobs = (capi.HipDemodJob * per)(*[capi.HipDemodJob(mod, n_re, i * n_re, i * G, seeds[(c * per + i) % pool_n], 1) for i in range(per)])
+            with torch.cuda.stream(self.st):
+                self.flags[:] = 0
+                self.d_time.copy_(h_time[c * per:(c + 1) * per], non_blocking=True)
+                self.orx.run(self.d_time.data_ptr(), self.d_grid.data_ptr(), per, st)
+                y = self.d_grid.index_select(1, idx).contiguous()
+                capi.check(lib.srsran_hip_predecoding_single(y.data_ptr(), self.d_h.data_ptr(), self.d_eq.data_ptr(), None, per * n_re, 1.0, 0.0, st), "eq")
+                capi.check(lib.srsran_hip_dft_batch_run(self.inv, self.d_eq.data_ptr(), self.d_sym.data_ptr(), per * len(data_sym), st), "deprecode")
+                capi.check(lib.srsran_hip_demod_run(self.dem, self.d_sym.data_ptr(), self.d_llr.data_ptr(), capi.LLR_SHORT, jobs, per, st), "demod")
+                capi.check(lib.srsran_hip_sch_decode(self.sch, self.d_llr.data_ptr(), self.rxd, per, iters, self.d_soft.data_ptr(), self.flags.ctypes.data,
+                                                     self.d_out.data_ptr(), self.res, st), "decode")
+                h_out[c * per:(c + 1) * per].copy_(self.d_out, non_blocking=True)
+                self.st.synchronize()
+            self.ok += sum(1 for r in self.res if r.crc_ok == 0)
+
+    ws = [W() for _ in range(workers)]
+
+    def run(nw):
+        errs = []
+
+        def body(w, k):
+            try:
+                for c in range(k, chunks, nw):
+                    w.chunk(c)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        for w in ws:
+            w.ok = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=body, args=(ws[k], k)) for k in range(nw)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        if errs:
+            raise errs[0]
+        return time.perf_counter() - t0
+
+    run(workers)
+    t3 = min(run(workers) for _ in range(2))
+    ok3 = sum(w.ok for w in ws)
+    t1 = run(1)
+    # H2D of the same samples alone
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(chunks):
+        ws[c % workers].d_time.copy_(h_time[c * per:(c + 1) * per], non_blocking=True)
+    torch.cuda.synchronize()
+    th = time.perf_counter() - t0
+    good = bool(np.array_equal(h_out[0].numpy()[:tbs // 8], payload[0]))
+    bytes_in = n_use * sf_sz * 8
+    for w in ws:
+        lib.srsran_hip_sch_free(w.sch)
+    return {"value": n_use * tbs / t3 / 1e6, "unit": "Mbit/s", "ms": t3 * 1e3, "subframes_per_s": n_use / t3,
+            "what": "%d UE-subframes in %d chunks from pinned host memory (%.0f MB of time samples in, payload bytes out), %d worker threads with a stream, handles "
+                    "and buffers each (the reference's nof_phy_threads model); every chunk: H2D -> OFDM -> equaliser -> IDFT -> demodulation -> transport blocks -> D2H"
+                    % (n_use, chunks, bytes_in / 1e6, workers),
+            "one_worker_mbit_per_s": n_use * tbs / t1 / 1e6, "h2d_alone_gb_per_s": bytes_in / th / 1e9,
+            "pcie_bound_mbit_per_s": n_use * tbs / th / 1e6, "tb_crc_ok": [ok3, n_use], "payload_matches": good}

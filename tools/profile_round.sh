@@ -5,13 +5,17 @@
 # Outputs go to gpurun_out/round/; the summaries to keep are copied into profiles/ by hand afterwards.
 set -o pipefail
 export TMPDIR=/tmp
-OUT=gpurun_out/round
+OUT=gpurun_out/round3
 mkdir -p $OUT
 B="python bench.py --steps 2 --warmup 1 --extra-steps 2 --no-cpu"
-timeout -k 10 700 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+if [ "$SKIP_PYTEST" != "1" ]; then
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -3 $OUT/pytest_gpu.log
+fi
 python bench.py > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json | cut -c1-300 &&
 python tools/bench_handle.py > $OUT/bench_handle.json 2> $OUT/bench_handle.err &&
+python tools/bench_tti.py --out $OUT/tti.json > /dev/null 2> $OUT/tti.err &&
+( rocprofv3 --kernel-trace --stats -d $OUT/trace_tti -o t -- python tools/bench_tti.py --calls 100 --snrs 6.0 --ntb 1,64 > /dev/null 2> $OUT/trace_tti.err; python tools/rocpd_summary.py $OUT/trace_tti > $OUT/tti_kernel_stats.txt; rm -rf $OUT/trace_tti ) &&
 python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
 python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
 python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&

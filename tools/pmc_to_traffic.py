@@ -12,7 +12,7 @@ UNITS = {  # kernel name fragment -> (key in the JSON, units per launch key, uni
     "ldpc_packed_kernel<false>": ("ldpc_packed_kernel", "code_words_per_launch", 16384),
     "pss_wave_kernel": ("pss_wave_kernel", "captures_per_launch", 256),
     "ofdm_kernel<phyhip::fft::Plan<4096": ("ofdm_kernel_n4096", "slots_per_launch", 2048),
-    "tdec_win_kernel<32, phyhip::turbo::Ar8, false>": ("tdec_win_kernel_8bit", "code_blocks_per_launch", 131040),
+    "tdec_win_kernel<16, phyhip::turbo::Ar8, false>": ("tdec_win_kernel_8bit", "code_blocks_per_launch", 131040),
 }
 # the kernels of one step of the uplink leg (extra.uplink: 64 UEs x 184 subframes): their bench-sized dispatches summed
 CHAIN = {"uplink_chain": (["ofdm_kernel<phyhip::fft::Plan<1536", "modem::", "dft_fixed_kernel<phyhip::fft::Plan<1200", "rm_rx_gather_lds_kernel<short>",

@@ -162,6 +162,7 @@ struct srsran_hip_tdec_batch {
   // latency kernel (small batches): its own workspace, allocated on first use for lat_cap code blocks
   uint32_t* d_ws_lat      = nullptr;
   uint32_t  lat_cap       = 0;
+  std::map<uint32_t, uint32_t*> crc_mult_lat; // per generator: one multiplier per 32-bit word of the kernel's hard-bit image
   bool      state_in_lat  = false; // the decoder state of the last launch lives in the latency kernel's workspace
 };
 
@@ -338,6 +339,9 @@ extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
   hipFree(h->d_deinter16);
   hipFree(h->d_dec_llr);
   for (auto& kv : h->crc_mult) {
+    hipFree(kv.second);
+  }
+  for (auto& kv : h->crc_mult_lat) {
     hipFree(kv.second);
   }
   delete h;
@@ -574,6 +578,24 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     if (ensure_lat_ws(h, n_cb)) {
       return SRSRAN_ERROR;
     }
+    // the latency kernel forms the CRC from 32-bit words of its hard-bit image (sub-block d at d * sbs4 bytes): word (d, w) holds the steps
+    // 32 w ... of sub-block d and is shifted into place with x^(bits behind it) mod g
+    uint32_t*& d_ml = h->crc_mult_lat[crc_poly];
+    if (!d_ml) {
+      const uint32_t W = h->K / h->nb, nblk = (W + 7) / 8, wps = (((nblk + 1 + 3) & ~3u) >> 2);
+      std::vector<uint32_t> m((size_t)h->nb * wps, 0u);
+      for (uint32_t d = 0; d < (uint32_t)h->nb; d++) {
+        for (uint32_t w = 0; w < wps; w++) {
+          if (32 * w < W) {
+            const uint32_t nbit = W - 32 * w > 32 ? 32 : W - 32 * w;
+            m[d * wps + w]      = xpow_mod((uint64_t)h->K - ((uint64_t)d * W + 32 * w + nbit), crc_poly);
+          }
+        }
+      }
+      PHY_HIP_CHECK(hipMalloc(&d_ml, m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
+      PHY_HIP_CHECK(upload(d_ml, m.data(), m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
+    }
+    p.crc_mult  = d_ml;
     p.ws        = h->d_ws_lat;
     p.ws_stride = turbo::lat_ws_dwords(h->K, h->nb);
     PHY_HIP_CHECK(turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);

@@ -442,6 +442,8 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
     if host_fed and ctx.world == 1:
         out["host_fed"] = _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, otx.sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n,
                                            gain, iters, payload, workers=3)
+        out["tti"] = _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, otx.sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n,
+                                      gain, iters, payload, workers=3, chunks=96, per=ues, tti=True)
     if want_cpu:
         import oracle_api as O
 
@@ -667,14 +669,15 @@ def host_fed_turbo(S, capi, torch, dev, d_llr, in_stride, K, nit, llr8, chunk=81
 
 
 def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n, gain, iters, payload,
-                     workers=3, chunks=8):
+                     workers=3, chunks=8, per=None, tti=False):
     """the uplink chain fed from HOST memory the way the reference's PHY is driven: `workers` threads (srsenb's nof_phy_threads, default 3), each with
     its own stream, handles and device buffers, take chunks of UE-subframes in turn: time samples pinned host -> HBM, the whole chain, payload bytes
     back to pinned host memory.  The transport-block call waits for its results (as decode_tb does), so overlap comes from the workers."""
     import threading
 
-    per = n_tb // chunks
+    per = per or n_tb // chunks
     n_use = per * chunks
+    lat = []
     dlen = tbs // 8 + 8
     h_time = torch.empty((n_use, sf_sz, 2), dtype=torch.float32).pin_memory()
     h_time.copy_(d_time[:n_use])
@@ -704,6 +707,7 @@ def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, d
             self.ok = 0
 
         def chunk(self, c):
+            t_c = time.perf_counter()
             st = self.st.cuda_stream
             jobs = (capi.HipDemodJob * per)(*[capi.HipDemodJob(mod, n_re, i * n_re, i * G, seeds[(c * per + i) % pool_n], 1) for i in range(per)])
             with torch.cuda.stream(self.st):
@@ -718,6 +722,7 @@ def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, d
                                                      self.d_out.data_ptr(), self.res, st), "decode")
                 h_out[c * per:(c + 1) * per].copy_(self.d_out, non_blocking=True)
                 self.st.synchronize()
+            lat.append(time.perf_counter() - t_c)
             self.ok += sum(1 for r in self.res if r.crc_ok == 0)
 
     ws = [W() for _ in range(workers)]
@@ -746,6 +751,21 @@ def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, d
             raise errs[0]
         return time.perf_counter() - t0
 
+    if tti:
+        # one subframe's worth of UEs per call: latency of a call (host samples in -> payload on the host), 1 and `workers` threads
+        res = {}
+        for nw in (1, workers):
+            run(nw)
+            del lat[:]
+            t = run(nw)
+            v = sorted(lat)
+            res["workers_%d" % nw] = {"p50_ms": 1e3 * v[len(v) // 2], "p99_ms": 1e3 * v[min(len(v) - 1, int(0.99 * len(v)))], "calls": len(v),
+                                      "subframes_per_s": n_use / t, "mbit_per_s": n_use * tbs / t / 1e6}
+        for w in ws:
+            lib.srsran_hip_sch_free(w.sch)
+        res["what"] = ("%d UE-subframes per call (one TTI of %d UEs): pinned host samples -> H2D -> OFDM -> equaliser -> IDFT -> demodulation -> transport blocks "
+                       "(CRC early stop) -> payload D2H; latency of a call seen by the worker thread" % (per, per))
+        return res
     run(workers)
     t3 = min(run(workers) for _ in range(2))
     ok3 = sum(w.ok for w in ws)

@@ -90,8 +90,8 @@ static inline bool lat_exists(int nb, bool arith8)
 // Batches of up to this many WAVES go to the latency kernel (one wave per code block; two for the 32-sub-block 8-bit decoder): one wave per
 // SIMD fills the chip's 1024 SIMDs once -- a lone wave already issues at the rate a SIMD sustains for packed / three-operand instructions
 // (tools/probe/valu_issue_probe.hip) --, two waves per SIMD take twice as long each; beyond that the throughput kernel's 8 blocks per wave
-// win.  Measured (K = 6144, 8 half iterations, profiles/r03_lat_time.txt): 16-bit 1024 blocks 0.67 against 1.81 ms, 2048 blocks 1.30 against
-// 1.83, 4096 blocks 2.65 against 2.03; 8-bit (two waves per block) 512 blocks 0.47 against 1.18, 1024 blocks 1.01 against 1.21, 2048 blocks 2.00 against 1.31.
+// win.  Measured (K = 6144, 8 half iterations, profiles/r03_lat_time.txt): 16-bit 1024 blocks 0.62 against 1.81 ms, 2048 blocks 1.20 against
+// 1.84, 4096 blocks 2.44 against 2.03; 8-bit (two waves per block) 512 blocks 0.47 against 1.18, 1024 blocks 1.00 against 1.21, 2048 blocks 1.99 against 1.32.
 constexpr uint32_t kLatMaxBlocks = 2048; // in waves
 static inline uint32_t lat_waves(int nb, uint32_t n_cb)
 {

@@ -192,6 +192,9 @@ SRSRAN_API int      srsran_cp_synch_init(srsran_cp_synch_t* q, uint32_t symbol_s
 SRSRAN_API void     srsran_cp_synch_free(srsran_cp_synch_t* q);
 SRSRAN_API int      srsran_cp_synch_resize(srsran_cp_synch_t* q, uint32_t symbol_sz);
 SRSRAN_API uint32_t srsran_cp_synch(srsran_cp_synch_t* q, const cf_t* input, uint32_t max_offset, uint32_t nof_symbols, uint32_t cp_len);
+/* Returns a complex value BY VALUE across the C ABI, as the reference does (cp.h:46).  The library is C++ (cf_t = std::complex<float>), its
+ * callers are C (cf_t = float _Complex): both are returned in xmm0 as two packed floats under the x86-64 System V ABI (class SSE, 8 bytes),
+ * which is why clang's -Wreturn-type-c-linkage remark is harmless here; tests/ref_link/c_caller.c calls it from C and checks the value. */
 SRSRAN_API cf_t     srsran_cp_synch_corr_output(srsran_cp_synch_t* q, uint32_t offset);
 
 /* ---- sync/sync.h:50-228 ---- */

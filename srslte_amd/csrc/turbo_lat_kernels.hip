@@ -58,6 +58,25 @@ __host__ __device__ constexpr bool type_y(int i)
   return i == 1 || i == 2 || i == 5 || i == 6;
 }
 
+// invariants of the rotating labelling, for every residue r and slot s: the partner slot (s ^ 1, ^ 2, ^ 4) holds the state that differs in the
+// shift register's outgoing bit; after the step both slots hold the two successors (u b2 b1) of that pair; three steps restore the labelling
+__host__ __device__ constexpr bool labelling_ok()
+{
+  for (int r = 0; r < 3; r++) {
+    for (int s = 0; s < 8; s++) {
+      const int part = s ^ (1 << r), st = state_of(r, s), nx = state_of(r + 1, s);
+      if (state_of(r, part) != (st ^ 1) || (nx & 3) != (st >> 1) || state_of(r + 1, part) != (nx ^ 4) || slot_of(r, st) != s) {
+        return false;
+      }
+      if (pm_of(nx) != st && (pm_of(nx) ^ 1) != st) { // the slot's own state is one of the two predecessors of its new state
+        return false;
+      }
+    }
+  }
+  return state_of(3, 5) == state_of(0, 5);
+}
+static_assert(labelling_ok(), "slot labelling of the in-place trellis butterflies");
+
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v)
 {

@@ -108,3 +108,10 @@ def test_pmch_file_test(data_dir):
     """100 PRB (N = 1536) MBSFN subframe: srsran_ofdm_rx_sf in MBSFN mode -> PMCH -> turbo decoder -> CRC (pmch_file_test.c:216-231)"""
     rc, out = _run("pmch_file_test", ["-i", data_dir / "pmch_100prbs_MCS2_SR0.bin"], data_dir)
     assert rc == 0 and "PMCH Decoded OK!" in out, out[-2000:]
+
+
+def test_c_caller_gets_complex_values_by_value(data_dir):
+    """tests/ref_link/c_caller.c (our own, plain C): srsran_cp_synch_corr_output returns cf_t by value from the C++ library to a C caller; the values
+    equal the correlation recomputed in C for every offset, and the peak is where the cyclic prefixes were put"""
+    rc, out = _run("c_caller", [], data_dir)
+    assert rc == 0 and "0 of 40 values off" in out, out[-1500:]

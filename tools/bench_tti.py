@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--ntb", default="1,8,64")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default="")
+    ap.add_argument("--llr8-mean", type=float, default=24.0, help="mean |LLR| of the int8 e bits (clipped to +-127)")
     a = ap.parse_args()
     import torch
     import srslte_amd as S, oracle_api as O
@@ -48,7 +49,7 @@ def main():
         pool = [O.make_tb(tbs, Qm, G, 0, snr, rng) for _ in range(pool_n)]
         for llr8 in (False, True):
             sdt, tdt = (np.int8, torch.int8) if llr8 else (np.int16, torch.int16)
-            es = [np.clip(np.round(e * (10.0 / np.mean(np.abs(e)))), -100, 100).astype(np.int8) if llr8 else e for e, _ in pool]
+            es = [np.clip(np.round(e * (a.llr8_mean / np.mean(np.abs(e)))), -127, 127).astype(np.int8) if llr8 else e for e, _ in pool]
             # the reference's chain on one core: per transport block
             ref_ms, ref_ok, ref_it = None, None, None
             if O.have_ref():

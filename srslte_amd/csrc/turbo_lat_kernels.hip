@@ -195,6 +195,16 @@ __device__ __forceinline__ s2 alpha_step(const LaneK& c, s2& a, s2 bn, s2 g_own,
   return out;
 }
 
+// the forward step alone, keeping the two branch sums (own -> own new state, partner -> own new state) for the LLR
+template <class AR, int R>
+__device__ __forceinline__ void alpha_branches(s2& a, s2 g_own, s2 g_cross, s2& t_o, s2& t_c)
+{
+  const s2 pa = from_u(partner<R>(to_u(a)));
+  t_o         = AR::add_raw(a, g_own);
+  t_c         = AR::add_raw(pa, g_cross);
+  a           = AR::clean(vmax(t_o, t_c));
+}
+
 __device__ __forceinline__ void load8(const uint32_t* q, uint32_t (&r)[8])
 {
   const uint4 a = *reinterpret_cast<const uint4*>(q), c = *reinterpret_cast<const uint4*>(q + 4);
@@ -686,22 +696,71 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
             bt[j] = st;
           }
         }
+        // forward recursion of the 8 steps: the two branch sums of every step are kept for the LLRs
+        s2 t_o[8], t_c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          t_o[j] = t_c[j] = splat(0); // (steps behind a ragged sub-block's end: defined values, never kept)
+          if (FULL || j < len) {
+            if ((R0 + j) % 3 == 0) {
+              alpha_branches<AR, 0>(o, go[j], gc[j], t_o[j], t_c[j]);
+            } else if ((R0 + j) % 3 == 1) {
+              alpha_branches<AR, 1>(o, go[j], gc[j], t_o[j], t_c[j]);
+            } else {
+              alpha_branches<AR, 2>(o, go[j], gc[j], t_o[j], t_c[j]);
+            }
+            if (AR::norm_at(b * 8 + j)) {
+              o = normalise<AR>(o);
+            }
+          }
+        }
+        // max-log-MAP outputs of the 8 steps, STAGE BY STAGE across the steps: the eight reductions are independent, so every cross-lane move
+        // reads a register written eight instructions earlier and needs no wait states (step by step, a fifth of the block was s_nop).
+        // Even slots collect the data-bit-0 maximum, odd slots the data-bit-1 one: a lane keeps the candidate of its class, sends the other to
+        // slot ^ 1, then ONE value per lane is reduced over slot ^ 2 and slot ^ 4.
+        s2 w[8], u[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const bool q = lk.q[(R0 + j) % 3];
+          w[j]         = AR::add_raw(bt[j], q ? t_o[j] : t_c[j]);
+          u[j]         = AR::add_raw(bt[j], q ? t_c[j] : t_o[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          u[j] = from_u(partner<0>(to_u(u[j])));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          w[j] = vmax(w[j], u[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          u[j] = from_u(partner<1>(to_u(w[j])));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          w[j] = vmax(w[j], u[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          u[j] = from_u(partner<2>(to_u(w[j])));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          w[j] = vmax(w[j], u[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          u[j] = from_u(partner<0>(to_u(w[j]))); // the other class' maximum
+        }
         s2 kept = splat(0), keptraw = splat(0);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           if (FULL || j < len) {
-            s2 llr;
-            if ((R0 + j) % 3 == 0) {
-              llr = alpha_step<AR, 0, true>(lk, o, bt[j], go[j], gc[j]);
-            } else if ((R0 + j) % 3 == 1) {
-              llr = alpha_step<AR, 1, true>(lk, o, bt[j], go[j], gc[j]);
-            } else {
-              llr = alpha_step<AR, 2, true>(lk, o, bt[j], go[j], gc[j]);
-            }
-            const uint32_t k = b * 8 + j;
-            if (AR::norm_at(k)) {
-              o = normalise<AR>(o);
-            }
+            const s2       m1  = lk.odd ? w[j] : u[j];
+            const s2       m0  = lk.odd ? u[j] : w[j];
+            const s2       llr = AR::llr(AR::clean(m1), AR::clean(m0));
+            const uint32_t k   = b * 8 + j;
             // decoder 1: ext1 - app1 (the a-priori it just used; zero in the first half iteration); decoder 2: ext2 - its systematic input
             s2 proc;
             if constexpr (dec1) {

@@ -83,6 +83,35 @@ SRSRAN_API int  srsran_hip_sch_decode_8bit(srsran_hip_sch_t* h, const int8_t* d_
 typedef struct SRSRAN_API {
   uint32_t F, C, K1, K2, K1_idx, K2_idx, C1, C2, tbs, L_tb, L_cb, Z;
 } srsran_cbsegm_t;
+
+/* ---- the reference's OWN seam for a whole transport block: `bool decode_tb_cb(srsran_sch_t*, srsran_softbuffer_rx_t*, srsran_cbsegm_t*,
+ * Qm, rv, nof_e_bits, void* e_bits, uint8_t* data)`, lib/src/phy/phch/sch.c:370-492 -- the only non-static function between
+ * srsran_dlsch_decode2 / srsran_ulsch_decode (sch.c:579-618, 1121-1192) and the per-code-block calls.  Same arguments, same side
+ * effects on HOST memory: e_bits are the caller's int16 (int8 when q->llr_is_8bit) soft bits, the soft buffer rows buffer_f[cb] receive
+ * the combined, de-matched soft bits of every code block that was still undecoded (HARQ state for the next transmission), `data`
+ * the decoded bytes (K/8 per undecoded code block at cb * rlen / 8, stored bytes of earlier rounds for the others), cb_crc / tb_crc /
+ * data[cb] of the soft buffer and q->avg_iterations are updated as sch.c:448-452,472-486 do.  One call = one upload, one
+ * de-matching launch and one early-stop decoder launch per block size, one download (the per-thread staging context is private).
+ * Rows that arrive all zero (srsran_softbuffer_rx_reset, softbuffer.c:147-167) are not uploaded.
+ * The two structs are the reference's layouts (softbuffer.h:40-47; sch.h:51-57 up to llr_is_8bit -- nothing behind it is touched). */
+typedef struct SRSRAN_API {
+  uint32_t  max_cb;
+  uint32_t  max_cb_size;
+  int16_t** buffer_f;
+  uint8_t** data;
+  bool*     cb_crc;
+  bool      tb_crc;
+} srsran_softbuffer_rx_t;
+typedef struct SRSRAN_API {
+  uint32_t max_iterations;
+  float    avg_iterations;
+  bool     llr_is_8bit;
+} srsran_hip_sch_head_t;
+SRSRAN_API bool srsran_hip_decode_tb_cb(void* q /* srsran_sch_t* */, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm,
+                                        uint32_t rv, uint32_t nof_e_bits, void* e_bits, uint8_t* data);
+/* the same under the reference's name, for a build whose sch.c no longer defines it */
+SRSRAN_API bool decode_tb_cb(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv,
+                             uint32_t nof_e_bits, void* e_bits, uint8_t* data);
 SRSRAN_API int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs);
 /* cbsegm.h:59-67, cbsegm.c:142-150,201-285: valid turbo block size; NR (LDPC) segmentation for base graph 1 / 2 */
 SRSRAN_API bool srsran_cbsegm_cbsize_isvalid(uint32_t size);

@@ -51,6 +51,9 @@ def build(force=False, verbose=True, jobs=8):
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
+        # an object newer than its source, every header and this file is kept (headers are shared: any header change rebuilds all)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(f) for f in [src, __file__] + HEADERS):
+            continue
         cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

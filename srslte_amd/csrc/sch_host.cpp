@@ -125,8 +125,15 @@ srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n
 } // namespace
 
 // decode_tb (sch.c:507-572) for a batch; llr8 = q->llr_is_8bit: 8-bit rate de-matching and the 8-bit window decoders (:408-412,426-428)
+// (tail: device-to-host copies a caller wants queued behind the last kernel and in front of the call's one host wait)
+struct TailCopy {
+  void*       dst;
+  const void* src;
+  size_t      bytes;
+};
 static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint32_t max_iterations, void* d_softbuf,
-                      uint8_t* cb_crc, uint8_t* d_data, srsran_hip_tb_result_t* results, void* stream, bool llr8)
+                      uint8_t* cb_crc, uint8_t* d_data, srsran_hip_tb_result_t* results, void* stream, bool llr8, const TailCopy* tail = nullptr,
+                      int n_tail = 0)
 {
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
@@ -370,6 +377,11 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   if (n || n_crc) {
     PHY_HIP_CHECK(hipMemcpyAsync(hb + o_noi, base + o_noi, o_tbr + n_crc * sizeof(rm::TbCrcResult) - o_noi, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
   }
+  for (int i = 0; i < n_tail; i++) {
+    if (tail[i].bytes) {
+      PHY_HIP_CHECK(hipMemcpyAsync(tail[i].dst, tail[i].src, tail[i].bytes, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    }
+  }
   PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
   // results, walking the blocks in the order of pass 2
   size_t jc = 0;
@@ -412,4 +424,206 @@ extern "C" int srsran_hip_sch_decode_8bit(srsran_hip_sch_t* h, const int8_t* d_e
                                           srsran_hip_tb_result_t* results, void* stream)
 {
   return sch_decode(h, d_e_bits, tbs, n_tb, max_iterations, d_softbuf, cb_crc, d_data, results, stream, true);
+}
+
+// ------------------------------------------------------------------------------------------------ the reference's transport-block seam
+//
+// decode_tb_cb (sch.c:370-492) on the caller's HOST buffers: what srsran_dlsch_decode2 / srsran_ulsch_decode reach through decode_tb
+// (sch.c:541).  The staging context (stream, transport-block decoder, device and pinned buffers) is private to the calling thread, as
+// the reference's worker threads each own their srsran_sch_t.
+
+namespace {
+
+struct TbStage {
+  hipStream_t       st  = nullptr;
+  srsran_hip_sch_t* sch = nullptr;
+  uint8_t*          pin = nullptr; // pinned image: [soft rows | e bits | data]
+  uint8_t*          dev = nullptr; // the same layout on the device
+  size_t            cap = 0;
+  bool              tried = false;
+  ~TbStage()
+  {
+    srsran_hip_sch_free(sch);
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    if (st) {
+      (void)hipStreamDestroy(st);
+    }
+  }
+  bool ready()
+  {
+    if (!tried) {
+      tried = true;
+      if (device_available()) {
+        bind_thread();
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+          st = nullptr;
+        } else if (srsran_hip_sch_create(&sch) != SRSRAN_SUCCESS) {
+          (void)hipStreamDestroy(st);
+          st = nullptr;
+        }
+      }
+    }
+    return st != nullptr;
+  }
+  bool grow(size_t need)
+  {
+    if (need <= cap) {
+      return true;
+    }
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    dev = pin = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&dev, need) != hipSuccess || hipHostMalloc((void**)&pin, need) != hipSuccess) {
+      return false;
+    }
+    cap = need;
+    return true;
+  }
+};
+
+// copies n bytes and says whether any of them was non-zero (a soft-buffer row straight after srsran_softbuffer_rx_reset is not worth a transfer)
+inline bool copy_and_test(uint8_t* dst, const uint8_t* src, size_t n)
+{
+  uint64_t acc = 0;
+  size_t   i   = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    memcpy(&v, src + i, 8);
+    memcpy(dst + i, &v, 8);
+    acc |= v;
+  }
+  for (; i < n; i++) {
+    dst[i] = src[i];
+    acc |= src[i];
+  }
+  return acc != 0;
+}
+
+} // namespace
+
+extern "C" bool srsran_hip_decode_tb_cb(void* qv, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv,
+                                        uint32_t nof_e_bits, void* e_bits, uint8_t* data)
+{
+  auto* q = static_cast<srsran_hip_sch_head_t*>(qv);
+  if (!q || !softbuffer || !cb_segm || !e_bits || !data || Qm == 0 || rv > 3) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: invalid arguments\n");
+    return false;
+  }
+  const uint32_t C = cb_segm->C;
+  if (C > 32) { // SRSRAN_MAX_CODEBLOCKS, sch.c:382-385
+    fprintf(stderr, "Error SRSRAN_MAX_CODEBLOCKS=%d\n", 32);
+    return false;
+  }
+  q->avg_iterations = 0; // sch.c:387
+  if (C == 0 || C > softbuffer->max_cb) {
+    return false;
+  }
+  static thread_local TbStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s (there is no CPU fallback)\n", get_error());
+    return false;
+  }
+  const bool   llr8 = q->llr_is_8bit;
+  const size_t es   = llr8 ? 1 : 2;
+  const size_t row  = (size_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE * es;
+  auto         al   = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_soft = 0, o_e = al(o_soft + C * row), o_data = al(o_e + (size_t)nof_e_bits * es);
+  const size_t n_data = cb_segm->tbs / 8 + 6; // the last block's K/8 bytes end 3 bytes behind the transport CRC (:424 writes whole blocks)
+  if (!s.grow(al(o_data + n_data))) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: staging allocation failed\n");
+    return false;
+  }
+  // per code block: size, payload bytes, soft-buffer span (the layout srsran_rm_turbo_rx_lut{,_8bit} fills for the AUTO decoder of that size)
+  uint8_t  flags[32];
+  uint32_t span[32], rbytes[32];
+  bool     any_flag = false, any_soft = false;
+  int      first = -1, last = -1;
+  for (uint32_t i = 0; i < C; i++) {
+    const uint32_t K   = i < cb_segm->C1 ? cb_segm->K1 : cb_segm->K2;
+    const uint32_t nsb = llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K);
+    span[i]   = nsb ? 3 * (K + 32) + 12 : 3 * K + 12;
+    rbytes[i] = (C == 1 ? K : K - 24) / 8;
+    flags[i]  = softbuffer->cb_crc[i] ? 1 : 0;
+    if (flags[i]) {
+      any_flag = true;
+      // decoded in an earlier round: its stored bytes (sch.c:466-471), which the transport CRC on the device needs too
+      memcpy(s.pin + o_data + (size_t)i * rbytes[i], softbuffer->data[i], rbytes[i]);
+    } else {
+      any_soft |= copy_and_test(s.pin + o_soft + i * row, reinterpret_cast<const uint8_t*>(softbuffer->buffer_f[i]), span[i] * es);
+      first = first < 0 ? (int)i : first;
+      last  = (int)i;
+    }
+  }
+  srsran_hip_tb_t    tb  = {cb_segm->tbs, Qm, rv, nof_e_bits, 0, 0, 0};
+  srsran_hip_tb_result_t res = {SRSRAN_ERROR, 0.f, 0};
+  if (first >= 0) {
+    memcpy(s.pin + o_e, e_bits, (size_t)nof_e_bits * es);
+    if (hipMemcpyAsync(s.dev + o_e, s.pin + o_e, (size_t)nof_e_bits * es, hipMemcpyHostToDevice, s.st) != hipSuccess) {
+      return false;
+    }
+    if (!any_soft && !any_flag) {
+      tb.rv |= SRSRAN_HIP_TB_NEW_DATA; // every row is still zero: the de-matcher writes the rows instead of accumulating into them
+    } else if (hipMemcpyAsync(s.dev + o_soft + first * row, s.pin + o_soft + first * row, (last - first) * row + span[last] * es, hipMemcpyHostToDevice,
+                              s.st) != hipSuccess) {
+      return false;
+    }
+    if (any_flag && hipMemcpyAsync(s.dev + o_data, s.pin + o_data, n_data, hipMemcpyHostToDevice, s.st) != hipSuccess) {
+      return false;
+    }
+  }
+  // the decoded bytes come back in front of the call's one host wait; the combined soft bits only when a block failed (second wait, below)
+  const TailCopy tail[1] = {{s.pin + o_data, s.dev + o_data, first >= 0 ? n_data : 0}};
+  const int rc = sch_decode(s.sch, s.dev + o_e, &tb, 1, q->max_iterations ? q->max_iterations : 1, s.dev + o_soft, flags, s.dev + o_data, &res, s.st, llr8, tail, 1);
+  if (rc != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());
+    return false;
+  }
+  int f_first = -1, f_last = -1; // still undecoded: their rows are the HARQ state the next transmission combines into
+  for (uint32_t i = 0; i < C; i++) {
+    if (!flags[i]) {
+      f_first = f_first < 0 ? (int)i : f_first;
+      f_last  = (int)i;
+    }
+  }
+  if (f_first >= 0 && (hipMemcpyAsync(s.pin + o_soft + f_first * row, s.dev + o_soft + f_first * row, (f_last - f_first) * row + span[f_last] * es,
+                                      hipMemcpyDeviceToHost, s.st) != hipSuccess ||
+                       hipStreamSynchronize(s.st) != hipSuccess)) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: download of the soft buffer rows failed\n");
+    return false;
+  }
+  // host side effects of sch.c:424-486
+  bool all_ok = true;
+  for (uint32_t i = 0; i < C; i++) {
+    if (softbuffer->cb_crc[i]) {
+      memcpy(&data[(size_t)i * rbytes[i]], softbuffer->data[i], rbytes[i]);
+      continue;
+    }
+    const uint32_t K = i < cb_segm->C1 ? cb_segm->K1 : cb_segm->K2;
+    memcpy(&data[(size_t)i * rbytes[i]], s.pin + o_data + (size_t)i * rbytes[i], i + 1 == C ? K / 8 : rbytes[i]);
+    if (flags[i]) {
+      softbuffer->cb_crc[i] = true;
+    } else {
+      all_ok = false;
+      // still undecoded: the next transmission combines into this row
+      memcpy(softbuffer->buffer_f[i], s.pin + o_soft + i * row, span[i] * es);
+    }
+  }
+  softbuffer->tb_crc = all_ok;
+  if (!all_ok) {
+    for (uint32_t i = 0; i < C; i++) {
+      if (softbuffer->cb_crc[i]) {
+        memcpy(softbuffer->data[i], &data[(size_t)i * rbytes[i]], rbytes[i]); // sch.c:476-484
+      }
+    }
+  }
+  q->avg_iterations = res.avg_iterations;
+  return all_ok;
+}
+
+extern "C" bool decode_tb_cb(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,
+                             void* e_bits, uint8_t* data)
+{
+  return srsran_hip_decode_tb_cb(q, softbuffer, cb_segm, Qm, rv, nof_e_bits, e_bits, data);
 }

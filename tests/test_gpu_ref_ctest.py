@@ -46,3 +46,29 @@ def test_ctest_line(entry, data_dir):
     args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
     rc, out = run_program("bin_full", entry["program"], args, data_dir, timeout=900)
     assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])
+
+
+# ---- the transport-block seam (tests/ref_link/Makefile target `tb`, tests/ref_link/tb_bind.c): the programs whose link contains the reference's
+# sch.c, built a second time with ITS decode_tb_cb (sch.c:370) weakened in the object file and the library's in its place -- every transport
+# block that srsran_pdsch_decode / srsran_pusch_decode / srsran_pmch_decode hand to srsran_dlsch_decode2 / srsran_ulsch_decode goes to the
+# device as one call (rate de-matching, turbo early stop, CRCs), on the reference's own soft-buffer structs.
+TB_PROGRAMS = {"pdsch_test", "pusch_test", "pmch_test", "pdsch_pdcch_file_test", "pmch_file_test"}
+
+
+def _selected_tb():
+    full = os.environ.get("REF_CTEST_FULL", "0") == "1"
+    seen = {}
+    for e in MANIFEST:
+        if e["program"] not in TB_PROGRAMS:
+            continue
+        n = seen.get(e["program"], 0)
+        seen[e["program"]] = n + 1
+        if full or e["program"] != "pdsch_test" or n % 4 == 0:
+            yield e
+
+
+@pytest.mark.parametrize("entry", list(_selected_tb()), ids=lambda e: "tb:%s:%s" % (e["program"], e["name"]))
+def test_ctest_line_through_the_transport_block_seam(entry, data_dir):
+    args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
+    rc, out = run_program("bin_tb", entry["program"], args, data_dir, timeout=900)
+    assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])

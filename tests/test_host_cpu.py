@@ -74,10 +74,13 @@ REFERENCE_LAYOUT = {"srsran_dft_plan_t": 48, "srsran_ofdm_cfg_t": 56, "srsran_of
                     "off_pss_conv_output_avg": 1864, "off_pss_tmp_ce": 34744, "off_sss_fc_tables": 3672,
                     "srsran_sync_t": 226864, "srsran_cfo_t": 40, "srsran_cp_synch_t": 16, "off_sync_cfo_corr_frame": 144800,
                     "off_sync_sss_signal": 194096, "srsran_ldpc_rm_t": 48, "srsran_ldpc_encoder_t": 80, "off_ldpc_rm_Ncb": 40,
-                    "off_ldpc_encoder_encode": 48}
+                    "off_ldpc_encoder_encode": 48,
+                    # the transport-block seam decode_tb_cb (sch.c:370): the soft buffer object and the head of srsran_sch_t
+                    "srsran_softbuffer_rx_t": 40, "off_softbuffer_cb_crc": 24, "off_softbuffer_tb_crc": 32,
+                    "off_sch_max_iterations": 0, "off_sch_avg_iterations": 4, "off_sch_llr_is_8bit": 8}
 
 
-OUR_INC = '#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n#include "srsran_amd/phy_modem_abi.h"\n#include "srsran_amd/phy_nr_sch_abi.h"\n'
+OUR_INC = '#define SCH_T srsran_hip_sch_head_t\n#include "srsran_amd/phy_abi.h"\n#include "srsran_amd/phy_sync_abi.h"\n#include "srsran_amd/phy_sch_abi.h"\n#include "srsran_amd/phy_modem_abi.h"\n#include "srsran_amd/phy_nr_sch_abi.h"\n'
 
 
 def _c_sizes(flags, include, extra=""):
@@ -111,6 +114,12 @@ int main(void) {
   printf("off_tdec_interleaver %zu\\n", offsetof(srsran_tdec_t, interleaver));
   printf("off_tdec_n_iter %zu\\n", offsetof(srsran_tdec_t, n_iter));
   printf("off_ldpc_decode_c %zu\\n", offsetof(srsran_ldpc_decoder_t, decode_c));
+  printf("srsran_softbuffer_rx_t %zu\\n", sizeof(srsran_softbuffer_rx_t));
+  printf("off_softbuffer_cb_crc %zu\\n", offsetof(srsran_softbuffer_rx_t, cb_crc));
+  printf("off_softbuffer_tb_crc %zu\\n", offsetof(srsran_softbuffer_rx_t, tb_crc));
+  printf("off_sch_max_iterations %zu\\n", offsetof(SCH_T, max_iterations));
+  printf("off_sch_avg_iterations %zu\\n", offsetof(SCH_T, avg_iterations));
+  printf("off_sch_llr_is_8bit %zu\\n", offsetof(SCH_T, llr_is_8bit));
   return 0; }
 """
     d = os.path.join(ROOT, "build", "scratch")
@@ -128,7 +137,7 @@ def test_struct_layout_matches_recorded_reference(L):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/lib/include"), reason="reference headers only exist in the dev container")
 def test_struct_layout_matches_reference():
-    inc = ('#include <complex.h>\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
+    inc = ('#define SCH_T srsran_sch_t\n#include <complex.h>\n#include "srsran/phy/phch/sch.h"\n#include "srsran/phy/dft/ofdm.h"\n#include "srsran/phy/fec/turbo/turbodecoder.h"\n'
            '#include "srsran/phy/fec/ldpc/ldpc_decoder.h"\n#include "srsran/phy/fec/crc.h"\n#include "srsran/phy/sync/pss.h"\n'
            '#include "srsran/phy/sync/sss.h"\n#include "srsran/phy/dft/dft_precoding.h"\n#include "srsran/phy/sync/sync.h"\n'
            '#include "srsran/phy/fec/ldpc/ldpc_rm.h"\n#include "srsran/phy/fec/ldpc/ldpc_encoder.h"\n')

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""The reference's OWN test programs as a stopwatch: its unmodified pdsch_test / pusch_test print the time srsran_pdsch_decode /
+srsran_pusch_decode took (pdsch_test.c:480-499, pusch_test.c:326-396).  Three link sets of the same program (tests/ref_link/Makefile):
+
+  refcpu  the reference's own objects on the host cores (everything but its three FFT files): the CPU baseline by the reference itself
+  full    the library bound per code block (srsran_rm_turbo_rx_lut + srsran_tdec_iteration + CRC per block,
+          a device round trip per half iteration)
+  tb      the library bound at the reference's transport-block seam decode_tb_cb (sch.c:370; tests/ref_link/tb_bind.c): one call per block
+
+Run on the GPU box:  python tools/bench_ref_programs.py > gpurun_out/ref_programs.json
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "ref_link", "_build")
+
+CASES = [
+    # (program, args, label).  pusch_test decodes a fresh subframe per iteration; pdsch_test -X n decodes ONCE and skips the n - 1 repetitions
+    # (pdsch.c:893: a block whose crc flag is set is not decoded again), so only its single, cold decode is a measurement
+    ("pusch_test", ["-n", "100", "-L", "100", "-m", "28", "-p", "enable_64qam", "-s", "40"], "PUSCH 100 PRB, MCS 28, 64-QAM (TBS 75376: 13 code blocks), 40 subframes"),
+    ("pusch_test", ["-n", "100", "-L", "50", "-m", "21", "-p", "uci_ack", "2", "-p", "cqi", "wideband", "-s", "40"], "PUSCH 50 of 100 PRB, MCS 21, ACK + CQI multiplexed"),
+    ("pusch_test", ["-n", "25", "-L", "25", "-m", "14", "-s", "40"], "PUSCH 25 PRB, MCS 14"),
+    ("pusch_test", ["-n", "6", "-L", "6", "-m", "0", "-s", "40"], "PUSCH 6 PRB, MCS 0 (one small code block)"),
+    ("pdsch_test", ["-n", "100", "-m", "28", "-X", "1"], "PDSCH 100 PRB, MCS 28: ONE cold decode (first call of the process)"),
+]
+
+
+def run(kind, prog, args):
+    exe = os.path.join(BUILD, kind, prog)
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, errors="replace", timeout=600)
+    out = r.stdout
+    res = {"rc": r.returncode}
+    m = re.search(r"DECODED (\w+) in ([0-9.]+) \(PHY bitrate=([0-9.]+) Mbps\. Processing bitrate=([0-9.]+) Mbps\)", out)
+    if m:  # pdsch_test: microseconds per srsran_pdsch_decode, averaged by the program over its -X repetitions
+        res.update(ok=m.group(1) == "OK", us_per_decode=float(m.group(2)), mbps=float(m.group(4)))
+    m = re.search(r"Decoded Rate: ([0-9.]+) Mbps", out)
+    if m:  # pusch_test: bits over the summed decode times of its subframes; the first subframe of a process pays the one-time set-up
+        per = [float(x) for x in re.findall(r"Processing: ([0-9.]+) Mbps", out)]
+        tbs = re.search(r"TBS: (\d+) bits", out)
+        res.update(mbps=float(m.group(1)), mbps_steady=sorted(per)[len(per) // 2] if per else None,
+                   us_per_decode_steady=(int(tbs.group(1)) / sorted(per)[len(per) // 2]) if per and tbs else None)
+    if "mbps" not in res:
+        res["tail"] = out[-400:]
+    return res
+
+
+def main():
+    rows = []
+    for prog, args, label in CASES:
+        row = {"program": prog, "args": " ".join(args), "what": label}
+        for kind, key in (("bin_refcpu", "reference_cpu_1_core"), ("bin_full", "library_per_code_block"), ("bin_tb", "library_transport_block_seam")):
+            row[key] = run(kind, prog, args)
+        rows.append(row)
+        print(json.dumps(row), file=sys.stderr, flush=True)
+    print(json.dumps({"host_cpus": os.cpu_count(), "rows": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

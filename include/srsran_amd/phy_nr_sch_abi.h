@@ -13,6 +13,7 @@
 
 #include "srsran_amd/phy_abi.h"
 #include "srsran_amd/phy_modem_abi.h"
+#include "srsran_amd/phy_sch_abi.h" /* srsran_softbuffer_rx_t, srsran_cbsegm_t */
 
 #ifdef __cplusplus
 extern "C" {
@@ -151,6 +152,18 @@ SRSRAN_API int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d
 SRSRAN_API int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
                                         int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,
                                         uint8_t* d_payload, srsran_hip_nr_tb_result_t* res, void* stream);
+
+/* ---- the reference's transport-block entry points on HOST buffers: sch_nr_decode (sch_nr.c:522-713) as srsran_dlsch_nr_decode /
+ * srsran_ulsch_nr_decode (:724-749) reach it, for one transport block.  `tb`: R, tbs, mod, rv, N_L, nof_bits of srsran_sch_tb_t and the Nref
+ * of srsran_sch_nr_fill_tb_info (e_offset / payload_offset / first_cb are ignored); scaling_fctr / max_nof_iter: those of the
+ * srsran_ldpc_decoder_t objects sch_nr.c:283-312 creates (layered decoders).  e_bits: the int8 soft bits of the still undecoded code
+ * blocks, back to back (:665); softbuffer: the reference's srsran_softbuffer_rx_t (softbuffer.h:40-47, declared in phy_sch_abi.h): rows
+ * buffer_f[r] used as int8 (:570), flags cb_crc[r], packed bits data[r] of decoded blocks -- read and updated as :584-652 do, except that
+ * the row of a block that decodes in this call is not written back (nothing reads it again before srsran_softbuffer_rx_reset).
+ * payload (tbs / 8 bytes) and *crc are written when every code block is decoded (:664-705), *avg_iter always (:657-661).
+ * tests/ref_link/nr_bind.c is the reference-side binding. */
+SRSRAN_API int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_iter, const srsran_hip_nr_tb_t* tb, const int8_t* e_bits,
+                                           srsran_softbuffer_rx_t* softbuffer, uint8_t* payload, bool* crc, float* avg_iter);
 
 #ifdef __cplusplus
 }

@@ -267,9 +267,15 @@ static uint32_t crc_row_of(srsran_hip_sch_nr_t* h, uint32_t tbs_bits, uint32_t o
   return row;
 }
 
-extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
-                                        int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,
-                                        uint8_t* d_payload, srsran_hip_nr_tb_result_t* res, void* stream)
+// (tail: device-to-host copies a caller wants queued behind the last kernel and in front of the call's one host wait)
+struct TailCopy {
+  void*       dst;
+  const void* src;
+  size_t      bytes;
+};
+static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb, int8_t* d_softbuffer,
+                         uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride, uint8_t* d_payload,
+                         srsran_hip_nr_tb_result_t* res, void* stream, const TailCopy* tail, int n_tail)
 {
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS;
@@ -422,7 +428,12 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
     PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipMemcpyAsync(h->h_flags + cb_lo, h->d_flags + cb_lo, cb_hi - cb_lo, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
+    for (int i = 0; i < n_tail; i++) {
+    if (tail[i].bytes) {
+      PHY_HIP_CHECK(hipMemcpyAsync(tail[i].dst, tail[i].src, tail[i].bytes, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    }
+  }
+  PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
     std::vector<uint32_t> it_sum(n_tb, 0);
     for (uint32_t i = 0; i < n_jobs; i++) {
       const Job& j = jobs[order[i]];
@@ -453,12 +464,227 @@ extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
   PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
   PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+  for (int i = 0; i < n_tail; i++) {
+    if (tail[i].bytes) {
+      PHY_HIP_CHECK(hipMemcpyAsync(tail[i].dst, tail[i].src, tail[i].bytes, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    }
+  }
   PHY_HIP_CHECK(hipStreamSynchronize(st), SRSRAN_ERROR);
   for (uint32_t t = 0; t < n_tb; t++) {
     res[t].all_decoded = h->h_res[t].all_decoded;
     res[t].crc_ok      = h->h_res[t].crc_ok;
     res[t].avg_iter    = 0.0f;
     res[t].nof_cb      = cfg[t].C;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb,
+                                        int8_t* d_softbuffer, uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride,
+                                        uint8_t* d_payload, srsran_hip_nr_tb_result_t* res, void* stream)
+{
+  return sch_nr_decode(h, d_e_bits, tbs, n_tb, d_softbuffer, sb_stride, cb_crc, d_cb_data, data_stride, d_payload, res, stream, nullptr, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ the reference's transport-block entry points
+//
+// sch_nr_decode (sch_nr.c:522-713) as srsran_dlsch_nr_decode / srsran_ulsch_nr_decode (:724-749) reach it, for ONE transport block on the
+// caller's HOST buffers in the reference's soft-buffer struct: one upload, one de-matching launch, one early-stop LDPC launch, the
+// code-block and transport-block finish kernels, one download.  The staging context is private to the calling thread.
+
+namespace {
+
+struct NrTbStage {
+  hipStream_t                               st = nullptr;
+  std::map<uint64_t, srsran_hip_sch_nr_t*>  sch; // (scaling factor, iterations) -> decoder object
+  uint8_t*                                  pin = nullptr; // pinned image: [soft rows | data rows | e bits | payload]
+  uint8_t*                                  dev = nullptr;
+  size_t                                    cap = 0;
+  bool                                      tried = false;
+  static const uint32_t                     MAX_CB = 160; // > SRSRAN_SCH_NR_MAX_NOF_CB_LDPC (sch_nr.h:41)
+  ~NrTbStage()
+  {
+    for (auto& kv : sch) {
+      srsran_hip_sch_nr_free(kv.second);
+    }
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    if (st) {
+      (void)hipStreamDestroy(st);
+    }
+  }
+  bool ready()
+  {
+    if (!tried) {
+      tried = true;
+      if (device_available()) {
+        bind_thread();
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+          st = nullptr;
+        }
+      }
+    }
+    return st != nullptr;
+  }
+  srsran_hip_sch_nr_t* decoder(float scaling, uint32_t iters)
+  {
+    uint32_t sbits;
+    memcpy(&sbits, &scaling, 4);
+    const uint64_t key = ((uint64_t)sbits << 32) | iters;
+    auto           it  = sch.find(key);
+    if (it != sch.end()) {
+      return it->second;
+    }
+    srsran_hip_sch_nr_t* h = nullptr;
+    if (srsran_hip_sch_nr_create(&h, scaling, iters, MAX_CB) != SRSRAN_SUCCESS) {
+      return nullptr;
+    }
+    sch[key] = h;
+    return h;
+  }
+  bool grow(size_t need)
+  {
+    if (need <= cap) {
+      return true;
+    }
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    dev = pin = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&dev, need) != hipSuccess || hipHostMalloc((void**)&pin, need) != hipSuccess) {
+      return false;
+    }
+    cap = need;
+    return true;
+  }
+};
+
+inline bool copy_and_test(uint8_t* dst, const uint8_t* src, size_t n) // copies, and says whether any byte was non-zero
+{
+  uint64_t acc = 0;
+  size_t   i   = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    memcpy(&v, src + i, 8);
+    memcpy(dst + i, &v, 8);
+    acc |= v;
+  }
+  for (; i < n; i++) {
+    dst[i] = src[i];
+    acc |= src[i];
+  }
+  return acc != 0;
+}
+
+} // namespace
+
+extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_iter, const srsran_hip_nr_tb_t* tb_in, const int8_t* e_bits,
+                                           srsran_softbuffer_rx_t* softbuffer, uint8_t* payload, bool* crc, float* avg_iter)
+{
+  if (!tb_in || !e_bits || !softbuffer || !payload || !crc || !avg_iter || !softbuffer->buffer_f || !softbuffer->data || !softbuffer->cb_crc) {
+    return SRSRAN_ERROR_INVALID_INPUTS; // sch_nr.c:528-531
+  }
+  TbCfg c;
+  if (!tb_cfg(*tb_in, &c)) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr decode: invalid transport block (tbs %u, mod %u, layers %u)\n", tb_in->tbs, tb_in->mod, tb_in->N_L);
+    return SRSRAN_ERROR;
+  }
+  if (softbuffer->max_cb < c.C || softbuffer->max_cb_size < c.N || c.C > NrTbStage::MAX_CB) { // :556-559
+    return SRSRAN_ERROR;
+  }
+  static thread_local NrTbStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr decode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  srsran_hip_sch_nr_t* h = s.decoder(scaling_fctr, max_nof_iter);
+  if (!h) {
+    return SRSRAN_ERROR;
+  }
+  auto           al         = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const uint32_t sb_stride  = (uint32_t)al(c.N);
+  const uint32_t data_stride = (uint32_t)al((c.Kr + 7) / 8);
+  const uint32_t cb_bytes   = (c.Kp - c.L_cb + 7) / 8; // packed bits of a decoded code block, softbuffer.rx->data[r] (:650-652)
+  uint8_t        flags[NrTbStage::MAX_CB];
+  size_t         n_e = 0;
+  for (uint32_t r = 0; r < c.C; r++) {
+    flags[r] = softbuffer->cb_crc[r] ? 1 : 0;
+    if (!flags[r]) {
+      n_e += get_E(c, r); // the input holds the soft bits of the still undecoded blocks, back to back (:665)
+    }
+    if (!softbuffer->buffer_f[r] || !softbuffer->data[r]) {
+      fprintf(stderr, "Error: soft-buffer provided NULL buffer for cb_idx=%u\n", r); // :571-574
+      return SRSRAN_ERROR;
+    }
+  }
+  const size_t o_soft = 0, o_data = al(o_soft + (size_t)c.C * sb_stride), o_e = al(o_data + (size_t)c.C * data_stride), o_pay = al(o_e + n_e);
+  if (!s.grow(al(o_pay + c.A / 8 + 8))) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr decode: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  bool any_flag = false, any_soft = false;
+  int  first = -1, last = -1;
+  for (uint32_t r = 0; r < c.C; r++) {
+    if (flags[r]) {
+      any_flag = true;
+      memcpy(s.pin + o_data + (size_t)r * data_stride, softbuffer->data[r], cb_bytes); // decoded earlier: its packed bits join the assembly
+    } else {
+      any_soft |= copy_and_test(s.pin + o_soft + (size_t)r * sb_stride, reinterpret_cast<const uint8_t*>(softbuffer->buffer_f[r]), c.N);
+      first = first < 0 ? (int)r : first;
+      last  = (int)r;
+    }
+  }
+  srsran_hip_nr_tb_t tb = *tb_in;
+  tb.rv &= 3u;
+  tb.e_offset = tb.payload_offset = tb.first_cb = 0;
+  if (first >= 0) {
+    memcpy(s.pin + o_e, e_bits, n_e);
+    PHY_HIP_CHECK(hipMemcpyAsync(s.dev + o_e, s.pin + o_e, n_e, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+    if (!any_soft && !any_flag) {
+      tb.rv |= SRSRAN_HIP_NR_TB_NEW_DATA; // rows as srsran_softbuffer_rx_reset left them: written, not accumulated into, and not uploaded
+    } else {
+      PHY_HIP_CHECK(hipMemcpyAsync(s.dev + o_soft + (size_t)first * sb_stride, s.pin + o_soft + (size_t)first * sb_stride,
+                                   (size_t)(last - first) * sb_stride + c.N, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+    }
+  }
+  if (any_flag) {
+    PHY_HIP_CHECK(hipMemcpyAsync(s.dev + o_data, s.pin + o_data, (size_t)c.C * data_stride, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  }
+  srsran_hip_nr_tb_result_t res = {};
+  const TailCopy tail[2] = {{s.pin + o_data, s.dev + o_data, (size_t)c.C * data_stride}, {s.pin + o_pay, s.dev + o_pay, c.A / 8}};
+  if (sch_nr_decode(h, reinterpret_cast<const int8_t*>(s.dev + o_e), &tb, 1, reinterpret_cast<int8_t*>(s.dev + o_soft), sb_stride, flags, s.dev + o_data,
+                    data_stride, s.dev + o_pay, &res, s.st, tail, 2) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr decode: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  // host side effects of :633-652: flags, the packed bits of the blocks decoded now; rows of the blocks that are still undecoded
+  int f_first = -1, f_last = -1;
+  for (uint32_t r = 0; r < c.C; r++) {
+    if (softbuffer->cb_crc[r]) {
+      continue;
+    }
+    if (flags[r]) {
+      softbuffer->cb_crc[r] = true;
+      memcpy(softbuffer->data[r], s.pin + o_data + (size_t)r * data_stride, cb_bytes);
+    } else {
+      f_first = f_first < 0 ? (int)r : f_first;
+      f_last  = (int)r;
+    }
+  }
+  if (f_first >= 0) {
+    PHY_HIP_CHECK(hipMemcpyAsync(s.pin + o_soft + (size_t)f_first * sb_stride, s.dev + o_soft + (size_t)f_first * sb_stride,
+                                 (size_t)(f_last - f_first) * sb_stride + c.N, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+    for (int r = f_first; r <= f_last; r++) {
+      if (!softbuffer->cb_crc[r]) {
+        memcpy(softbuffer->buffer_f[r], s.pin + o_soft + (size_t)r * sb_stride, c.N);
+      }
+    }
+  }
+  *avg_iter = res.avg_iter; // :657-661
+  if (res.all_decoded) {    // :664-666: otherwise neither the payload nor res->crc is touched
+    memcpy(payload, s.pin + o_pay, c.A / 8);
+    *crc = res.crc_ok != 0;
   }
   return SRSRAN_SUCCESS;
 }

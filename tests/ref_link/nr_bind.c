@@ -1,0 +1,54 @@
+/* tests/ref_link/nr_bind.c -- the reference-side binding of the NR transport-block entry points.
+ *
+ * Compiled against the REFERENCE's headers, like any file a maintainer adds to lib/src/phy/phch.  The reference's sch_nr.c is compiled
+ * unmodified; its definitions of srsran_dlsch_nr_decode / srsran_ulsch_nr_decode (sch_nr.c:724-749, one-line wrappers of the static
+ * sch_nr_decode) are made weak symbols in the object file (objcopy --weaken-symbol, tests/ref_link/Makefile) and these take their place:
+ * a transport block that srsran_pdsch_nr_decode / srsran_pusch_nr_decode hand over goes to the device as ONE call instead of a rate
+ * de-matching call and a decoder call per code block.  Everything else of sch_nr.c stays the reference's: object set-up, carrier,
+ * srsran_sch_nr_fill_tb_info (whose Nref comes from the reference's resource-allocation code), the transmit side. */
+#include <math.h>
+#include <stdbool.h>
+#include <stdint.h>
+
+#include "srsran/phy/phch/sch_nr.h"
+
+/* include/srsran_amd/phy_nr_sch_abi.h (its type names would collide with the reference headers of this file: declared by hand) */
+typedef struct {
+  double   R;
+  uint32_t tbs, mod, rv, N_L, nof_bits, Nref, e_offset, payload_offset, first_cb, reserved;
+} srsran_hip_nr_tb_t;
+extern int srsran_hip_sch_nr_decode_tb(float                     scaling_fctr,
+                                       uint32_t                  max_nof_iter,
+                                       const srsran_hip_nr_tb_t* tb,
+                                       const int8_t*             e_bits,
+                                       srsran_softbuffer_rx_t*   softbuffer,
+                                       uint8_t*                  payload,
+                                       bool*                     crc,
+                                       float*                    avg_iter);
+
+static int decode_on_device(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, int8_t* e_bits, srsran_sch_tb_res_nr_t* res)
+{
+  if (!q || !sch_cfg || !tb || !e_bits || !res) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  srsran_sch_nr_tb_info_t cfg = {};
+  if (srsran_sch_nr_fill_tb_info(&q->carrier, sch_cfg, tb, &cfg) < SRSRAN_SUCCESS) {
+    return SRSRAN_ERROR;
+  }
+  const srsran_ldpc_decoder_t* decoder = (cfg.bg == BG1) ? q->decoder_bg1[cfg.Z] : q->decoder_bg2[cfg.Z];
+  if (decoder == NULL) {
+    return SRSRAN_ERROR;
+  }
+  srsran_hip_nr_tb_t d = {.R = tb->R, .tbs = (uint32_t)tb->tbs, .mod = (uint32_t)tb->mod, .rv = (uint32_t)tb->rv, .N_L = tb->N_L, .nof_bits = tb->nof_bits, .Nref = cfg.Nref};
+  return srsran_hip_sch_nr_decode_tb(decoder->scaling_fctr, decoder->max_nof_iter, &d, e_bits, tb->softbuffer.rx, res->payload, &res->crc, &res->avg_iter);
+}
+
+int srsran_dlsch_nr_decode(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, int8_t* e_bits, srsran_sch_tb_res_nr_t* res)
+{
+  return decode_on_device(q, sch_cfg, tb, e_bits, res);
+}
+
+int srsran_ulsch_nr_decode(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, int8_t* e_bits, srsran_sch_tb_res_nr_t* res)
+{
+  return decode_on_device(q, sch_cfg, tb, e_bits, res);
+}

@@ -376,3 +376,79 @@ def test_large_transport_block_vs_oracle(hiplib):
     assert np.array_equal(d_soft.to_numpy(np.int8, (24, SB))[2:2 + cfg.C], soft)
     assert ok == 1 and np.array_equal(d_out.to_numpy(np.uint8, (tbs // 8,)), payload)
     hiplib.srsran_hip_sch_nr_free(h)
+
+
+class _SoftbufferRx(C.Structure):  # srsran_softbuffer_rx_t, softbuffer.h:40-47
+    _fields_ = [("max_cb", C.c_uint32), ("max_cb_size", C.c_uint32), ("buffer_f", C.POINTER(C.c_void_p)), ("data", C.POINTER(C.c_void_p)),
+                ("cb_crc", C.POINTER(C.c_bool)), ("tb_crc", C.c_bool)]
+
+
+def test_transport_block_entry_point_on_the_reference_structs(hiplib):
+    """srsran_hip_sch_nr_decode_tb = sch_nr_decode (sch_nr.c:522-713) as srsran_dlsch_nr_decode / srsran_ulsch_nr_decode reach it, on HOST buffers in
+    the reference's srsran_softbuffer_rx_t: the 21-block transport block of the test above (two sizes of E, two layers, limited buffer), a
+    first transmission that leaves some code blocks undecoded and the retransmission (rv 2) that carries the soft bits of exactly those --
+    flags, stored code blocks, iteration average, the soft rows of the undecoded blocks, payload and CRC equal to the oracle's loop"""
+    from srslte_amd import capi
+
+    fn = hiplib.srsran_hip_sch_nr_decode_tb
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    tbs, R, mod, Nl = 176208, 0.8, 3, 2
+    G, Nref = 12 * 19003, 20000
+    cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, Nref)
+    Es = [O.sch_nr_get_E(cfg, r) for r in range(cfg.C)]
+    rng = np.random.default_rng(11)
+    payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+    e = O.sch_nr_encode_tb(cfg, 0, payload)
+    llr = np.clip(np.round(9.0 * (1.0 - 2.0 * e) + 5.0 * rng.standard_normal(G)), -63, 63).astype(np.int8)
+    SB, DS = 66 * 384, 8448 // 8
+    max_cb = cfg.C + 3
+    rows = [np.zeros(SB + 8, np.int16) for _ in range(max_cb)]  # srsran_softbuffer_rx_init_guru: int16 rows, used as int8 by sch_nr.c:570
+    keep = [np.zeros(SB // 8 + 8, np.uint8) for _ in range(max_cb)]
+    flags = np.zeros(max_cb, np.bool_)
+    sb = _SoftbufferRx(max_cb, SB + 8, (C.c_void_p * max_cb)(*[r.ctypes.data for r in rows]), (C.c_void_p * max_cb)(*[k.ctypes.data for k in keep]),
+                       flags.ctypes.data_as(C.POINTER(C.c_bool)), False)
+    out = np.full(tbs // 8 + 16, 0xEE, np.uint8)
+    crc_ok, avg = C.c_bool(False), C.c_float(-1)
+    tb = capi.HipNrTb(R, tbs, mod, 0, Nl, G, Nref, 0, 0, 0, 0)
+    assert fn(0.8, 6, C.byref(tb), O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) == 0
+    soft, crc, data = np.zeros((cfg.C, SB), np.int8), np.zeros(cfg.C, np.uint8), np.zeros((cfg.C, DS), np.uint8)
+    o_out, ok, o_avg = O.sch_nr_decode_tb(cfg, 0, 0.8, 6, llr, soft, crc, data)
+    assert 0 < crc.sum() < cfg.C and np.array_equal(flags[:cfg.C].astype(np.uint8), crc) and not flags[cfg.C:].any()
+    assert abs(avg.value - o_avg) < 1e-6 and not crc_ok.value and np.all(out == 0xEE)  # (payload and crc untouched: not every block decoded, :664-666)
+    cb_bytes = (cfg.Kp - cfg.L_cb) // 8
+    for r in range(cfg.C):
+        if crc[r]:
+            assert np.array_equal(keep[r][:cb_bytes], data[r][:cb_bytes]), r
+        else:
+            assert np.array_equal(rows[r].view(np.int8)[:SB], soft[r]), r
+    # retransmission: soft bits of the undecoded blocks only (sch_nr.c:584-588,665), combining in the rows the first call left on the host
+    e2 = O.sch_nr_encode_tb(cfg, 2, payload)
+    off = np.cumsum([0] + Es)
+    left = np.concatenate([e2[off[r]:off[r + 1]] for r in range(cfg.C) if not crc[r]])
+    llr2 = np.clip(np.round(9.0 * (1.0 - 2.0 * left) + 3.0 * rng.standard_normal(left.size)), -63, 63).astype(np.int8)
+    tb.rv = 2
+    assert fn(0.8, 6, C.byref(tb), O.P(llr2), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) == 0
+    o_out, ok, o_avg = O.sch_nr_decode_tb(cfg, 2, 0.8, 6, llr2, soft, crc, data)
+    assert ok == 1 and crc_ok.value and flags[:cfg.C].all() and abs(avg.value - o_avg) < 1e-6
+    assert np.array_equal(out[:tbs // 8], payload) and np.all(out[tbs // 8:] == 0xEE)
+    # a small single-block transport block (CRC16, BG2), fresh soft buffer
+    tbs, R, mod, Nl, G = 1032, 0.4, 1, 1, 2600
+    cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, 0)
+    assert cfg.C == 1 and cfg.L_tb == 16 and cfg.bg == 1
+    cfg.Nref = 50 * cfg.Z  # full buffer (the library takes Nref = 0 for it)
+    payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+    e = O.sch_nr_encode_tb(cfg, 0, payload)
+    llr = np.clip(np.round(12.0 * (1.0 - 2.0 * e) + 4.0 * rng.standard_normal(e.size)), -63, 63).astype(np.int8)
+    for r in rows:
+        r[:] = 0
+    flags[:] = False
+    tb = capi.HipNrTb(R, tbs, mod, 0, Nl, G, 0, 0, 0, 0, 0)
+    assert fn(0.8, 6, C.byref(tb), O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) == 0
+    soft, crc, data = np.zeros((1, SB), np.int8), np.zeros(1, np.uint8), np.zeros((1, DS), np.uint8)
+    o_out, ok, o_avg = O.sch_nr_decode_tb(cfg, 0, 0.8, 6, llr, soft, crc, data)
+    assert ok == 1 and crc_ok.value and flags[0] and abs(avg.value - o_avg) < 1e-6 and np.array_equal(out[:tbs // 8], payload)
+    # argument protection (sch_nr.c:528-531, 556-559)
+    assert fn(0.8, 6, None, O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) < 0
+    sb.max_cb = 0
+    assert fn(0.8, 6, C.byref(tb), O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) < 0

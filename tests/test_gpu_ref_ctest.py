@@ -52,7 +52,9 @@ def test_ctest_line(entry, data_dir):
 # sch.c, built a second time with ITS decode_tb_cb (sch.c:370) weakened in the object file and the library's in its place -- every transport
 # block that srsran_pdsch_decode / srsran_pusch_decode / srsran_pmch_decode hand to srsran_dlsch_decode2 / srsran_ulsch_decode goes to the
 # device as one call (rate de-matching, turbo early stop, CRCs), on the reference's own soft-buffer structs.
-TB_PROGRAMS = {"pdsch_test", "pusch_test", "pmch_test", "pdsch_pdcch_file_test", "pmch_file_test"}
+# NR (tests/ref_link/nr_bind.c): srsran_dlsch_nr_decode / srsran_ulsch_nr_decode (sch_nr.c:724-749) of the unmodified sch_nr.o weakened, the
+# binding's in their place -- sch_nr_test drives them directly, pdsch_nr_test / pusch_nr_test through srsran_pdsch_nr_decode / srsran_pusch_nr_decode
+TB_PROGRAMS = {"pdsch_test", "pusch_test", "pmch_test", "pdsch_pdcch_file_test", "pmch_file_test", "sch_nr_test", "pdsch_nr_test", "pusch_nr_test"}
 
 
 def _selected_tb():

@@ -32,6 +32,10 @@ _NO_PACK = ["-fno-slp-vectorize", "-mllvm", "-disable-vector-combine"]
 EXTRA_FLAGS = {"pss_wave_kernels.hip": _NO_PACK, "ofdm_kernels.hip": _NO_PACK, "sync_kernels.hip": _NO_PACK}
 
 
+# development only: extra compiler flags for timing experiments (e.g. -DLAT_EXP_NO_COLLECT), never set by the product build
+_DEV_FLAGS = os.environ.get("SRSRAN_HIP_BUILD_FLAGS", "").split()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -54,7 +58,7 @@ def build(force=False, verbose=True, jobs=8):
         # an object newer than its source, every header and this file is kept (headers are shared: any header change rebuilds all)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(f) for f in [src, __file__] + HEADERS):
             continue
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + _DEV_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

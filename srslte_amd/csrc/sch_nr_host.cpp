@@ -337,7 +337,14 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
   for (uint32_t i = cb_lo; i < cb_hi; i++) {
     h->h_flags[i] = cb_crc[i] ? 1 : 0;
   }
-  PHY_HIP_CHECK(hipMemcpyAsync(h->d_flags + cb_lo, h->h_flags + cb_lo, cb_hi - cb_lo, hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  // A slot's worth of code blocks or less: the kernels read the job lists from, and write flags / iteration counts / results into, the PINNED HOST
+  // images themselves (mapped into the device's address space): seven stream operations fewer per call, 6-9 us each whatever the size
+  // (tools/probe/roundtrip_probe.hip).  Large batches keep the copies.
+  const bool direct = n_jobs + n_tb <= 1024;
+  uint8_t*   x_flags = direct ? h->h_flags : h->d_flags;
+  if (!direct) {
+    PHY_HIP_CHECK(hipMemcpyAsync(h->d_flags + cb_lo, h->h_flags + cb_lo, cb_hi - cb_lo, hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  }
 
   if (n_jobs) {
     // ---- rate de-matching, grouped by the parameters of init_rm
@@ -388,8 +395,13 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
       h->h_map[i]  = j.cb;
       h->h_cbf[i]  = nrsch::CbFin{j.cb, j.cb, j.cb_len};
     }
-    PHY_HIP_CHECK(hipMemcpyAsync(h->d_map, h->h_map, n_jobs * sizeof(uint32_t), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(h->d_cbf, h->h_cbf, n_jobs * sizeof(nrsch::CbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    uint32_t*     x_map  = direct ? h->h_map : h->d_map;
+    nrsch::CbFin* x_cbf  = direct ? h->h_cbf : h->d_cbf;
+    int*          x_iter = direct ? h->h_iter : h->d_iter;
+    if (!direct) {
+      PHY_HIP_CHECK(hipMemcpyAsync(h->d_map, h->h_map, n_jobs * sizeof(uint32_t), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+      PHY_HIP_CHECK(hipMemcpyAsync(h->d_cbf, h->h_cbf, n_jobs * sizeof(nrsch::CbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    }
     for (uint32_t i = 0; i < n_jobs;) {
       uint32_t e = i;
       while (e < n_jobs && dec_key(jobs[order[e]]) == dec_key(jobs[order[i]])) {
@@ -405,14 +417,16 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
         }
         it = h->dec.emplace(key, d).first;
       }
-      if (srsran_hip_ldpc_batch_run_crc_map(it->second, d_softbuffer, sb_stride, h->d_msg, MSG_STRIDE, h->d_map + i, e - i, j.n_llr, j.poly, j.order,
-                                            h->d_iter + i, st) != SRSRAN_SUCCESS) {
+      if (srsran_hip_ldpc_batch_run_crc_map(it->second, d_softbuffer, sb_stride, h->d_msg, MSG_STRIDE, x_map + i, e - i, j.n_llr, j.poly, j.order,
+                                            x_iter + i, st) != SRSRAN_SUCCESS) {
         return SRSRAN_ERROR;
       }
       i = e;
     }
-    PHY_HIP_CHECK(nrsch::launch_cb_finish(h->d_msg, MSG_STRIDE, h->d_cbf, h->d_iter, n_jobs, h->d_flags, d_cb_data, data_stride, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(h->h_iter, h->d_iter, n_jobs * sizeof(int), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(nrsch::launch_cb_finish(h->d_msg, MSG_STRIDE, x_cbf, x_iter, n_jobs, x_flags, d_cb_data, data_stride, st), SRSRAN_ERROR);
+    if (!direct) {
+      PHY_HIP_CHECK(hipMemcpyAsync(h->h_iter, h->d_iter, n_jobs * sizeof(int), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    }
     // ---- back to transport blocks
     if (!ensure(&h->d_tbf, &h->h_tbf, &h->tbf_cap, n_tb) || !ensure(&h->d_res, &h->h_res, &h->res_cap, n_tb)) {
       return SRSRAN_ERROR;
@@ -424,10 +438,15 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
         return SRSRAN_ERROR;
       }
     }
-    PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMemcpyAsync(h->h_flags + cb_lo, h->d_flags + cb_lo, cb_hi - cb_lo, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    if (!direct) {
+      PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+    }
+    PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, x_flags, direct ? h->h_tbf : h->d_tbf, n_tb, d_payload, h->d_crc_mult,
+                                          direct ? h->h_res : h->d_res, st), SRSRAN_ERROR);
+    if (!direct) {
+      PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+      PHY_HIP_CHECK(hipMemcpyAsync(h->h_flags + cb_lo, h->d_flags + cb_lo, cb_hi - cb_lo, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+    }
     for (int i = 0; i < n_tail; i++) {
     if (tail[i].bytes) {
       PHY_HIP_CHECK(hipMemcpyAsync(tail[i].dst, tail[i].src, tail[i].bytes, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
@@ -461,9 +480,14 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
       return SRSRAN_ERROR;
     }
   }
-  PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, h->d_flags, h->d_tbf, n_tb, d_payload, h->d_crc_mult, h->d_res, st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+  if (!direct) {
+    PHY_HIP_CHECK(hipMemcpyAsync(h->d_tbf, h->h_tbf, n_tb * sizeof(nrsch::TbFin), hipMemcpyHostToDevice, st), SRSRAN_ERROR);
+  }
+  PHY_HIP_CHECK(nrsch::launch_tb_finish(d_cb_data, data_stride, x_flags, direct ? h->h_tbf : h->d_tbf, n_tb, d_payload, h->d_crc_mult,
+                                        direct ? h->h_res : h->d_res, st), SRSRAN_ERROR);
+  if (!direct) {
+    PHY_HIP_CHECK(hipMemcpyAsync(h->h_res, h->d_res, n_tb * sizeof(nrsch::TbFinRes), hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
+  }
   for (int i = 0; i < n_tail; i++) {
     if (tail[i].bytes) {
       PHY_HIP_CHECK(hipMemcpyAsync(tail[i].dst, tail[i].src, tail[i].bytes, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
@@ -559,21 +583,35 @@ struct NrTbStage {
   }
 };
 
-inline bool copy_and_test(uint8_t* dst, const uint8_t* src, size_t n) // copies, and says whether any byte was non-zero
+// true when the n bytes at p (8-byte aligned, as the rows of a soft buffer are) are all zero: a row straight after srsran_softbuffer_rx_reset
+// is not worth a copy, let alone a transfer.  Read-only, four independent accumulators (vectorises), early exit per 4 KB.
+inline bool all_zero(const uint8_t* p, size_t n)
 {
-  uint64_t acc = 0;
-  size_t   i   = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint64_t v;
-    memcpy(&v, src + i, 8);
-    memcpy(dst + i, &v, 8);
-    acc |= v;
+  size_t i = 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const size_t    w = n / 8;
+    for (size_t j = 0; j < w;) {
+      const size_t e = j + 512 < w ? j + 512 : w;
+      uint64_t     a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      for (; j + 4 <= e; j += 4) {
+        a0 |= q[j], a1 |= q[j + 1], a2 |= q[j + 2], a3 |= q[j + 3];
+      }
+      for (; j < e; j++) {
+        a0 |= q[j];
+      }
+      if (a0 | a1 | a2 | a3) {
+        return false;
+      }
+    }
+    i = w * 8;
   }
   for (; i < n; i++) {
-    dst[i] = src[i];
-    acc |= src[i];
+    if (p[i]) {
+      return false;
+    }
   }
-  return acc != 0;
+  return true;
 }
 
 } // namespace
@@ -629,17 +667,23 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
       any_flag = true;
       memcpy(s.pin + o_data + (size_t)r * data_stride, softbuffer->data[r], cb_bytes); // decoded earlier: its packed bits join the assembly
     } else {
-      any_soft |= copy_and_test(s.pin + o_soft + (size_t)r * sb_stride, reinterpret_cast<const uint8_t*>(softbuffer->buffer_f[r]), c.N);
-      first = first < 0 ? (int)r : first;
-      last  = (int)r;
+      any_soft = any_soft || !all_zero(reinterpret_cast<const uint8_t*>(softbuffer->buffer_f[r]), c.N);
+      first    = first < 0 ? (int)r : first;
+      last     = (int)r;
+    }
+  }
+  if (any_soft || any_flag) { // a retransmission: the rows hold the earlier transmissions' soft bits
+    for (uint32_t r = 0; r < c.C; r++) {
+      if (!flags[r]) {
+        memcpy(s.pin + o_soft + (size_t)r * sb_stride, softbuffer->buffer_f[r], c.N);
+      }
     }
   }
   srsran_hip_nr_tb_t tb = *tb_in;
   tb.rv &= 3u;
   tb.e_offset = tb.payload_offset = tb.first_cb = 0;
   if (first >= 0) {
-    memcpy(s.pin + o_e, e_bits, n_e);
-    PHY_HIP_CHECK(hipMemcpyAsync(s.dev + o_e, s.pin + o_e, n_e, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+    memcpy(s.pin + o_e, e_bits, n_e); // (the de-matcher reads them once, coalesced: straight from the pinned image)
     if (!any_soft && !any_flag) {
       tb.rv |= SRSRAN_HIP_NR_TB_NEW_DATA; // rows as srsran_softbuffer_rx_reset left them: written, not accumulated into, and not uploaded
     } else {
@@ -652,7 +696,7 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
   }
   srsran_hip_nr_tb_result_t res = {};
   const TailCopy tail[2] = {{s.pin + o_data, s.dev + o_data, (size_t)c.C * data_stride}, {s.pin + o_pay, s.dev + o_pay, c.A / 8}};
-  if (sch_nr_decode(h, reinterpret_cast<const int8_t*>(s.dev + o_e), &tb, 1, reinterpret_cast<int8_t*>(s.dev + o_soft), sb_stride, flags, s.dev + o_data,
+  if (sch_nr_decode(h, reinterpret_cast<const int8_t*>(s.pin + o_e), &tb, 1, reinterpret_cast<int8_t*>(s.dev + o_soft), sb_stride, flags, s.dev + o_data,
                     data_stride, s.dev + o_pay, &res, s.st, tail, 2) != SRSRAN_SUCCESS) {
     fprintf(stderr, "[srsran_phy_hip] sch_nr decode: %s\n", get_error());
     return SRSRAN_ERROR;
@@ -675,9 +719,11 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
     PHY_HIP_CHECK(hipMemcpyAsync(s.pin + o_soft + (size_t)f_first * sb_stride, s.dev + o_soft + (size_t)f_first * sb_stride,
                                  (size_t)(f_last - f_first) * sb_stride + c.N, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
     PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+    // (the circular buffer of a block ends at Ncb = min(N, Nref), ldpc_rm.c:704-705: nothing behind it is ever written or read)
+    const uint32_t n_cb_buf = c.N <= c.Nref ? c.N : c.Nref;
     for (int r = f_first; r <= f_last; r++) {
       if (!softbuffer->cb_crc[r]) {
-        memcpy(softbuffer->buffer_f[r], s.pin + o_soft + (size_t)r * sb_stride, c.N);
+        memcpy(softbuffer->buffer_f[r], s.pin + o_soft + (size_t)r * sb_stride, n_cb_buf);
       }
     }
   }

@@ -272,14 +272,51 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
     auto         fetch  = [&](uint32_t e) -> short {
       return p.in_is8 ? AR::conv_in((int)reinterpret_cast<const signed char*>(p.input)[in_off + e]) : AR::conv_in((int)p.input[in_off + e]);
     };
-    for (uint32_t b = 0; b < nblk; b++) {
+    if (p.sb_layout) {
+      // rm_turbo layout (what the de-matcher leaves in the soft buffer): element (step k, sub-block d) of stream a at a (K + 32) + k NB + d, so the
+      // two sub-blocks of a pair are ONE aligned 32-bit (16-bit soft bits) or 16-bit (8-bit soft bits) word, a wave reads 8 steps x NB elements
+      // = one contiguous run per stream, and four 8-step blocks are requested before the first is stored (the element-wise loop below: two
+      // dependent 2-byte loads per stream and block, 8 us more per launch)
+      const uint8_t* in8 = reinterpret_cast<const uint8_t*>(p.input) + (p.in_is8 ? in_off : 2 * in_off);
+      auto           pair_word = [&](uint32_t e) -> uint32_t { // elements e, e + 1 (e even) through AR::conv_in, as `fetch` does
+        if (p.in_is8) {
+          const uint32_t w = *reinterpret_cast<const uint16_t*>(in8 + e);
+          return (uint32_t)(uint16_t)AR::conv_in((int)(signed char)(w & 0xffu)) | ((uint32_t)(uint16_t)AR::conv_in((int)(signed char)(w >> 8)) << 16);
+        }
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(in8 + 2 * (size_t)e);
+        return (uint32_t)(uint16_t)AR::conv_in((int)(short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((int)(short)(w >> 16)) << 16);
+      };
+      constexpr uint32_t UB = 4;
+      for (uint32_t b0 = 0; b0 < nblk; b0 += UB) {
+        uint32_t v[UB][3];
+#pragma unroll
+        for (uint32_t u = 0; u < UB; u++) {
+          const uint32_t k  = (b0 + u) * 8 + slot;
+          const uint32_t kk = k < long_sb ? k : long_sb - 1;
+#pragma unroll
+          for (int a3 = 0; a3 < 3; a3++) {
+            v[u][a3] = pair_word(a3 * (K + 32) + kk * NB + 2 * pl);
+          }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UB; u++) {
+          if (b0 + u < nblk) {
+            const uint32_t at = ((b0 + u) * LPC + pl) * 8 + slot;
+            S[at]  = v[u][0];
+            P0[at] = v[u][1];
+            P1[at] = v[u][2];
+          }
+        }
+      }
+    }
+    for (uint32_t b = p.sb_layout ? nblk : 0; b < nblk; b++) {
       const uint32_t k  = b * 8 + slot;
       const uint32_t kk = k < long_sb ? k : long_sb - 1;
       uint32_t       v[3];
 #pragma unroll
       for (int a3 = 0; a3 < 3; a3++) {
         short lo, hi;
-        if (p.sb_layout) { // rm_turbo layout: element (step k, sub-block d) of stream a at a (K + 32) + k NB + d
+        if (p.sb_layout) { // (taken above)
           lo = fetch(a3 * (K + 32) + kk * NB + 2 * pl);
           hi = fetch(a3 * (K + 32) + kk * NB + 2 * pl + 1);
         } else { // natural order [s p0 p1] x K

@@ -347,13 +347,13 @@ extern "C" void srsran_dft_run_r(srsran_dft_plan_t* plan, const float* in, float
   }
   const size_t bytes = (size_t)plan->size * sizeof(float);
   memcpy(c->h_in, in, bytes);
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
+  // (one transform per call: the kernel loads its input once and stores its output once, so it works on the pinned host images themselves --
+  // no copy operation on either side, 6-9 us each whatever the size: tools/probe/roundtrip_probe.hip)
   dft::Params p;
-  fill_params(&p, c, c->d_in, c->d_out, !plan->forward, false, false, false, plan->db);
+  fill_params(&p, c, c->h_in, c->h_out, !plan->forward, false, false, false, plan->db);
   p.real_mode = plan->forward ? 1 : 2;
   p.norm      = plan->norm ? 1.0f / (float)plan->size : 0.0f; // dft_fftw.c:374-377: 1/N, not 1/sqrt(N)
   PHY_HIP_CHECK_VOID(dft::launch(p, c->stream));
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_out, bytes);
 }
@@ -466,21 +466,23 @@ static void run_contiguous(srsran_dft_plan_t* plan, const cf_t* in, cf_t* out, b
   memcpy(c->h_in, in, bytes);
   // copy_post leaves the last `dc` output samples untouched: seed the staging buffer with the caller's data
   memcpy(c->h_out, out, bytes);
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_out, c->h_out, bytes, hipMemcpyHostToDevice, c->stream));
   if (c->N1) {
+    // four-step path: several passes over the data, which therefore lives on the device
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_in, c->h_in, bytes, hipMemcpyHostToDevice, c->stream));
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_out, c->h_out, bytes, hipMemcpyHostToDevice, c->stream));
     if (run_large(c, c->d_in, c->d_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
                   options && plan->db, c->stream)) {
       fprintf(stderr, "[srsran_phy_hip] srsran_dft_run: %s\n", get_error());
       return;
     }
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
   } else {
+    // one kernel, input loaded once, output stored once: on the pinned host images themselves (see srsran_dft_run_r)
     dft::Params p;
-    fill_params(&p, c, c->d_in, c->d_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
+    fill_params(&p, c, c->h_in, c->h_out, !plan->forward, options && plan->mirror, options && plan->dc, options && plan->norm,
                 options && plan->db);
     PHY_HIP_CHECK_VOID(dft::launch(p, c->stream));
   }
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_out, bytes);
 }
@@ -708,12 +710,10 @@ extern "C" int srsran_dft_precoding(srsran_dft_precoding_t* q, cf_t* input, cf_t
   }
   // all symbols in one launch (the reference loops srsran_dft_run_c per symbol, :122-124)
   memcpy(c->h_in, input, n * sizeof(cf_t));
-  PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, n * sizeof(cf_t), hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
-  dft::Params p;
-  fill_params(&p, c, c->d_in, c->d_out, !plan->forward, plan->mirror, plan->dc, plan->norm, plan->db);
+  dft::Params p; // (the kernel works on the pinned host images themselves, see srsran_dft_run_r)
+  fill_params(&p, c, c->h_in, c->h_out, !plan->forward, plan->mirror, plan->dc, plan->norm, plan->db);
   p.how_many = (int)nof_symbols;
   PHY_HIP_CHECK(dft::launch(p, c->stream), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpyAsync(c->h_out, c->d_out, n * sizeof(cf_t), hipMemcpyDeviceToHost, c->stream), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipStreamSynchronize(c->stream), SRSRAN_ERROR);
   memcpy(output, c->h_out, n * sizeof(cf_t));
   return SRSRAN_SUCCESS;

@@ -121,8 +121,8 @@ struct Stage {
   bool        tried    = false;
   ~Stage()
   {
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    (void)hipHostFree(d_in);
+    (void)hipHostFree(d_out);
     if (st) {
       (void)hipStreamDestroy(st);
     }
@@ -142,10 +142,13 @@ struct Stage {
     if (need <= *cap) {
       return true;
     }
-    (void)hipFree(*p);
+    // PINNED HOST memory, mapped into the device's address space: a single call's symbols are read once and its soft bits written once, so the
+    // kernel works on the staging images themselves -- no copy operation on either side of it (6-9 us each whatever the size, and from / to
+    // pageable memory a staged, blocking one: tools/probe/roundtrip_probe.hip)
+    (void)hipHostFree(*p);
     *p   = nullptr;
     *cap = 0;
-    if (hipMalloc(p, need + need / 2 + 256) != hipSuccess) {
+    if (hipHostMalloc(p, need + need / 2 + 256) != hipSuccess) {
       return false;
     }
     *cap = need + need / 2 + 256;
@@ -186,10 +189,10 @@ int run_host(uint32_t mod, const void* in, void* out, int llr_type, uint32_t n, 
   p.single  = modem::Job{mod, n, 0, 0, seed, scramble ? 1u : 0u, 0, modem::tiles_of(mod, n)};
   p.n_jobs  = 1;
   p.n_tiles = p.single.ntiles;
-  PHY_HIP_CHECK(hipMemcpyAsync(s.d_in, in, in_bytes, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  memcpy(s.d_in, in, in_bytes);
   PHY_HIP_CHECK(modem::launch(p, s.st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpyAsync(out, s.d_out, n_llr * es, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  memcpy(out, s.d_out, n_llr * es);
   return SRSRAN_SUCCESS;
 }
 
@@ -421,14 +424,14 @@ extern "C" int srsran_predecoding_single(cf_t* y, cf_t* h, cf_t* x, float* csi, 
   }
   uint8_t* din  = (uint8_t*)s.d_in;
   uint8_t* dout = (uint8_t*)s.d_out;
-  PHY_HIP_CHECK(hipMemcpyAsync(din, y, nb, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpyAsync(din + slot, h, nb, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  memcpy(din, y, nb); // (the staging images are pinned host memory the kernel works on directly, see Stage::grow)
+  memcpy(din + slot, h, nb);
   PHY_HIP_CHECK(modem::launch_eq(din, din + slot, dout, csi ? (float*)(dout + slot) : nullptr, (uint32_t)nof_symbols, scaling, noise_estimate, s.st),
                 SRSRAN_ERROR);
-  PHY_HIP_CHECK(hipMemcpyAsync(x, dout, nb, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
-  if (csi) {
-    PHY_HIP_CHECK(hipMemcpyAsync(csi, dout + slot, (size_t)nof_symbols * sizeof(float), hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
-  }
   PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  memcpy(x, dout, nb);
+  if (csi) {
+    memcpy(csi, dout + slot, (size_t)nof_symbols * sizeof(float));
+  }
   return nof_symbols;
 }

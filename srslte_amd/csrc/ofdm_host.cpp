@@ -589,17 +589,21 @@ void rx_run(srsran_ofdm_t* q, cf_t* input, cf_t* output, bool with_ramp)
   const size_t   nt = q->sf_sz, nr = (size_t)q->nof_re * 2 * q->nof_symbols;
   const bool     sh = std::isnormal(q->cfg.freq_shift_f);
   memcpy(c->h_time, input, nt * sizeof(cf_t));
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_time, c->h_time, nt * sizeof(cf_t), hipMemcpyHostToDevice, c->stream));
+  // One subframe per call: the demodulator reads every sample once and writes every resource element once, so it works on the PINNED HOST
+  // images themselves (mapped into the device's address space) -- no copy operation on either side of the kernel: a copy operation costs
+  // 6-9 us whatever its size, the 380 KB of a 20 MHz subframe cross the bus in about as much (tools/probe/roundtrip_probe.hip).
+  float2* t_in = reinterpret_cast<float2*>(c->h_time);
   if (sh) {
-    // ofdm.c:455-457 multiplies the caller's input buffer in place; reproduce the side effect
+    // ofdm.c:455-457 multiplies the caller's input buffer in place; reproduce the side effect (product kept on the device for the transform)
+    PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_time, c->h_time, nt * sizeof(cf_t), hipMemcpyHostToDevice, c->stream));
     PHY_HIP_CHECK_VOID(ofdm::launch_prod_ccc(c->d_time, c->b->d_shift, c->d_time, (int)nt, c->stream));
     PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_time, c->d_time, nt * sizeof(cf_t), hipMemcpyDeviceToHost, c->stream));
+    t_in = c->d_time;
   }
-  if (batch_run(c->b, c->d_time, c->d_re, 1, false, false, c->stream, with_ramp)) {
+  if (batch_run(c->b, t_in, reinterpret_cast<float2*>(c->h_re), 1, false, false, c->stream, with_ramp)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ofdm_rx_sf: %s\n", get_error());
     return;
   }
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_re, c->d_re, nr * sizeof(cf_t), hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   if (sh) {
     memcpy(input, c->h_time, nt * sizeof(cf_t));
@@ -758,12 +762,11 @@ extern "C" void srsran_ofdm_tx_sf(srsran_ofdm_t* q)
   OfdmCtx*     c  = ctx_of(q);
   const size_t nt = q->sf_sz, nr = (size_t)q->nof_re * 2 * q->nof_symbols;
   memcpy(c->h_re, q->cfg.in_buffer, nr * sizeof(cf_t));
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->d_re, c->h_re, nr * sizeof(cf_t), hipMemcpyHostToDevice, c->stream));
-  if (batch_run(c->b, c->d_re, c->d_time, 1, true, true, c->stream)) {
+  // (as rx_run: the modulator reads and writes the pinned host images directly)
+  if (batch_run(c->b, reinterpret_cast<float2*>(c->h_re), reinterpret_cast<float2*>(c->h_time), 1, true, true, c->stream)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_ofdm_tx_sf: %s\n", get_error());
     return;
   }
-  PHY_HIP_CHECK_VOID(hipMemcpyAsync(c->h_time, c->d_time, nt * sizeof(cf_t), hipMemcpyDeviceToHost, c->stream));
   PHY_HIP_CHECK_VOID(hipStreamSynchronize(c->stream));
   if (q->mbsfn_subframe) {
     // the samples between the non-MBSFN and the MBSFN region are not written (ofdm.c:551-553)

@@ -787,3 +787,23 @@ def _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, sf_sz, nprb, nsc, d
                     % (n_use, chunks, bytes_in / 1e6, workers),
             "one_worker_mbit_per_s": n_use * tbs / t1 / 1e6, "h2d_alone_gb_per_s": bytes_in / th / 1e9,
             "pcie_bound_mbit_per_s": n_use * tbs / th / 1e6, "tb_crc_ok": [ok3, n_use], "payload_matches": good}
+
+
+# ------------------------------------------------------------------------------------------------ the reference's transport-block seams
+
+def leg_seam(ctx, steps=3, warmup=1, want_cpu=True):
+    """ONE transport block per call through the reference's own seams, on HOST buffers in the reference's structs -- what an unmodified
+    srsran_pusch_decode / srsran_pdsch_nr_decode reaches (decode_tb_cb, sch.c:370; srsran_dlsch_nr_decode, sch_nr.c:724): p50 / p99 of 100 calls,
+    host to host, beside the reference's own objects on one core for the same block (tools/seam_bench.py).  Latency, not throughput: `value` is
+    the LTE 16-bit block's p50 in ms."""
+    import oracle_api as O
+    import seam_bench as SB
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    lte = SB.lte_points(lib, capi, O, 100, [8.0], with_ref=want_cpu)
+    nr = SB.nr_points(lib, capi, O, 100, sigmas=(9.0,), with_ref=want_cpu)
+    p16 = [p for p in lte["points"] if p["llr"] == "int16"][0]
+    return {"metric": "one transport block per call through the reference's own seam, host to host (latency)", "value": p16["p50_ms"], "unit": "ms",
+            "higher_is_better": False, "config": {"workload": lte["what"]}, "lte": lte["points"], "nr": nr}

@@ -16,6 +16,10 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json |
 python tools/bench_handle.py > $OUT/bench_handle.json 2> $OUT/bench_handle.err &&
 python tools/bench_tti.py --out $OUT/tti.json > /dev/null 2> $OUT/tti.err &&
 ( rocprofv3 --kernel-trace --stats -d $OUT/trace_tti -o t -- python tools/bench_tti.py --calls 100 --snrs 6.0 --ntb 1,64 > /dev/null 2> $OUT/trace_tti.err; python tools/rocpd_summary.py $OUT/trace_tti > $OUT/tti_kernel_stats.txt; rm -rf $OUT/trace_tti ) &&
+python tools/seam_bench.py > $OUT/seam_time.json 2> $OUT/seam_time.err &&
+python tools/bench_ref_programs.py > $OUT/ref_programs.json 2> $OUT/ref_programs.err &&
+python tools/dbg/es_time.py 1 > $OUT/es_time.txt 2> /dev/null && python tools/dbg/es_time.py 64 >> $OUT/es_time.txt 2> /dev/null &&
+( python tools/dbg/lat_time.py 6144 0; python tools/dbg/lat_time.py 5824 1; python tools/dbg/lat_time.py 6144 0 8 ) > $OUT/lat_time.txt 2> /dev/null &&
 python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
 python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
 python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&
@@ -65,6 +69,7 @@ for V in wave pair block; do
   rm -rf $OUT/v_s $OUT/v_l
 done
 unset SRSRAN_HIP_PSS_VARIANT
+( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o roundtrip_probe roundtrip_probe.hip 2> /dev/null; ./roundtrip_probe 0 ) > $OUT/roundtrip_probe.txt 2>&1
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o acs_layout_probe acs_layout_probe.hip 2> /dev/null; ./acs_layout_probe ) > $OUT/acs_layout_probe.txt 2>&1
 cat $OUT/acs_layout_probe.txt
 echo "profile pass rc=$?"

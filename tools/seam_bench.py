@@ -5,7 +5,7 @@ one transport block of 13 code blocks (TBS 75376, 64-QAM), fresh soft buffer per
 from pinned memory)."""
 import argparse, ctypes as C, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 SB = 18600
 
@@ -19,15 +19,8 @@ class SchHead(C.Structure):
     _fields_ = [("max_iterations", C.c_uint32), ("avg_iterations", C.c_float), ("llr_is_8bit", C.c_bool)]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--calls", type=int, default=200)
-    ap.add_argument("--snrs", default="30.0,8.0,6.0")
-    a = ap.parse_args()
-    import srslte_amd as S, oracle_api as O
-    from srslte_amd import capi
-    lib = S.lib()
-    capi.check(lib.srsran_hip_set_device(0), "set_device")
+def lte_points(lib, capi, O, calls, snrs, with_ref=True):
+    """srsran_hip_decode_tb_cb (= decode_tb_cb, sch.c:370) on host buffers: TBS 75376 (13 code blocks), fresh soft buffer per call"""
     fn = lib.srsran_hip_decode_tb_cb
     fn.restype = C.c_bool
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -43,13 +36,13 @@ def main():
                       flags.ctypes.data_as(C.POINTER(C.c_bool)), False)
     data = np.zeros(tbs // 8 + 8, np.uint8)
     out = {"what": "srsran_hip_decode_tb_cb, TBS %d (%d code blocks), host buffers, fresh soft buffer per call, max 10 half iterations" % (tbs, ncb), "points": []}
-    for snr in [float(x) for x in a.snrs.split(",")]:
+    for snr in snrs:
         e16, payload = O.make_tb(tbs, Qm, G, 0, snr, np.random.default_rng(int(snr * 10)))
         for llr8 in (False, True):
             e = np.clip(np.round(e16 * (24.0 / np.mean(np.abs(e16)))), -127, 127).astype(np.int8) if llr8 else e16
             q = SchHead(10, 0.0, llr8)
             t, ok = [], 0
-            for i in range(a.calls + 10):
+            for i in range(calls + 10):
                 for r in rows:  # srsran_softbuffer_rx_reset_tbs (softbuffer.c:147-167), outside the timed region as in pusch_test.c
                     r[:] = 0
                 flags[:] = False
@@ -60,14 +53,40 @@ def main():
                     t.append(dt * 1e3)
                     ok += int(good)
             t.sort()
-            out["points"].append({"snr_knob_db": snr, "llr": "int8" if llr8 else "int16", "p50_ms": t[len(t) // 2], "p99_ms": t[int(len(t) * 0.99) - 1], "min_ms": t[0],
-                                  "ok": [ok, a.calls], "avg_half_iterations": q.avg_iterations, "payload_ok": bool(np.array_equal(data[:tbs // 8], payload[:tbs // 8]))})
-            print(json.dumps(out["points"][-1]), file=sys.stderr, flush=True)
+            p = {"snr_knob_db": snr, "llr": "int8" if llr8 else "int16", "p50_ms": t[len(t) // 2], "p99_ms": t[int(len(t) * 0.99) - 1], "min_ms": t[0],
+                 "ok": [ok, calls], "avg_half_iterations": q.avg_iterations, "payload_ok": bool(np.array_equal(data[:tbs // 8], payload[:tbs // 8]))}
+            if with_ref and O.have_ref():
+                # the reference's own rm_turbo / turbodecoder / crc objects (oracle/_ref) in the order of decode_tb_cb, one core
+                chain = O.RefSchChain(llr8, 10)
+                tr = []
+                for _ in range(8):
+                    soft, crc = chain.new_softbuffer(ncb), np.zeros(ncb, np.uint8)
+                    soft[:] = 0
+                    t0 = time.perf_counter()
+                    chain.decode_tb(tbs, Qm, 0, e, soft, crc)
+                    tr.append((time.perf_counter() - t0) * 1e3)
+                tr.sort()
+                p["reference_one_core_ms"] = tr[len(tr) // 2]
+            out["points"].append(p)
+            print(json.dumps(p), file=sys.stderr, flush=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calls", type=int, default=200)
+    ap.add_argument("--snrs", default="30.0,8.0,6.0")
+    a = ap.parse_args()
+    import srslte_amd as S, oracle_api as O
+    from srslte_amd import capi
+    lib = S.lib()
+    capi.check(lib.srsran_hip_set_device(0), "set_device")
+    out = lte_points(lib, capi, O, a.calls, [float(x) for x in a.snrs.split(",")])
     out["nr"] = nr_points(lib, capi, O, a.calls)
     print(json.dumps(out, indent=1))
 
 
-def nr_points(lib, capi, O, calls):
+def nr_points(lib, capi, O, calls, sigmas=(6.0, 9.0, 10.0), with_ref=True):
     """the NR entry point srsran_hip_sch_nr_decode_tb (= srsran_dlsch_nr_decode / srsran_ulsch_nr_decode, sch_nr.c:724-749) on host buffers: one transport
     block of 67,368 bits (8 code blocks, BG1, Z = 384, E = 12672), fresh soft buffer per call, max 10 iterations with CRC early stop; beside it the
     reference's own objects (oracle/_ref: srsran_ldpc_rm_rx_c + srsran_ldpc_decoder_decode_crc_c per code block, the decoder type its dispatch picks on
@@ -88,7 +107,7 @@ def nr_points(lib, capi, O, calls):
     payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
     e = O.sch_nr_encode_tb(cfg, 0, payload)
     pts = []
-    for sigma in (6.0, 9.0, 10.0):
+    for sigma in sigmas:
         llr = np.clip(np.round(16.0 * (1.0 - 2.0 * e) + sigma * rng.standard_normal(G)), -63, 63).astype(np.int8)
         out = np.zeros(tbs // 8, np.uint8)
         crc_ok, avg = C.c_bool(False), C.c_float(0)
@@ -108,7 +127,7 @@ def nr_points(lib, capi, O, calls):
         t.sort()
         p = {"noise_knob": sigma, "p50_ms": t[len(t) // 2], "p99_ms": t[int(len(t) * 0.99) - 1], "ok": [good, calls], "avg_iterations": avg.value,
              "payload_ok": bool(np.array_equal(out, payload))}
-        if O.have_ref():
+        if with_ref and O.have_ref():
             p["reference_one_core"] = ref_nr_tb(O, cfg, llr, 10)
         pts.append(p)
         print(json.dumps(p), file=sys.stderr, flush=True)
@@ -148,4 +167,5 @@ def ref_nr_tb(O, cfg, llr, max_iter, reps=12):
     return {"ms_per_tb_median": t[len(t) // 2], "avg_iterations": its / cfg.C, "decoder_type": "C_AVX512" if use512 else "C_AVX2"}
 
 
-main()
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,11 @@ SRSRAN_API int srsran_hip_sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_
 SRSRAN_API int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_iter, const srsran_hip_nr_tb_t* tb, const int8_t* e_bits,
                                            srsran_softbuffer_rx_t* softbuffer, uint8_t* payload, bool* crc, float* avg_iter);
 
+/* sch_nr_encode (sch_nr.c:375-520) as srsran_dlsch_nr_encode / srsran_ulsch_nr_encode (:715-741) reach it, one transport block on HOST buffers:
+ * data tbs / 8 payload bytes, e_bits one bit per byte, the code blocks' rate-matched bits back to back (G bytes).  Stateless (the reference
+ * re-encodes on every call too); the code words it parks in softbuffer.tx->buffer_b[r] are not written. */
+SRSRAN_API int srsran_hip_sch_nr_encode_tb(const srsran_hip_nr_tb_t* tb, const uint8_t* data, uint8_t* e_bits);
+
 #ifdef __cplusplus
 }
 #endif

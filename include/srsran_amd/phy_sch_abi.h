@@ -153,6 +153,19 @@ SRSRAN_API void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h);
 SRSRAN_API int  srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_data, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
                                       void* stream);
 
+/* ---- the transmit side's entry: encode_tb (sch.c:239-368) as srsran_dlsch_encode2 (:625-658) reaches it, one transport block on HOST
+ * buffers.  data: tbs / 8 payload bytes, or NULL for a retransmission of what the soft buffer holds; e_bits: byte-packed, nof_e_bits bits
+ * from bit 0 (the unused bits of the last byte as srsran_rm_turbo_tx_lut leaves them).  softbuffer (softbuffer.h:49-53): the rows keep each
+ * code block's payload slice between calls (the reference keeps its coded bits there; the contents are private to the encoder either way).
+ * tests/ref_link/tb_bind.c shows the reference-side binding. */
+typedef struct SRSRAN_API {
+  uint32_t  max_cb;
+  uint32_t  max_cb_size;
+  uint8_t** buffer_b;
+} srsran_softbuffer_tx_t;
+SRSRAN_API int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,
+                                    uint8_t* data, uint8_t* e_bits);
+
 #ifdef __cplusplus
 }
 #endif

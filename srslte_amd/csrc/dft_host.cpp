@@ -156,14 +156,14 @@ int ctx_reserve(DftCtx* c, size_t n_in, size_t n_out)
     (void)hipFree(c->d_in);
     (void)hipHostFree(c->h_in);
     PHY_HIP_CHECK(hipMalloc(&c->d_in, n_in * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipHostMalloc(&c->h_in, n_in * sizeof(cf_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(host_image_alloc(&c->h_in, n_in * sizeof(cf_t)), SRSRAN_ERROR);
     c->cap_in = n_in;
   }
   if (n_out > c->cap_out) {
     (void)hipFree(c->d_out);
     (void)hipHostFree(c->h_out);
     PHY_HIP_CHECK(hipMalloc(&c->d_out, n_out * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipHostMalloc(&c->h_out, n_out * sizeof(cf_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(host_image_alloc(&c->h_out, n_out * sizeof(cf_t)), SRSRAN_ERROR);
     c->cap_out = n_out;
   }
   return SRSRAN_SUCCESS;

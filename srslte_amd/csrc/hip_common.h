@@ -57,6 +57,19 @@ inline hipError_t upload(void* dst, const void* src, size_t bytes)
   return e != hipSuccess ? e : hipDeviceSynchronize();
 }
 
+// Host memory that kernels read and write THEMSELVES (single-call staging images, job lists and verdicts of small calls): pinned, mapped into
+// the device's address space and explicitly coherent (fine-grained) -- what the host wrote before a launch is what the kernel reads, what a
+// kernel wrote is what the host reads after the stream's wait, whatever HIP_HOST_COHERENT says about the default.
+inline hipError_t host_image_alloc(void** p, size_t bytes)
+{
+  return hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+}
+template <class T>
+inline hipError_t host_image_alloc(T** p, size_t bytes)
+{
+  return host_image_alloc(reinterpret_cast<void**>(p), bytes);
+}
+
 // development knobs: launch-shape alternatives kept in the tree for measurement (profiles/r02_turbo_variants.txt, r02_pss_variants.txt) and a few
 // sizing overrides.  The environment variable of a knob is read ONCE (first use); srsran_hip_dev_knob() overrides a knob at run time,
 // which is how tests/test_gpu_variants.py switches kernels inside one process.  -1 = not set.

@@ -148,7 +148,7 @@ struct Stage {
     (void)hipHostFree(*p);
     *p   = nullptr;
     *cap = 0;
-    if (hipHostMalloc(p, need + need / 2 + 256) != hipSuccess) {
+    if (host_image_alloc(p, need + need / 2 + 256) != hipSuccess) {
       return false;
     }
     *cap = need + need / 2 + 256;

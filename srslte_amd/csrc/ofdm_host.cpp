@@ -559,14 +559,14 @@ int ctx_sync(srsran_ofdm_t* q)
     (void)hipFree(c->d_time);
     (void)hipHostFree(c->h_time);
     PHY_HIP_CHECK(hipMalloc(&c->d_time, nt * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipHostMalloc(&c->h_time, nt * sizeof(cf_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(host_image_alloc(&c->h_time, nt * sizeof(cf_t)), SRSRAN_ERROR);
     c->cap_time = nt;
   }
   if (nr > c->cap_re) {
     (void)hipFree(c->d_re);
     (void)hipHostFree(c->h_re);
     PHY_HIP_CHECK(hipMalloc(&c->d_re, nr * sizeof(float2)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipHostMalloc(&c->h_re, nr * sizeof(cf_t)), SRSRAN_ERROR);
+    PHY_HIP_CHECK(host_image_alloc(&c->h_re, nr * sizeof(cf_t)), SRSRAN_ERROR);
     c->cap_re = nr;
   }
   return SRSRAN_SUCCESS;

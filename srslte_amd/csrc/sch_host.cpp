@@ -250,7 +250,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
     h->d_scratch = h->h_scratch = nullptr;
     h->scratch_cap               = 0;
     PHY_HIP_CHECK(hipMalloc(&h->d_scratch, bytes), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipHostMalloc(&h->h_scratch, bytes), SRSRAN_ERROR);
+    PHY_HIP_CHECK(host_image_alloc(&h->h_scratch, bytes), SRSRAN_ERROR);
     h->scratch_cap = bytes;
   }
   uint8_t* hb   = static_cast<uint8_t*>(h->h_scratch);
@@ -481,7 +481,7 @@ struct TbStage {
     (void)hipHostFree(pin);
     dev = pin = nullptr;
     cap = 0;
-    if (hipMalloc((void**)&dev, need) != hipSuccess || hipHostMalloc((void**)&pin, need) != hipSuccess) {
+    if (hipMalloc((void**)&dev, need) != hipSuccess || host_image_alloc(&pin, need) != hipSuccess) {
       return false;
     }
     cap = need;

@@ -133,7 +133,7 @@ bool ensure(T** d, T** h, size_t* cap, size_t n)
   (void)hipHostFree(*h);
   *d = nullptr, *h = nullptr, *cap = 0;
   const size_t c = n + n / 2 + 16;
-  if (hipMalloc(d, c * sizeof(T)) != hipSuccess || hipHostMalloc(h, c * sizeof(T)) != hipSuccess) {
+  if (hipMalloc(d, c * sizeof(T)) != hipSuccess || host_image_alloc(h, c * sizeof(T)) != hipSuccess) {
     return false;
   }
   *cap = c;
@@ -201,7 +201,7 @@ extern "C" int srsran_hip_sch_nr_create(srsran_hip_sch_nr_t** hh, float scaling_
   h->max_iter = max_nof_iter ? max_nof_iter : 10;                  // ldpc_decoder.c:42,579
   h->max_cb   = max_cb;
   if (srsran_hip_nr_sch_create(&h->rm) != SRSRAN_SUCCESS || hipMalloc(&h->d_msg, (size_t)max_cb * MSG_STRIDE) != hipSuccess ||
-      hipMalloc(&h->d_flags, max_cb) != hipSuccess || hipHostMalloc(&h->h_flags, max_cb) != hipSuccess) {
+      hipMalloc(&h->d_flags, max_cb) != hipSuccess || host_image_alloc(&h->h_flags, max_cb) != hipSuccess) {
     srsran_hip_sch_nr_free(h);
     return SRSRAN_ERROR;
   }
@@ -575,7 +575,7 @@ struct NrTbStage {
     (void)hipHostFree(pin);
     dev = pin = nullptr;
     cap = 0;
-    if (hipMalloc((void**)&dev, need) != hipSuccess || hipHostMalloc((void**)&pin, need) != hipSuccess) {
+    if (hipMalloc((void**)&dev, need) != hipSuccess || host_image_alloc(&pin, need) != hipSuccess) {
       return false;
     }
     cap = need;
@@ -839,5 +839,51 @@ extern "C" int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d
     }
     i = e;
   }
+  return SRSRAN_SUCCESS;
+}
+
+// sch_nr_encode (sch_nr.c:375-520) as srsran_dlsch_nr_encode / srsran_ulsch_nr_encode (:715-741) reach it, for ONE transport block on the caller's
+// HOST buffers: payload bytes in, rate-matched bits (one per byte) of every code block out, back to back.  Stateless: the code words the
+// reference parks in softbuffer.tx->buffer_b[r] (it re-encodes on every call as well, :434-470) are not written.
+extern "C" int srsran_hip_sch_nr_encode_tb(const srsran_hip_nr_tb_t* tb_in, const uint8_t* data, uint8_t* e_bits)
+{
+  if (!tb_in || !data || !e_bits) {
+    return SRSRAN_ERROR_INVALID_INPUTS; // sch_nr.c:381-383
+  }
+  TbCfg c;
+  if (!tb_cfg(*tb_in, &c) || c.C > NrTbStage::MAX_CB) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr encode: invalid transport block (tbs %u, mod %u, layers %u)\n", tb_in->tbs, tb_in->mod, tb_in->N_L);
+    return SRSRAN_ERROR;
+  }
+  static thread_local NrTbStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr encode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  srsran_hip_sch_nr_t* h = s.decoder(0.8f, 10); // (the transmit side has no decoder parameters: one object per thread)
+  if (!h) {
+    return SRSRAN_ERROR;
+  }
+  size_t n_e = 0;
+  for (uint32_t r = 0; r < c.C; r++) {
+    n_e += get_E(c, r);
+  }
+  auto         al    = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_pay = 0, o_e = al(o_pay + c.A / 8 + 8);
+  if (!s.grow(al(o_e + n_e))) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr encode: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  memcpy(s.pin + o_pay, data, c.A / 8);
+  srsran_hip_nr_tb_t tb = *tb_in;
+  tb.rv &= 3u;
+  tb.e_offset = tb.payload_offset = tb.first_cb = 0;
+  // the kernels read the payload from, and the rate matcher writes the bits into, the pinned host image itself (read twice, written once)
+  if (srsran_hip_sch_nr_encode(h, s.pin + o_pay, &tb, 1, s.pin + o_e, s.st) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] sch_nr encode: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  memcpy(e_bits, s.pin + o_e, n_e);
   return SRSRAN_SUCCESS;
 }

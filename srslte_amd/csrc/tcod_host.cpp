@@ -457,3 +457,159 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   h->pending = true;
   return SRSRAN_SUCCESS;
 }
+
+// ------------------------------------------------------------------------------------------------ the reference's transmit-side entry
+//
+// encode_tb (sch.c:239-368) as srsran_dlsch_encode2 (:625-658) reaches it, for ONE transport block on the caller's HOST buffers: payload bytes
+// in, byte-packed rate-matched bits out.  The reference keeps every code block's coded bits in softbuffer->buffer_b[i] so that a call with
+// data == NULL (a retransmission) only rate-matches again; here the rows keep the block's PAYLOAD slice instead (their contents are private
+// to the encoder either way) and such a call encodes again from them.
+namespace {
+struct TxTbStage {
+  hipStream_t           st  = nullptr;
+  srsran_hip_sch_enc_t* enc = nullptr;
+  uint8_t*              pin = nullptr; // pinned, device-visible image: [payload | e bits]
+  uint8_t*              dev = nullptr; // e bits on the device (the code blocks OR their partial bytes into them: not a job for host memory)
+  size_t                cap = 0;
+  bool                  tried = false;
+  ~TxTbStage()
+  {
+    srsran_hip_sch_enc_free(enc);
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    if (st) {
+      (void)hipStreamDestroy(st);
+    }
+  }
+  bool ready()
+  {
+    if (!tried) {
+      tried = true;
+      if (device_available()) {
+        bind_thread();
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+          st = nullptr;
+        } else if (srsran_hip_sch_enc_create(&enc) != SRSRAN_SUCCESS) {
+          (void)hipStreamDestroy(st);
+          st = nullptr;
+        }
+      }
+    }
+    return st != nullptr;
+  }
+  bool grow(size_t need)
+  {
+    if (need <= cap) {
+      return true;
+    }
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+    dev = pin = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&dev, need) != hipSuccess || host_image_alloc(&pin, need) != hipSuccess) {
+      return false;
+    }
+    cap = need;
+    return true;
+  }
+};
+} // namespace
+
+extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,
+                                    uint8_t* data, uint8_t* e_bits)
+{
+  if (!e_bits || !cb_segm || !softbuffer) {
+    fprintf(stderr, "Invalid parameters: e_bits=%d, cb_segm=%d, softbuffer=%d\n", e_bits != 0, cb_segm != 0, softbuffer != 0); // sch.c:351
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (cb_segm->F) {
+    fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // :254-257
+    return SRSRAN_ERROR;
+  }
+  if (cb_segm->C > softbuffer->max_cb) {
+    fprintf(stderr, "Error number of CB to encode (%d) exceeds soft buffer size (%d CBs)\n", cb_segm->C, softbuffer->max_cb); // :259-262
+    return SRSRAN_ERROR;
+  }
+  if (Qm == 0 || rv > 3) {
+    fprintf(stderr, "Invalid Qm\n"); // :264-267
+    return SRSRAN_ERROR;
+  }
+  const uint32_t C = cb_segm->C, tbs = cb_segm->tbs;
+  if (C == 0 || tbs == 0 || nof_e_bits == 0) {
+    return SRSRAN_SUCCESS; // the loop over code blocks does not run
+  }
+  static thread_local TxTbStage s;
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  auto         al    = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t n_out = (nof_e_bits + 7) / 8;
+  const size_t o_pay = 0, o_e = al(o_pay + tbs / 8 + 8);
+  if (!s.grow(al(o_e + n_out + 8))) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  // payload slices of the code blocks in the transmit side's order (the C2 smaller blocks first, sch.c:284-290)
+  uint32_t rp = 0;
+  for (uint32_t i = 0; i < C; i++) {
+    const uint32_t K    = i < cb_segm->C2 ? cb_segm->K2 : cb_segm->K1;
+    const uint32_t rlen = C > 1 ? K - 24 : K;
+    const uint32_t nb   = (i + 1 == C ? rlen - 24 : rlen) / 8; // the last block ends with the transport-block CRC, which is not payload
+    if (!softbuffer->buffer_b[i]) {
+      return SRSRAN_ERROR;
+    }
+    if (data) {
+      memcpy(softbuffer->buffer_b[i], data + rp / 8, nb);
+    }
+    memcpy(s.pin + o_pay + rp / 8, softbuffer->buffer_b[i], nb);
+    rp += 8 * nb;
+  }
+  if (rp != tbs) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: segmentation does not add up to the transport block size (%u != %u)\n", rp, tbs);
+    return SRSRAN_ERROR;
+  }
+  const srsran_hip_tb_t tb = {tbs, Qm, rv, nof_e_bits, 0, 0, 0};
+  if (srsran_hip_sch_encode(s.enc, s.pin + o_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(hipMemcpyAsync(s.pin + o_e, s.dev, n_out, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);
+  // The unused low bits of the last byte: srsran_rm_turbo_tx_lut copies every block's circular buffer piece by piece with srsran_bit_copy
+  // (rm_turbo.c:362-374), which ZEROES the rest of a piece's last byte when the piece starts byte aligned on both sides and preserves it
+  // otherwise (bit.c:685-698): replay the pieces of the last code block for the byte the transport block ends in.
+  const uint32_t tail = nof_e_bits & 7u;
+  uint8_t        keep = 0;
+  if (tail) {
+    const uint32_t Gp = nof_e_bits / Qm, gamma = Gp % C;
+    const uint32_t K  = C - 1 < cb_segm->C2 ? cb_segm->K2 : cb_segm->K1;
+    const uint32_t E  = Qm * (Gp / C) + ((C - 1 <= C - gamma - 1) ? 0u : Qm);
+    const uint32_t wp = nof_e_bits - E, in_len = 3 * K + 12;
+    bool           zeroed = false;
+    uint32_t       w_len = 0, r_ptr = rm::tx_start_index(K, rv);
+    while (w_len < E) {
+      uint32_t cp = E - w_len;
+      if (cp + r_ptr >= in_len) {
+        cp = in_len - r_ptr;
+      }
+      const uint32_t d0 = wp + w_len;
+      if (((d0 + cp) >> 3) == (nof_e_bits >> 3)) {
+        if ((d0 & 7u) == 0 && (r_ptr & 7u) == 0 && (cp & 7u)) {
+          zeroed = true;
+        }
+      }
+      r_ptr += cp;
+      if (r_ptr >= in_len) {
+        r_ptr -= in_len;
+      }
+      w_len += cp;
+    }
+    keep = zeroed ? 0 : (uint8_t)(e_bits[n_out - 1] & (0xffu >> tail));
+  }
+  memcpy(e_bits, s.pin + o_e, n_out);
+  if (tail) {
+    e_bits[n_out - 1] = (uint8_t)((e_bits[n_out - 1] & (0xff00u >> tail)) | keep);
+  }
+  return SRSRAN_SUCCESS;
+}

@@ -1,8 +1,8 @@
 /* tests/ref_link/nr_bind.c -- the reference-side binding of the NR transport-block entry points.
  *
  * Compiled against the REFERENCE's headers, like any file a maintainer adds to lib/src/phy/phch.  The reference's sch_nr.c is compiled
- * unmodified; its definitions of srsran_dlsch_nr_decode / srsran_ulsch_nr_decode (sch_nr.c:724-749, one-line wrappers of the static
- * sch_nr_decode) are made weak symbols in the object file (objcopy --weaken-symbol, tests/ref_link/Makefile) and these take their place:
+ * unmodified; its definitions of srsran_dlsch_nr_decode / srsran_ulsch_nr_decode and srsran_dlsch_nr_encode / srsran_ulsch_nr_encode
+ * (sch_nr.c:715-749, one-line wrappers of the static sch_nr_decode / sch_nr_encode) are made weak symbols in the object file (objcopy --weaken-symbol, tests/ref_link/Makefile) and these take their place:
  * a transport block that srsran_pdsch_nr_decode / srsran_pusch_nr_decode hand over goes to the device as ONE call instead of a rate
  * de-matching call and a decoder call per code block.  Everything else of sch_nr.c stays the reference's: object set-up, carrier,
  * srsran_sch_nr_fill_tb_info (whose Nref comes from the reference's resource-allocation code), the transmit side. */
@@ -25,6 +25,31 @@ extern int srsran_hip_sch_nr_decode_tb(float                     scaling_fctr,
                                        uint8_t*                  payload,
                                        bool*                     crc,
                                        float*                    avg_iter);
+
+extern int srsran_hip_sch_nr_encode_tb(const srsran_hip_nr_tb_t* tb, const uint8_t* data, uint8_t* e_bits);
+
+static int encode_on_device(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, const uint8_t* data, uint8_t* e_bits)
+{
+  if (!q || !sch_cfg || !tb || !data || !e_bits) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  srsran_sch_nr_tb_info_t cfg = {};
+  if (srsran_sch_nr_fill_tb_info(&q->carrier, sch_cfg, tb, &cfg) < SRSRAN_SUCCESS) {
+    return SRSRAN_ERROR;
+  }
+  srsran_hip_nr_tb_t d = {.R = tb->R, .tbs = (uint32_t)tb->tbs, .mod = (uint32_t)tb->mod, .rv = (uint32_t)tb->rv, .N_L = tb->N_L, .nof_bits = tb->nof_bits, .Nref = cfg.Nref};
+  return srsran_hip_sch_nr_encode_tb(&d, data, e_bits);
+}
+
+int srsran_dlsch_nr_encode(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, const uint8_t* data, uint8_t* e_bits)
+{
+  return encode_on_device(q, sch_cfg, tb, data, e_bits);
+}
+
+int srsran_ulsch_nr_encode(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, const uint8_t* data, uint8_t* e_bits)
+{
+  return encode_on_device(q, sch_cfg, tb, data, e_bits);
+}
 
 static int decode_on_device(srsran_sch_nr_t* q, const srsran_sch_cfg_t* sch_cfg, const srsran_sch_tb_t* tb, int8_t* e_bits, srsran_sch_tb_res_nr_t* res)
 {

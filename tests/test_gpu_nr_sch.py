@@ -452,3 +452,27 @@ def test_transport_block_entry_point_on_the_reference_structs(hiplib):
     assert fn(0.8, 6, None, O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) < 0
     sb.max_cb = 0
     assert fn(0.8, 6, C.byref(tb), O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) < 0
+
+
+def test_transmit_entry_point_on_host_buffers(hiplib):
+    """srsran_hip_sch_nr_encode_tb = sch_nr_encode (sch_nr.c:375-520) as srsran_dlsch_nr_encode / srsran_ulsch_nr_encode reach it, host buffers:
+    equal to the oracle's loop for every redundancy version of a 21-block transport block (two sizes of E, two layers, limited buffer) and for
+    a single CRC16 block on base graph 2"""
+    from srslte_amd import capi
+
+    fn = hiplib.srsran_hip_sch_nr_encode_tb
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for tbs, R, mod, Nl, G, Nref in ((176208, 0.8, 3, 2, 12 * 19003, 20000), (1032, 0.4, 1, 1, 2600, 0), (67368, 0.67, 4, 1, 8 * 12672, 0)):
+        cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, Nref)
+        if not Nref:
+            cfg.Nref = (66 if cfg.bg == 0 else 50) * cfg.Z
+        payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+        for rv in range(4):
+            e = O.sch_nr_encode_tb(cfg, rv, payload)
+            out = np.full(e.size + 32, 7, np.uint8)
+            tb = capi.HipNrTb(R, tbs, mod, rv, Nl, G, Nref, 0, 0, 0, 0)
+            assert fn(C.byref(tb), O.P(payload), O.P(out)) == 0
+            assert np.array_equal(out[:e.size], e) and np.all(out[e.size:] == 7), (tbs, rv)
+    assert fn(None, O.P(payload), O.P(out)) < 0

@@ -27,6 +27,9 @@ CASES = [
     ("pusch_test", ["-n", "25", "-L", "25", "-m", "14", "-s", "40"], "PUSCH 25 PRB, MCS 14"),
     ("pusch_test", ["-n", "6", "-L", "6", "-m", "0", "-s", "40"], "PUSCH 6 PRB, MCS 0 (one small code block)"),
     ("pdsch_test", ["-n", "100", "-m", "28", "-X", "1"], "PDSCH 100 PRB, MCS 28: ONE cold decode (first call of the process)"),
+    # the transmit side: pdsch_test encodes the block -X times for real (pdsch_test.c:421-436) -- us_per_encode; its decode figure of such a run is void (above)
+    ("pdsch_test", ["-n", "100", "-m", "28", "-X", "50"], "PDSCH 100 PRB, MCS 28: srsran_pdsch_encode x 50 (us_per_encode; the decode figure of this run is void)"),
+    ("pdsch_test", ["-n", "25", "-m", "20", "-X", "50"], "PDSCH 25 PRB, MCS 20: srsran_pdsch_encode x 50 (us_per_encode)"),
 ]
 
 
@@ -41,6 +44,9 @@ def run(kind, prog, args):
     m = re.search(r"DECODED (\w+) in ([0-9.]+) \(PHY bitrate=([0-9.]+) Mbps\. Processing bitrate=([0-9.]+) Mbps\)", out)
     if m:  # pdsch_test: microseconds per srsran_pdsch_decode, averaged by the program over its -X repetitions
         res.update(ok=m.group(1) == "OK", us_per_decode=float(m.group(2)), mbps=float(m.group(4)))
+    m = re.search(r"ENCODED in ([0-9.]+) \(PHY bitrate=([0-9.]+) Mbps\. Processing bitrate=([0-9.]+) Mbps\)", out)
+    if m:
+        res.update(us_per_encode=float(m.group(1)))
     m = re.search(r"Decoded Rate: ([0-9.]+) Mbps", out)
     if m:  # pusch_test: bits over the summed decode times of its subframes; the first subframe of a process pays the one-time set-up
         per = [float(x) for x in re.findall(r"Processing: ([0-9.]+) Mbps", out)]

@@ -596,8 +596,17 @@ extern "C" bool srsran_hip_decode_tb_cb(void* qv, srsran_softbuffer_rx_t* softbu
       return false;
     }
   }
+  if (first < 0) {
+    // every code block was decoded in an earlier round (not a state the reference's callers produce: they reset a decoded block's soft buffer):
+    // nothing to launch, the stored bytes are the block (sch.c:466-471), no iteration is counted
+    for (uint32_t i = 0; i < C; i++) {
+      memcpy(&data[(size_t)i * rbytes[i]], softbuffer->data[i], rbytes[i]);
+    }
+    softbuffer->tb_crc = true;
+    return true;
+  }
   // the decoded bytes come back in front of the call's one host wait; the combined soft bits only when a block failed (second wait, below)
-  const TailCopy tail[1] = {{s.pin + o_data, s.dev + o_data, first >= 0 ? n_data : 0}};
+  const TailCopy tail[1] = {{s.pin + o_data, s.dev + o_data, n_data}};
   const int rc = sch_decode(s.sch, s.pin + o_e, &tb, 1, q->max_iterations ? q->max_iterations : 1, s.dev + o_soft, flags, s.dev + o_data, &res, s.st, llr8, tail, 1);
   if (rc != SRSRAN_SUCCESS) {
     fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());

@@ -398,6 +398,14 @@ def test_decode_tb_cb_on_the_reference_structs(hiplib, llr8):
     assert ok and ret2 == 0 and sb.tb_crc and np.all(flags[:s["C"]]) and abs(q.avg_iterations - o_avg2) < 1e-6
     assert np.array_equal(data2[:tbs // 8 + 3], payload) and np.array_equal(data2[:tbs // 8 + 3], o_data2[:tbs // 8 + 3])
     assert bytes(q.guard) == bytes([0xA5] * 64)
+    # every code block decoded already (the reference's callers reset such a buffer first; its loop would only copy the stored blocks, :466-471)
+    # -- decode_tb_cb then copies the STORED blocks, which were only kept while the block failed (:476): same bytes as the oracle's loop
+    data3 = np.full(tbs // 8 + 6, 0x22, np.uint8)
+    assert fn(C.byref(q), C.byref(sb), C.byref(cs), Qm, 2, G, O.P(e2), O.P(data3)) and sb.tb_crc and q.avg_iterations == 0.0
+    _, o_data3, _ = O.sch_decode_tb(tbs, Qm, 2, e2, o_soft, o_crc, 6, o_keep)
+    rl = [((s["K1"] if c < s["C1"] else s["K2"]) - 24) // 8 for c in range(s["C"])]
+    for c in range(s["C"]):
+        assert np.array_equal(data3[sum(rl[:c]):sum(rl[:c + 1])], o_data3[sum(rl[:c]):sum(rl[:c + 1])]), c
     # ---- srsran_softbuffer_rx_reset (rows and flags zero), then the 13-block grant of the uplink configuration, first transmission decodes
     for r in rows:
         r[:] = 0

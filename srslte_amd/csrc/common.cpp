@@ -28,6 +28,16 @@ const char* get_error()
 
 namespace {
 std::atomic<int> g_device{-1}; // -1: never chosen, every thread stays where HIP put it
+
+// The reference's threading model is one PHY worker per in-flight subframe, and every worker's handles and staging contexts own a stream.  The
+// runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and streams that share a queue run
+// their work one behind the other: three workers decoding a transport block each then take 249 us per call instead of 142, with eight queues
+// 146 (tools/probe/seam_threads.c, profiles/r03_seam_threads.txt).  Ask for eight -- before the runtime reads its settings at the process's
+// first HIP call, and only if the application or the user has not chosen a value.
+__attribute__((constructor)) void more_hardware_queues()
+{
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
 }
 
 void bind_thread()

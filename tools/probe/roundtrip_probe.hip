@@ -39,6 +39,64 @@ static void timeit(const char* what, F f, int reps = 400)
   printf("  %-78s p50 %7.1f us   p99 %7.1f us   min %7.1f us\n", what, t[t.size() / 2], t[(size_t)(t.size() * 0.99) - 1], t[0]);
 }
 
+// a kernel that lasts about `us` microseconds (one small workgroup spinning on the clock): the host wait of N concurrent callers, each with its own
+// stream, by hipStreamSynchronize and by polling hipStreamQuery -- does a caller's wait get longer when other threads wait too?
+__global__ void spin_us(long long cycles, int* out)
+{
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) {
+  }
+  if (out) {
+    out[0] = 1;
+  }
+}
+
+#include <atomic>
+#include <thread>
+static void threaded(int n_threads, bool poll)
+{
+  std::vector<std::vector<double>> lat(n_threads);
+  std::atomic<int>                 ready{0};
+  auto work = [&](int t) {
+    hipStream_t st;
+    hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    int* d;
+    hipMalloc(&d, 64);
+    ready++;
+    while (ready.load() < n_threads) {
+    }
+    for (int i = 0; i < 320; i++) {
+      const double t0 = now_us();
+      hipLaunchKernelGGL(spin_us, dim3(13), dim3(64), 0, st, 100LL * 100, d); // wall_clock64 ticks at 100 MHz: 100 us
+      if (poll) {
+        while (hipStreamQuery(st) == hipErrorNotReady) {
+        }
+      } else {
+        hipStreamSynchronize(st);
+      }
+      if (i >= 20) {
+        lat[t].push_back(now_us() - t0);
+      }
+    }
+    hipFree(d);
+    hipStreamDestroy(st);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++) {
+    th.emplace_back(work, t);
+  }
+  for (auto& x : th) {
+    x.join();
+  }
+  std::vector<double> all;
+  for (auto& l : lat) {
+    all.insert(all.end(), l.begin(), l.end());
+  }
+  std::sort(all.begin(), all.end());
+  printf("  %d thread(s), a 100 us kernel each per call, wait by %-22s p50 %7.1f us   p99 %7.1f us\n", n_threads, poll ? "hipStreamQuery polling:" : "hipStreamSynchronize:", all[all.size() / 2],
+         all[(size_t)(all.size() * 0.99) - 1]);
+}
+
 int main(int argc, char** argv)
 {
   unsigned flags = argc > 1 ? (unsigned)atoi(argv[1]) : 0;
@@ -80,5 +138,9 @@ int main(int argc, char** argv)
   }
   timeit("four kernels back to back + sync", [&] { for (int k = 0; k < 4; k++) launch(small); hipStreamSynchronize(st); });
   timeit("hipMemsetAsync + kernel + sync", [&] { hipMemsetAsync(d_out, 0, small, st); launch(small); hipStreamSynchronize(st); });
+  for (int n : {1, 3, 8}) {
+    threaded(n, false);
+    threaded(n, true);
+  }
   return 0;
 }

@@ -72,54 +72,6 @@ def lte_points(lib, capi, O, calls, snrs, with_ref=True):
     return out
 
 
-def lte_concurrent(lib, capi, O, calls, threads, snr=8.0):
-    """the reference's threading model: `threads` PHY workers (srsenb: nof_phy_threads = 3), each with its own srsran_sch_t / soft buffer, each decoding one
-    transport block per call through the seam at the same time (own stream and staging per thread inside the library)"""
-    import threading
-    fn = lib.srsran_hip_decode_tb_cb
-    fn.restype = C.c_bool
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
-    tbs, Qm, G = 75376, 6, 100800
-    ncb = O.cbsegm(tbs)["C"]
-    cs = capi.Cbsegm()
-    assert lib.srsran_cbsegm(C.byref(cs), tbs) == 0
-    e16, payload = O.make_tb(tbs, Qm, G, 0, snr, np.random.default_rng(int(snr * 10)))
-    lat, oks = [[] for _ in range(threads)], [0] * threads
-    start = threading.Barrier(threads)
-
-    def work(t):
-        rows = [np.zeros(SB, np.int16) for _ in range(ncb)]
-        keep = [np.zeros(SB // 8, np.uint8) for _ in range(ncb)]
-        flags = np.zeros(ncb, np.bool_)
-        sb = SoftbufferRx(ncb, SB, (C.c_void_p * ncb)(*[r.ctypes.data for r in rows]), (C.c_void_p * ncb)(*[k.ctypes.data for k in keep]),
-                          flags.ctypes.data_as(C.POINTER(C.c_bool)), False)
-        data = np.zeros(tbs // 8 + 8, np.uint8)
-        q = SchHead(10, 0.0, False)
-        e = e16.copy()
-        start.wait()
-        args = (C.byref(q), C.byref(sb), C.byref(cs), Qm, 0, G, e.ctypes.data, data.ctypes.data)
-        for i in range(calls + 10):
-            # (every block decodes at this operating point, so the rows stay as the reset left them -- decoded blocks' rows are not written back -- and
-            # only the flags need clearing: the threads share the interpreter lock, anything done under it shows up in the others' timings)
-            flags[:] = False
-            t0 = time.perf_counter()
-            good = fn(*args)
-            dt = time.perf_counter() - t0
-            if i >= 10:
-                lat[t].append(dt * 1e3)
-                oks[t] += int(good)
-        oks[t] = oks[t] if np.array_equal(data[:tbs // 8], payload[:tbs // 8]) else 0
-
-    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    t0 = time.perf_counter()
-    [x.start() for x in th]
-    [x.join() for x in th]
-    wall = time.perf_counter() - t0
-    allv = sorted(v for l in lat for v in l)
-    return {"threads": threads, "snr_knob_db": snr, "p50_ms": allv[len(allv) // 2], "p99_ms": allv[int(len(allv) * 0.99) - 1], "ok": [sum(oks), threads * calls],
-            "blocks_per_s_all_threads": threads * (calls + 10) / wall}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=200)
@@ -131,9 +83,7 @@ def main():
     capi.check(lib.srsran_hip_set_device(0), "set_device")
     out = lte_points(lib, capi, O, a.calls, [float(x) for x in a.snrs.split(",")])
     out["nr"] = nr_points(lib, capi, O, a.calls)
-    out["concurrent_workers"] = [lte_concurrent(lib, capi, O, a.calls, n) for n in (1, 3, 8)]
-    for c in out["concurrent_workers"]:
-        print(json.dumps(c), file=sys.stderr, flush=True)
+    # (several worker threads at once: tools/probe/seam_threads.c -- threads of this interpreter share its lock, and a call's return waits for it)
     print(json.dumps(out, indent=1))
 
 

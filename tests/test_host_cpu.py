@@ -243,3 +243,25 @@ def test_product_never_touches_the_oracle():
                         if re.search(r'import oracle|oracle/lib|liboracle|#include "../oracle|orc_[a-z]+\(', txt):
                             bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_transport_block_seams_are_bound_in_the_reference_programs():
+    """tests/ref_link `make tb`: in the reference's unmodified sch.o / sch_nr.o the seam symbols are WEAK definitions, and the linked programs call the
+    library's entry points through the bindings (static facts of the build, no GPU needed; the programs themselves run in tests/test_gpu_ref_ctest.py)"""
+    build = os.path.join(ROOT, "tests", "ref_link", "_build")
+    weak = {"sch_weak.o": {"decode_tb_cb", "srsran_dlsch_encode2"},
+            "sch_nr_weak.o": {"srsran_dlsch_nr_decode", "srsran_ulsch_nr_decode", "srsran_dlsch_nr_encode", "srsran_ulsch_nr_encode"}}
+    if not os.path.exists(os.path.join(build, "bin_tb", "pusch_test")):
+        pytest.skip("tests/ref_link/_build/bin_tb not built (needs the reference tree: dev container)")
+    for obj, names in weak.items():
+        p = os.path.join(build, "obj", "tb", obj)
+        if os.path.exists(p):  # (objects stay in the dev container's tree; the programs travel)
+            syms = dict((ln.split()[-1], ln.split()[-2]) for ln in subprocess.check_output(["nm", p], text=True).splitlines() if len(ln.split()) >= 3)
+            assert all(syms.get(n) == "W" for n in names), (obj, {n: syms.get(n) for n in names})
+    und = lambda prog: {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(build, "bin_tb", prog)], text=True).splitlines()}
+    lte, nr = und("pusch_test"), und("pdsch_nr_test")
+    assert {"srsran_hip_decode_tb_cb", "srsran_hip_encode_tb"} <= lte, sorted(n for n in lte if "hip" in n)
+    assert {"srsran_hip_sch_nr_decode_tb", "srsran_hip_sch_nr_encode_tb"} <= nr, sorted(n for n in nr if "hip" in n)
+    # the plain link set of the same program binds the per-code-block entry points instead
+    full = {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(build, "bin_full", "pusch_test")], text=True).splitlines()}
+    assert "srsran_hip_decode_tb_cb" not in full and "srsran_tdec_iteration" in full

@@ -546,7 +546,8 @@ extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_c
   auto         al    = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t n_out = (nof_e_bits + 7) / 8;
   const size_t o_pay = 0, o_e = al(o_pay + tbs / 8 + 8);
-  if (!s.grow(al(o_e + n_out + 8))) {
+  const size_t d_pay = al(n_out + 8); // device image: [e bits | payload]
+  if (!s.grow(al(o_e + n_out + 8) + 512)) {
     fprintf(stderr, "[srsran_phy_hip] encode_tb: staging allocation failed\n");
     return SRSRAN_ERROR;
   }
@@ -570,7 +571,9 @@ extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_c
     return SRSRAN_ERROR;
   }
   const srsran_hip_tb_t tb = {tbs, Qm, rv, nof_e_bits, 0, 0, 0};
-  if (srsran_hip_sch_encode(s.enc, s.pin + o_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
+  // (the payload goes up with a copy operation: the CRC and encoder kernels read it byte-wise and more than once, which is slow across the bus)
+  PHY_HIP_CHECK(hipMemcpyAsync(s.dev + d_pay, s.pin + o_pay, tbs / 8, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  if (srsran_hip_sch_encode(s.enc, s.dev + d_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
     fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
     return SRSRAN_ERROR;
   }

@@ -423,6 +423,26 @@ def test_decode_tb_cb_on_the_reference_structs(hiplib, llr8):
     ret, o_data, o_avg = O.sch_decode_tb(tbs, Qm, 0, e, o_soft, o_crc, 8)
     assert ok and ret == 0 and np.all(flags) and abs(q.avg_iterations - o_avg) < 1e-6 and q.avg_iterations < 8
     assert np.array_equal(data, o_data) and np.array_equal(data[:tbs // 8 + 3], payload)
+    # ---- single-block transport blocks: CRC24A on the block itself (sch.c:432-438); K <= 400 goes to the scalar decoder (turbodecoder.c:381-408)
+    for tbs, Qm, G, snr_db in ((4584, 2, 9000, 3.0), (936, 2, 2400, 3.0), (152, 2, 600, 4.0), (16, 2, 144, 5.0), (4584, 2, 5200, -2.0)):
+        s = O.cbsegm(tbs)
+        assert s["C"] == 1
+        sb, rows, keep, flags = _host_softbuffer(2, dt)
+        e, payload = O.make_tb(tbs, Qm, G, 0, snr_db, np.random.default_rng(tbs))
+        e = q8(e)
+        cs = seg_struct(tbs)
+        data = np.zeros(tbs // 8 + 6, np.uint8)
+        q.max_iterations = 5
+        ok = fn(C.byref(q), C.byref(sb), C.byref(cs), Qm, 0, G, O.P(e), O.P(data))
+        o_soft, o_crc = np.zeros((1, SB), dt), np.zeros(1, np.uint8)
+        ret, o_data, o_avg = O.sch_decode_tb(tbs, Qm, 0, e, o_soft, o_crc, 5)
+        assert bool(ok) == bool(o_crc[0]) and bool(flags[0]) == bool(o_crc[0]) and abs(q.avg_iterations - o_avg) < 1e-6, (tbs, G, ok, o_crc, q.avg_iterations, o_avg)
+        K = s["K1"]
+        assert np.array_equal(data[:K // 8], o_data[:K // 8]), (tbs, G)
+        if not o_crc[0]:
+            n = 3 * (K + 32) + 12 if K > 400 else 3 * K + 12
+            got, want = views(rows)[0][:n], o_soft[0][:n]
+            assert np.array_equal(_mask_tail_slots(got, K) if K > 400 else got, _mask_tail_slots(want, K) if K > 400 else want), (tbs, G)
     # bad arguments fail loudly, nothing is written
     assert not fn(None, C.byref(sb), C.byref(cs), Qm, 0, G, O.P(e), O.P(data))
     assert not fn(C.byref(q), C.byref(sb), C.byref(cs), 0, 0, G, O.P(e), O.P(data))

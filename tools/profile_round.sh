@@ -69,7 +69,10 @@ for V in wave pair block; do
   rm -rf $OUT/v_s $OUT/v_l
 done
 unset SRSRAN_HIP_PSS_VARIANT
-( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o roundtrip_probe roundtrip_probe.hip 2> /dev/null; ./roundtrip_probe 0 ) > $OUT/roundtrip_probe.txt 2>&1
+( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o roundtrip_probe roundtrip_probe.hip -lpthread 2> /dev/null; ./roundtrip_probe 0 ) > $OUT/roundtrip_probe.txt 2>&1
+( cd tools/probe && gcc -O2 -I../../include seam_threads.c -o seam_threads -L../../srslte_amd/lib -lsrsran_phy_hip -Wl,-rpath,'$ORIGIN/../../srslte_amd/lib' -lpthread -lm 2> /dev/null
+  echo "== the library's default (it asks for 8 hardware queues)"; ./seam_threads; echo "== GPU_MAX_HW_QUEUES=4 (the runtime's own default)"; GPU_MAX_HW_QUEUES=4 ./seam_threads ) > $OUT/seam_threads.txt 2>&1
+python tools/dbg/enc_time.py > $OUT/enc_time.txt 2> /dev/null
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o acs_layout_probe acs_layout_probe.hip 2> /dev/null; ./acs_layout_probe ) > $OUT/acs_layout_probe.txt 2>&1
 cat $OUT/acs_layout_probe.txt
 echo "profile pass rc=$?"

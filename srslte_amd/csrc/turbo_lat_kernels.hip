@@ -346,16 +346,49 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
   const int      rW        = (int)(long_sb % 3); // residue of the step index one past a sub-block
 
   // ---- hard decision (turbodecoder.c:370-378, turbodecoder_win.h:973-993) + CRC of the K bits (sch.c:430-447).
-  // The hard bits are collected DURING the last forward pass into an LDS image (sub-block d at simg + d * sbs4 bytes, MSB first, zero padded),
-  // so the decision reads no global memory: the first version walked the decision LLRs in D block by block, one memory round trip each
-  // -- a third of an early-stop half iteration.  D is only written when the caller wants the decision LLRs (parity aid).
+  // A pass that may be the last files its raw outputs in D in natural order (one store per lane and 8-step block, next to the exchange store); the
+  // decision then loads D eight blocks at a time and turns signs into image bytes (sub-block d at simg + d * sbs4 bytes, MSB first, zero padded)
+  // with one wave-wide ballot per sub-block of a pair: the 8 lanes of a pair hold the 8 steps of a block = one byte.  History: walking D one block
+  // per memory round trip cost a third of an early-stop half iteration; collecting the bits inside the block loop (LDS atomics, byte stores into a
+  // scratch, two 64-bit registers per lane) cost 11.5 of its 69.5 us whichever way; this form costs the same per half iteration (the store 6.7 us,
+  // the pass over D 5 us: tools/dbg/es_time.py against builds without either) but needs no image clearing and 25 registers fewer (72 instead of
+  // 97 AGPRs of spilled state), which shows in the launch's fixed part: 832 blocks 0.182 -> 0.158 ms at one half iteration.
   uint8_t*       simg   = reinterpret_cast<uint8_t*>(&simg_all[grp][0]);
   const uint32_t sbs4   = (nblk + 1 + 3) & ~3u; // bytes per sub-block in the image
+  for (uint32_t w = li; w < (uint32_t)NB * (sbs4 >> 2); w += G) {
+    simg_all[grp][w] = 0; // (bytes behind a sub-block's last block stay zero)
+  }
   auto           decide = [&](bool write, bool final_try) -> uint32_t {
     const bool     whole = (long_sb & 7) == 0;
     const uint32_t bps   = long_sb >> 3;
     const uint32_t poly  = crc_poly & 0xffffffu;
     uint32_t       crc   = 0;
+    {
+      const int sh = (lane & 63) & ~7; // this pair's byte in the ballots of its wave
+      constexpr uint32_t UD = 8; // loads in flight (24 were slower: the registers they take are spilled state of the caller)
+      for (uint32_t b0 = 0; b0 < nblk; b0 += UD) {
+        uint32_t r[UD];
+#pragma unroll
+        for (uint32_t u = 0; u < UD; u++) {
+          const uint32_t b = b0 + u < nblk ? b0 + u : nblk - 1;
+          r[u]             = D[b * G + li];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UD; u++) {
+          const uint32_t b = b0 + u;
+          if (b < nblk) { // (uniform)
+            const bool               in = b * 8 + slot < long_sb;
+            const s2                 v  = from_u(r[u]);
+            const unsigned long long mx = __ballot(in && v.x > 0), my = __ballot(in && v.y > 0);
+            if (slot == 0) {
+              simg[(2 * pl) * sbs4 + b]     = (uint8_t)(__brev((uint32_t)(mx >> sh) & 0xffu) >> 24);
+              simg[(2 * pl + 1) * sbs4 + b] = (uint8_t)(__brev((uint32_t)(my >> sh) & 0xffu) >> 24);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
     if (crc_poly) {
       // the CRC is linear: every lane runs the bit-serial register (crc.c:92-140, zero start) over whole 32-bit words of the image and shifts its
       // remainder into place with x^(bits behind the word) mod g (p.crc_mult: one multiplier per word of the image, turbo_host.cpp)
@@ -670,13 +703,6 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
     const uint32_t* lut  = dec1 ? p.deint : p.inter; // per (block, destination pair, step): row | source sub-blocks (turbo_host.cpp)
     uint32_t*       dst  = dec1 ? A2 : A1;
     const bool      last = (n + 1 == p.n_end) || crc_poly;
-    const bool      want_d = last && p.dec_llr != nullptr;
-    if (last) { // the image collects this pass's hard decisions
-      for (uint32_t w = li; w < (uint32_t)NB * (sbs4 >> 2); w += G) {
-        simg_all[grp][w] = 0;
-      }
-      __syncthreads();
-    }
     {
       uint32_t ckb[3], trb[3]; // check-point and exchange entry of a block, same three-set scheme
       auto     issue_aux = [&](uint32_t b, int set) {
@@ -826,29 +852,18 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
           dst[dat] = v;
         }
         if (last) {
-          // what tdec_decision_byte reads (turbodecoder.c:370-378), natural order: ext1 after decoder 1, the de-interleaved ext2 after decoder 2;
-          // bit = LLR > 0 goes into the image at (sub-block, step) of the value's DESTINATION
-          uint32_t r, kd; // value and its step index in natural order
+          // what tdec_decision_byte reads (turbodecoder.c:370-378), natural order: ext1 after decoder 1, the de-interleaved ext2 after decoder 2
+          // (every lane takes part in the exchange: across two waves it has a barrier inside)
+          uint32_t r, at;
           if constexpr (dec1) {
             r  = to_u(keptraw);
-            kd = b * 8 + slot;
+            at = (b * LPC + pl) * 8 + slot;
           } else {
             r  = pick(to_u(keptraw));
-            kd = row;
+            at = dat;
           }
           if (slot < len) {
-            const s2       v  = from_u(r);
-            const uint32_t sh = 8 * ((kd >> 3) & 3u) + 7 - (kd & 7u);
-            uint32_t*      im = &simg_all[grp][0];
-            if (v.x > 0) {
-              atomicOr(&im[((2 * pl) * sbs4 + (kd >> 3)) >> 2], 1u << sh);
-            }
-            if (v.y > 0) {
-              atomicOr(&im[((2 * pl + 1) * sbs4 + (kd >> 3)) >> 2], 1u << sh);
-            }
-            if (want_d) {
-              D[dec1 ? (b * LPC + pl) * 8 + slot : dat] = r;
-            }
+            D[at] = r;
           }
         }
       };

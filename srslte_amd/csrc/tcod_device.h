@@ -26,16 +26,23 @@ struct TbCbJob { // one code block of a transport block
   const uint16_t* table; // forward rate-matching table of (K, rv): position in the natural [d0 d1 d2] x K + 12 buffer of each bit
   uint32_t table_len;
   uint32_t pad;
+  uint32_t crc_mult_row; // CRC24B: row of TbParams::crc_mult with lane l's x^(bits behind its stretch) mod g for a block of this many bits
+  uint32_t pad2;
 };
 struct TbCrcJob { // CRC24A of one transport block
   uint32_t src_byte, n_bytes;
+  uint32_t crc_mult_row; // row of TbParams::crc_mult with lane l's x^(8 bytes behind its stretch) mod g for this many bytes
+  uint32_t pad;
 };
+// the lanes' stretches of an n-unit message and what lies behind them: lane l takes units [min(l L, n), min((l + 1) L, n)), L = ceil(n / 64)
+void crc_lane_multipliers(uint32_t n_units, uint32_t bits_per_unit, uint32_t poly24, uint32_t* m64);
 struct TbParams {
   const uint8_t*  data;   // packed payload bytes of all transport blocks
   uint8_t*        e_bits; // packed output, zeroed by the launcher's caller (blocks OR their bits in)
   const TbCbJob*  cbs;
   const TbCrcJob* tbs;
   uint32_t*       tb_crc; // n_tb checksums (device scratch)
+  const uint32_t* crc_mult; // rows of 64 lane multipliers (host: crc_lane_multipliers)
   uint32_t        n_cb, n_tb;
 };
 hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream);

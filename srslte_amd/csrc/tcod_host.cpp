@@ -6,6 +6,7 @@
 #include "tcod_device.h"
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 using namespace phyhip;
@@ -291,7 +292,77 @@ struct srsran_hip_sch_enc {
   size_t cap       = 0;
   hipEvent_t done  = nullptr;
   bool   pending   = false;
+  // lane multipliers of the two CRCs, one row of 64 per message length seen so far (key: length | generator << 31), resident on the device
+  std::map<uint32_t, uint32_t> mult_row;
+  uint32_t*                    d_mult = nullptr;
+  uint32_t                     mult_rows_cap = 0;
 };
+
+namespace {
+uint32_t h_mulmod24(uint32_t a, uint32_t m, uint32_t poly)
+{
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r = ((r << 1) & 0xffffffu) ^ (((r >> 23) & 1u) ? poly : 0u);
+    r ^= ((m >> i) & 1u) ? a : 0u;
+  }
+  return r;
+}
+uint32_t h_xpow24(uint32_t n, uint32_t poly)
+{
+  uint32_t r = 1, b = 2;
+  while (n) {
+    if (n & 1u) {
+      r = h_mulmod24(r, b, poly);
+    }
+    b = h_mulmod24(b, b, poly);
+    n >>= 1;
+  }
+  return r;
+}
+} // namespace
+
+void phyhip::tcod::crc_lane_multipliers(uint32_t n_units, uint32_t bits_per_unit, uint32_t poly24, uint32_t* m64)
+{
+  const uint32_t L = (n_units + 63u) / 64u;
+  for (uint32_t l = 0; l < 64; l++) {
+    const uint32_t i1 = std::min((l + 1) * L, n_units);
+    m64[l]            = h_xpow24(bits_per_unit * (n_units - i1), poly24);
+  }
+}
+
+// row of lane multipliers for a message of n units (bytes for the transport CRC24A, bits for the code-block CRC24B): computed and uploaded
+// the first time the length is seen by this object
+static uint32_t enc_mult_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb)
+{
+  const uint32_t key = n_units | (cb ? 0x80000000u : 0u);
+  auto           it  = h->mult_row.find(key);
+  if (it == h->mult_row.end()) {
+    const uint32_t row = (uint32_t)h->mult_row.size();
+    if (row >= h->mult_rows_cap) {
+      const uint32_t cap = h->mult_rows_cap ? 2 * h->mult_rows_cap : 32;
+      uint32_t*      nd  = nullptr;
+      if (hipMalloc(&nd, (size_t)cap * 64 * sizeof(uint32_t)) != hipSuccess ||
+          (h->d_mult && (hipMemcpy(nd, h->d_mult, (size_t)row * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+                         hipDeviceSynchronize() != hipSuccess))) { // nothing may still read the old table when it is freed below
+        (void)hipFree(nd);
+        set_error("sch encode: device allocation of the CRC multiplier table failed");
+        return 0xffffffffu;
+      }
+      (void)hipFree(h->d_mult);
+      h->d_mult        = nd;
+      h->mult_rows_cap = cap;
+    }
+    uint32_t m[64];
+    tcod::crc_lane_multipliers(n_units, cb ? 1u : 8u, cb ? 0x800063u : 0x864CFBu, m);
+    if (upload(h->d_mult + (size_t)row * 64, m, sizeof(m)) != hipSuccess) {
+      set_error("sch encode: upload of the CRC multiplier table failed");
+      return 0xffffffffu;
+    }
+    it = h->mult_row.emplace(key, row).first;
+  }
+  return it->second; // (a row INDEX: the table may move while a call's jobs are still being written)
+}
 
 extern "C" int srsran_hip_sch_enc_create(srsran_hip_sch_enc_t** hh)
 {
@@ -321,6 +392,7 @@ extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
   }
   (void)hipFree(h->d_scratch);
   (void)hipHostFree(h->h_scratch);
+  (void)hipFree(h->d_mult);
   (void)hipEventDestroy(h->done);
   delete h;
 }
@@ -398,7 +470,10 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
     const srsran_cbsegm_t& cs = seg[t];
-    crcs[t]                   = {tb.data_offset, tb.tbs / 8};
+    crcs[t]                   = {tb.data_offset, tb.tbs / 8, enc_mult_row(h, tb.tbs / 8, false), 0};
+    if (crcs[t].crc_mult_row == 0xffffffffu) {
+      return SRSRAN_ERROR;
+    }
     // sch.c:254-330: bits per block and rate-matched lengths
     const uint32_t Gp = tb.nof_e_bits / tb.Qm, gamma = Gp % cs.C;
     uint32_t       src = 8 * tb.data_offset, wp = tb.e_offset;
@@ -423,6 +498,10 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
       j.f2                = ki->f2;
       j.table             = ki->table;
       j.table_len         = ki->table_len;
+      j.crc_mult_row      = j.crc24b ? enc_mult_row(h, j.n_src_bits + (last ? 24u : 0u), true) : 0u;
+      if (j.crc_mult_row == 0xffffffffu) {
+        return SRSRAN_ERROR;
+      }
       src += j.n_src_bits;
       wp += j.E;
       cbs[at++] = j;
@@ -438,6 +517,7 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   p.tb_crc = reinterpret_cast<uint32_t*>(db + n_cb * sizeof(tcod::TbCbJob) + n_tb * sizeof(tcod::TbCrcJob));
   p.n_cb   = (uint32_t)n_cb;
   p.n_tb   = n_tb;
+  p.crc_mult = h->d_mult;
   // the code blocks OR their partial bytes into the output: clear every transport block's range first (adjacent ranges merged)
   std::vector<std::pair<uint32_t, uint32_t>> rng;
   for (uint32_t t = 0; t < n_tb; t++) {

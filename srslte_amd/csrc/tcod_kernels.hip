@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64) void tb_crc24a_kernel(const TbParams p)
       c = crc24_bit(c, (b >> k) & 1u, CRC24A_POLY);
     }
   }
-  c = mulmod24(c, xpow24(8u * (job.n_bytes - i1), CRC24A_POLY), CRC24A_POLY);
+  // (the multiplier x^(8 bytes behind this lane's stretch) comes from the host: a square-and-multiply per lane was two fifths of this kernel)
+  c = mulmod24(c, p.crc_mult[job.crc_mult_row * 64u + (threadIdx.x & 63u)], CRC24A_POLY);
   c = wave_xor(c);
   if (threadIdx.x == 0) {
     p.tb_crc[blockIdx.x] = c;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64) void tb_encode_kernel(const TbParams p)
     for (uint32_t i = i0; i < i1; i++) {
       v = crc24_bit(v, sm[3u * i], CRC24B_POLY);
     }
-    v = wave_xor(mulmod24(v, xpow24(n - i1, CRC24B_POLY), CRC24B_POLY));
+    v = wave_xor(mulmod24(v, p.crc_mult[job.crc_mult_row * 64u + lane], CRC24B_POLY));
     if (lane < 24) {
       sm[3u * (n + lane)] = (v >> (23u - lane)) & 1u;
     }

@@ -476,3 +476,69 @@ def test_transmit_entry_point_on_host_buffers(hiplib):
             assert fn(C.byref(tb), O.P(payload), O.P(out)) == 0
             assert np.array_equal(out[:e.size], e) and np.all(out[e.size:] == 7), (tbs, rv)
     assert fn(None, O.P(payload), O.P(out)) < 0
+
+
+def test_transport_block_entry_point_random_harq_sequences(hiplib):
+    """srsran_hip_sch_nr_decode_tb over randomly drawn HARQ processes (fixed seed): both base graphs, 1 ... 12 code blocks, QPSK ... 256-QAM, one or two
+    layers, full and limited buffers, up to three transmissions (rv 0, 2, 3; each carries the soft bits of the still undecoded blocks only) -- after
+    every call flags, stored code blocks, iteration average, the rows of the undecoded blocks, and payload / CRC once everything is decoded, equal
+    the oracle's sch_nr_decode on its own buffers"""
+    from srslte_amd import capi
+
+    fn = hiplib.srsran_hip_sch_nr_decode_tb
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    SB, DS = 66 * 384, 8448 // 8
+    n_fail = n_retx_ok = 0
+    for trial in range(12):
+        tbs = int(rng.choice([288, 1032, 3752, 8456, 20496, 42016, 67368, 98376])) // 8 * 8
+        R = float(rng.choice([0.2, 0.45, 0.67, 0.85]))
+        mod, Nl = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+        Qm = [1, 2, 4, 6, 8][mod]
+        G = max(Qm * Nl * 8, int(tbs / R) // (Qm * Nl) * (Qm * Nl))
+        cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, 0)
+        N = (66 if cfg.bg == 0 else 50) * cfg.Z
+        Nref = int(rng.choice([0, 0, N * 3 // 4]))
+        cfg = O.sch_nr_tb_info(tbs, R, mod, G, Nl, Nref)
+        cfg.Nref = Nref if Nref else N
+        Es = [O.sch_nr_get_E(cfg, r) for r in range(cfg.C)]
+        if min(Es) == 0:
+            continue
+        max_iter = int(rng.integers(3, 9))
+        sigma = float(rng.uniform(4.0, 11.0))
+        payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+        max_cb = cfg.C + 1
+        rows = [np.zeros(SB + 8, np.int16) for _ in range(max_cb)]
+        keep = [np.zeros(SB // 8 + 8, np.uint8) for _ in range(max_cb)]
+        flags = np.zeros(max_cb, np.bool_)
+        sb = _SoftbufferRx(max_cb, SB + 8, (C.c_void_p * max_cb)(*[r.ctypes.data for r in rows]), (C.c_void_p * max_cb)(*[k.ctypes.data for k in keep]),
+                           flags.ctypes.data_as(C.POINTER(C.c_bool)), False)
+        soft, crc, data = np.zeros((cfg.C, SB), np.int8), np.zeros(cfg.C, np.uint8), np.zeros((cfg.C, DS), np.uint8)
+        cb_bytes = (cfg.Kp - cfg.L_cb) // 8
+        off = np.cumsum([0] + Es)
+        for rv in (0, 2, 3):
+            e = O.sch_nr_encode_tb(cfg, rv, payload)
+            left = np.concatenate([e[off[r]:off[r + 1]] for r in range(cfg.C) if not crc[r]])
+            llr = np.clip(np.round(14.0 * (1.0 - 2.0 * left) + sigma * rng.standard_normal(left.size)), -63, 63).astype(np.int8)
+            out = np.full(tbs // 8 + 8, 0xEE, np.uint8)
+            crc_ok, avg = C.c_bool(False), C.c_float(-1)
+            tb = capi.HipNrTb(R, tbs, mod, rv, Nl, G, Nref, 0, 0, 0, 0)
+            assert fn(0.8, max_iter, C.byref(tb), O.P(llr), C.byref(sb), O.P(out), C.byref(crc_ok), C.byref(avg)) == 0
+            o_out, ok, o_avg = O.sch_nr_decode_tb(cfg, rv, 0.8, max_iter, llr, soft, crc, data)
+            tag = (trial, tbs, R, mod, Nl, G, Nref, rv, round(sigma, 1), max_iter)
+            assert np.array_equal(flags[:cfg.C].astype(np.uint8), crc) and not flags[cfg.C] and abs(avg.value - o_avg) < 1e-6, (tag, flags, crc, avg.value, o_avg)
+            ncb = min(N, cfg.Nref)
+            for r in range(cfg.C):
+                if crc[r]:
+                    assert np.array_equal(keep[r][:cb_bytes], data[r][:cb_bytes]), (tag, r)
+                else:
+                    assert np.array_equal(rows[r].view(np.int8)[:ncb], soft[r][:ncb]), (tag, r)
+            if crc.all():
+                assert bool(crc_ok.value) == bool(ok) and np.array_equal(out[:tbs // 8], o_out) and np.all(out[tbs // 8:] == 0xEE), tag
+                assert not ok or np.array_equal(o_out, payload), tag
+                n_retx_ok += int(rv != 0)
+                break
+            assert np.all(out == 0xEE) and not crc_ok.value, tag
+            n_fail += 1
+    assert n_fail >= 3 and n_retx_ok >= 1, (n_fail, n_retx_ok)

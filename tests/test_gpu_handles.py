@@ -306,3 +306,23 @@ def test_submission_queue_registry_is_bounded(hiplib):
     _run_threads([worker(t) for t in range(n_thr)])
     assert lib.srsran_hip_coalesce_shapes() <= max(shapes0 + 1, 12)
     assert lib.srsran_hip_coalesce_shapes() <= 12
+
+
+def test_transport_block_seam_under_concurrent_workers(hiplib, tmp_path):
+    """the reference's threading model on the seam, from C (tools/probe/seam_threads.c: 1 / 2 / 3 / 4 / 8 PHY worker threads, each with its own soft buffer,
+    decoding a transport block per call through srsran_hip_decode_tb_cb at the same time; the block comes from the library's own transmit entry
+    srsran_hip_encode_tb): every call of every thread returns the payload"""
+    import os
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "seam_threads")
+    libdir = os.path.join(root, "srslte_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "probe", "seam_threads.c"), "-o", exe, "-L" + libdir,
+                           "-lsrsran_phy_hip", "-Wl,-rpath," + libdir, "-lpthread", "-lm"])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:]
+    rows = re.findall(r"(\d+) worker thread\(s\).*?(\d+) of (\d+) decoded", out.stdout)
+    assert [int(r[0]) for r in rows] == [1, 2, 3, 4, 8], out.stdout[-2000:]
+    assert all(a == b for _, a, b in rows), rows

@@ -230,8 +230,8 @@ def plumbing_only(a, rank, world):
     import torch.distributed as dist
     from srslte_amd import sharding
 
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world > 1:  # the workers' own rendezvous (sharding.job_store: also under torch.distributed.run, whose agent owns MASTER_PORT)
+        sharding.init_collectives(rank, world, torch.device("cpu"), prefer="gloo")
     cfg = sharding.broadcast_config({"n_prb": N_PRB, "n_fft": N_FFT, "k_cb": K_CB, "nit": NIT, "cb_per_sf": CB_PER_SF, "sf": a.sf} if rank == 0 else None)
     lo, hi = sharding.shard_range(cfg["sf"] * world, rank, world)
     if world > 1:

@@ -42,6 +42,23 @@ def max_over_ranks(x, device=None):
     return float(t.item())
 
 
+def job_store(rank, world, timeout):
+    """The rendezvous store of the job, under a prefix of this job's own.
+
+    Launched by bench.py's own launcher (or by hand): rank 0 hosts a TCPStore on MASTER_ADDR:MASTER_PORT.  Launched by
+    `python -m torch.distributed.run` (what the driver does for N > 1): the elastic agent already listens on MASTER_PORT and says so with
+    TORCHELASTIC_USE_AGENT_STORE=True -- every rank, 0 included, is then a CLIENT of the agent's store (a second server on that port is
+    EADDRINUSE).  Same rule as torch's own env:// rendezvous (torch/distributed/rendezvous.py: _create_c10d_store)."""
+    host, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+        store = dist.TCPStore(host, port, world, is_master=False, timeout=timeout)
+    else:
+        store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timeout, wait_for_workers=True, multi_tenant=True)
+    # the agent's store outlives a restart of the workers: keep this job's keys apart from an earlier attempt's
+    run = "%s/%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return dist.PrefixStore("srslte_amd/" + run, store)
+
+
 def init_collectives(rank, world, device=None, prefer="nccl", timeout_s=120):
     """Creates the job's process group -- also at world size 1, so that a 1-GPU run executes the very RCCL bootstrap an N-GPU run needs.
 
@@ -62,8 +79,7 @@ def init_collectives(rank, world, device=None, prefer="nccl", timeout_s=120):
         os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         s.close()
     to = datetime.timedelta(seconds=timeout_s)
-    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0), timeout=to,
-                          wait_for_workers=True)
+    store = job_store(rank, world, to)
     cpu = torch.device("cpu")
     if prefer != "nccl":
         dist.init_process_group("gloo", store=dist.PrefixStore("gloo", store), rank=rank, world_size=world, timeout=to)

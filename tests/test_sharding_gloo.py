@@ -142,3 +142,46 @@ def test_collectives_are_initialised_at_world_size_1(tmp_path):
     """a 1-rank job builds its process group too (on the GPU box: RCCL at world size 1; here: the agreed fallback)"""
     res = _run_agree(tmp_path, 1)
     assert len(res) == 1 and res[0]["cfg"] == {"k_cb": 6144} and res[0]["t"] == 1.0 and len(res[0]["seen"]) == 1
+
+
+def test_collectives_under_torch_distributed_run(tmp_path):
+    """the driver starts N > 1 ranks with `python -m torch.distributed.run --master-addr 127.0.0.1 --master-port P`: the elastic agent
+    then OWNS that port (TORCHELASTIC_USE_AGENT_STORE=True) and every rank, 0 included, must join its store as a client
+    (sharding.job_store) -- a second server on the port is EADDRINUSE on rank 0 (round-3 advice)"""
+    import json
+    import socket
+
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_WORKER % ROOT)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = sorted((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [r["rank"] for r in res] == [0, 1]
+    for r in res:
+        assert r["cfg"] == {"k_cb": 6144} and r["t"] == 2.0 and [x["rank"] for x in r["seen"]] == [0, 1]
+
+
+def test_bench_worker_under_torch_distributed_run():
+    """bench.py itself as the driver launches it for N > 1 (plumbing rehearsal: no kernels)"""
+    import json
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--sf", "11", "--plumbing-only"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and [tuple(x) for x in r["shards"]] == [(0, 11), (11, 22)]

@@ -353,19 +353,13 @@ def worker(a):
         if ev:
             ev[2].record()
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    ctx.barrier()
-    torch.cuda.synchronize()
+    import bench_legs as L
+
+    # warm-up, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier (bench_legs._timed: the same protocol for every leg);
+    # next to the wall time it leaves per-step end-event deltas, the device span and the cost of the closing barrier in `timing`
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(evs[i])
-    torch.cuda.synchronize()
-    ctx.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = L._timed(ctx, torch, lambda i: step(None if i is None else evs[i]), a.steps, a.warmup)
+    timing = L.timing_fields()
     t_ofdm = sum(e[0].elapsed_time(e[1]) for e in evs) / a.steps * 1e-3
     t_tdec = sum(e[1].elapsed_time(e[2]) for e in evs) / a.steps * 1e-3
     dt, t_ofdm, t_tdec = ctx.max_over_ranks([dt, t_ofdm, t_tdec])
@@ -389,7 +383,7 @@ def worker(a):
         res = {
             "metric": "turbo decoded Mbit/s (LTE 20 MHz, K=6144, 8 half-iterations) incl. OFDM demod of the same subframes",
             "value": value, "unit": "Mbit/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / a.steps * 1e3, "timing": timing, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic", "collective_backend": backend, "ranks_seen": seen,
             "config": {"workload": "LTE 20 MHz (BASELINE configs[1]): ofdm_rx_sf N=2048 100 PRB + tdec_run_all K=6144 nof_iterations=8, "
                                    "%d subframes + %d code blocks per GPU per step; the code blocks are %d distinct noisy code words "

@@ -65,20 +65,53 @@ def _qam64(bits):
     return ((i + 1j * q) / np.sqrt(42.0)).astype(np.complex64)
 
 
+LAST_TIMING = {}
+
+
 def _timed(ctx, torch, step, steps, warmup):
-    """the bench contract for one leg: warm-up, barrier + synchronize, `steps` steps, synchronize + barrier; returns wall seconds (max over ranks)"""
+    """the bench contract for one leg: warm-up, barrier + synchronize, `steps` steps, synchronize + barrier; returns wall seconds of this rank.
+
+    Attribution of the timed region (no extra synchronisation: one more event per step on the launch stream, host clocks around the phases)
+    is left in LAST_TIMING -- this rank's figures, milliseconds:
+      step_ms_{min,median,max}  deltas of consecutive per-step end events (the first one against an event recorded before step 0)
+      gpu_span_ms               first start event -> last end event
+      submit_ms                 host time to submit all steps (a host that cannot keep ahead of the device shows here)
+      drain_ms                  host wait in the synchronize after the last submit
+      barrier_ms                wall of the closing barrier + synchronize (the collective of the contract; at world size 1 it is pure overhead)
+      outside_gpu_ms            wall - gpu_span: everything of the timed region that is not the device running the steps
+      slowest_step              index of the step with the largest delta"""
     for _ in range(warmup):
         step(None)
     torch.cuda.synchronize()
+    # the closing barrier's collective is warmed here, outside the timed region (its first use builds / launches what later ones reuse)
     ctx.barrier()
     torch.cuda.synchronize()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    ends[0].record()
     for i in range(steps):
         step(i)
+        ends[i + 1].record()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
     ctx.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    t3 = time.perf_counter()
+    d = [ends[i].elapsed_time(ends[i + 1]) for i in range(steps)]
+    srt = sorted(d)
+    span = ends[0].elapsed_time(ends[steps])
+    LAST_TIMING.clear()
+    LAST_TIMING.update({"step_ms_min": srt[0], "step_ms_median": srt[len(srt) // 2], "step_ms_max": srt[-1], "slowest_step": d.index(srt[-1]),
+                        "gpu_span_ms": span, "submit_ms": (t1 - t0) * 1e3, "drain_ms": (t2 - t1) * 1e3, "barrier_ms": (t3 - t2) * 1e3,
+                        "outside_gpu_ms": (t3 - t0) * 1e3 - span})
+    return t3 - t0
+
+
+def timing_fields():
+    return {k: round(v, 4) if isinstance(v, float) else v for k, v in LAST_TIMING.items()}
 
 
 def _host_has(flag):
@@ -198,7 +231,7 @@ def leg_ldpc(ctx, steps=3, warmup=1, want_cpu=True, cw=16384, slots=2048, iters=
     tr_o, _ = traffic_of(tj, "ofdm_kernel_n4096", slots, "slots_per_launch")
     out = {"metric": "LDPC decoded Mbit/s (info bits, NR BG1 Z=384, %d iterations) incl. OFDM demod N=4096 of %d slots" % (iters, slots),
            "value": ctx.world * cw * K * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
-           "ms_per_step": dt / steps * 1e3, "dtype": "int8", "scaling": "weak",
+           "ms_per_step": dt / steps * 1e3, "timing": timing_fields(), "dtype": "int8", "scaling": "weak",
            "config": {"workload": "NR 100 MHz SCS 30 kHz (BASELINE configs[2]): ofdm_rx N=4096 273 PRB x %d slots + ldpc BG1 Z=384 x %d code words, "
                                   "%d iterations, scaling 0.8, no early stop; %d distinct code words (device encoder + AWGN 3 dB) tiled %dx, per GPU"
                                   % (slots, cw, iters, pool_n, reps)},
@@ -282,7 +315,7 @@ def leg_cellsearch(ctx, steps=3, warmup=1, want_cpu=True, caps=256):
     tr, src = traffic_of(tj, "pss_wave_kernel", caps, "captures_per_launch")
     out = {"metric": "cell search Msamples/s (10 ms captures at 30.72 Msps, 3 PSS hypotheses + SSS = 504 PCI hypotheses per capture)",
            "value": ctx.world * caps * frame * steps / dt / 1e6, "unit": "Msamples/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
-           "ms_per_step": dt / steps * 1e3, "dtype": "f32", "scaling": "weak",
+           "ms_per_step": dt / steps * 1e3, "timing": timing_fields(), "dtype": "f32", "scaling": "weak",
            "config": {"workload": "BASELINE configs[4]: %d captures x 307,200 samples per GPU, fft 2048, 4 distinct captures (noise + one cell) tiled" % caps},
            "captures_per_s": ctx.world * caps * steps / dt, "results_correct": bool(ok),
            "roofline": {"kernel": "srsran_hip_cellsearch_run (pss correlation + peak/PSR + SSS kernels; the correlation dominates)", "bound": "hbm",
@@ -426,10 +459,11 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
     tr_u, src_u = traffic_of(load_traffic(), "uplink_chain", n_tb, "ue_subframes_per_step")
     out = {"metric": "multi-UE LTE uplink, PUSCH receive path from time samples to transport blocks, Mbit/s of TBS (all GPUs)",
            "value": ctx.world * n_tb * tbs * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
-           "ms_per_step": t_step * 1e3, "dtype": "f32 / int16", "scaling": "weak",
-           "config": {"workload": "BASELINE configs[3], per-GPU shard: %d UEs x %d subframes, 20 MHz (100 PRB), 64-QAM, TBS %d (%d code blocks of 5824), "
+           "ms_per_step": t_step * 1e3, "timing": timing_fields(), "dtype": "f32 / int16", "scaling": "weak",
+           "config": {"workload": "BASELINE configs[3], per-GPU shard: %d UEs x %d subframes, 20 MHz (100 PRB, symbol size N=%d: the reference's default "
+                                  "for 100 PRB, phy_common.c:366-378), 64-QAM, TBS %d (%d code blocks of 5824), "
                                   "Es/N0 %.1f dB, at most %d half iterations with CRC early stop; %d distinct transport blocks (device transmit side + AWGN) tiled"
-                                  % (ues, sf, tbs, ncb, snr, iters, pool_n)},
+                                  % (ues, sf, otx.sf_sz // 15, tbs, ncb, snr, iters, pool_n)},
            "subframes_per_s": ctx.world * n_tb * steps / dt, "tb_crc_ok": [ok, n_tb], "payload_matches_on_ok_blocks": bool(good),
            "avg_half_iterations": float(np.mean([r.avg_iterations for r in res])),
            "stage_ms": {"ofdm_rx": float(pm[0]), "gather+equaliser": float(pm[1]), "transform_deprecoding": float(pm[2]),
@@ -438,7 +472,8 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                         "achieved": n_tb * unit_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": n_tb * unit_bytes / t_step / 1e9 / HBM_PEAK_GBS, "traffic": tr_u, "traffic_source": src_u, "avg_launch_ms": t_step * 1e3,
                         "algorithmic_bytes_per_launch": n_tb * unit_bytes,
-                        "note": "algorithmic = time samples in (245,760 B) + payload out (7,972 B) per UE-subframe; wall time of the step, host work included"}}
+                        "note": "algorithmic = time samples in (%d B: 15 x N=%d complex64) + payload out (%d B) per UE-subframe; wall time of the step, host work included"
+                                % (otx.sf_sz * 8, otx.sf_sz // 15, tbs // 8)}}
     if host_fed and ctx.world == 1:
         out["host_fed"] = _uplink_host_fed(torch, S, capi, lib, dev, d_time, n_tb, otx.sf_sz, nprb, nsc, data_sym, n_re, G, tbs, ncb, mod, Qm, seeds, pool_n,
                                            gain, iters, payload, workers=3)
@@ -553,7 +588,7 @@ def leg_turbo8(ctx, steps=3, warmup=1, want_cpu=True, n_cb=131040, K=6144, nit=8
     tr, src = traffic_of(load_traffic(), "tdec_win_kernel_8bit", n_cb, "code_blocks_per_launch")
     out = {"metric": "turbo decoded Mbit/s through the 8-bit API (LTE 20 MHz, K=6144, 8 half iterations; what srsenb / srsue run)",
            "value": ctx.world * n_cb * K * steps / dt / 1e6, "unit": "Mbit/s", "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
-           "ms_per_step": dt / steps * 1e3, "dtype": "int8", "scaling": "weak",
+           "ms_per_step": dt / steps * 1e3, "timing": timing_fields(), "dtype": "int8", "scaling": "weak",
            "config": {"workload": "srsran_hip_tdec_batch_run_8bit: %d blocks K=%d, nof_iterations=%d, AUTO -> avx8 window (32 sub-blocks); %d distinct noisy "
                                   "code words (half at Es/N0 3 dB, half at -1 dB) tiled %dx, per GPU" % (n_cb, K, nit, pool_n, reps)},
            "roofline": {"kernel": "tdec_win_kernel<32, Ar8, false>", "bound": "hbm", "achieved": n_cb * unit / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -23,7 +23,15 @@ MANIFEST = json.load(open(os.path.join(HERE, "ref_link", "ctest_manifest.json"))
 ALL_LINES_OF = {"ofdm_test", "dft_test", "turbodecoder_test", "turbocoder_test", "rm_turbo_test", "sync_test", "cfo_test", "ldpc_chain_test",
                 "ldpc_rm_chain_test", "ldpc_dec_test", "ldpc_dec_s_test", "ldpc_dec_avx2_test", "ldpc_enc_test", "ldpc_enc_avx2_test",
                 "ldpc_rm_test", "pusch_test", "sch_nr_test", "pusch_nr_test", "pdsch_nr_test", "pmch_test", "pbch_file_test", "pcfich_file_test",
-                "phich_file_test", "pdcch_file_test", "pdsch_pdcch_file_test", "pmch_file_test", "modem_test", "prach_test"}
+                "phich_file_test", "pdcch_file_test", "pdsch_pdcch_file_test", "pmch_file_test", "modem_test", "prach_test", "phy_dl_nr_test", "pucch_ca_test"}
+
+
+def _phy_dl_default(e):
+    """lib/test/phy/phy_dl_test (eNB-DL -> UE-DL loop-back, BASELINE configs[0]'s harness): every 6-PRB line (N=128, the configs[0] cell) and the
+    top-MCS lines of the 100-PRB cell (configs[1]'s cell: 13 code blocks of 6144 per transport block) by default, all 240 with REF_CTEST_FULL=1"""
+    a = e["args"]
+    prb, mcs = int(a[a.index("-p") + 1]), int(a[a.index("-m") + 1])
+    return prb == 6 or (prb == 100 and mcs >= 27)
 
 
 def _selected():
@@ -32,7 +40,10 @@ def _selected():
     for e in MANIFEST:
         n = seen.get(e["program"], 0)
         seen[e["program"]] = n + 1
-        if full or e["program"] in ALL_LINES_OF or n % 8 == 0:
+        if e["program"] == "phy_dl_test":
+            if full or _phy_dl_default(e):
+                yield e
+        elif full or e["program"] in ALL_LINES_OF or n % 8 == 0:
             yield e
 
 
@@ -54,7 +65,8 @@ def test_ctest_line(entry, data_dir):
 # device as one call (rate de-matching, turbo early stop, CRCs), on the reference's own soft-buffer structs.
 # NR (tests/ref_link/nr_bind.c): srsran_dlsch_nr_decode / srsran_ulsch_nr_decode (sch_nr.c:724-749) of the unmodified sch_nr.o weakened, the
 # binding's in their place -- sch_nr_test drives them directly, pdsch_nr_test / pusch_nr_test through srsran_pdsch_nr_decode / srsran_pusch_nr_decode
-TB_PROGRAMS = {"pdsch_test", "pusch_test", "pmch_test", "pdsch_pdcch_file_test", "pmch_file_test", "sch_nr_test", "pdsch_nr_test", "pusch_nr_test"}
+TB_PROGRAMS = {"pdsch_test", "pusch_test", "pmch_test", "pdsch_pdcch_file_test", "pmch_file_test", "sch_nr_test", "pdsch_nr_test", "pusch_nr_test",
+               "phy_dl_test", "phy_dl_nr_test"}
 
 
 def _selected_tb():
@@ -65,7 +77,10 @@ def _selected_tb():
             continue
         n = seen.get(e["program"], 0)
         seen[e["program"]] = n + 1
-        if full or e["program"] != "pdsch_test" or n % 4 == 0:
+        if e["program"] == "phy_dl_test":
+            if full or _phy_dl_default(e):
+                yield e
+        elif full or e["program"] != "pdsch_test" or n % 4 == 0:
             yield e
 
 

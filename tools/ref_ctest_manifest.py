@@ -87,6 +87,26 @@ EXTRA = [  # literal stand-ins for the looped lines (fec/ldpc/test/CMakeLists.tx
 ]
 
 
+def phy_level_lines():
+    """lib/test/phy/CMakeLists.txt: the eNB-DL -> UE-DL loop-back program of BASELINE configs[0] ("CPU reference via lib/test/phy").  Its 240
+    phy_dl_test lines come from nested foreach loops (:33-59), restated here; pucch_ca_test (:63) and the five phy_dl_nr_test lines (:67-74) are literal."""
+    for prb in (6, 15, 25, 50, 75, 100):
+        for q in (0, 1):
+            for tm in (1, 2, 3, 4):
+                for mcs in range(0, 29, 7):
+                    if q and mcs == 28:  # :42-48: with 256-QAM tables the top index is 27 (26 at 15 PRB)
+                        mcs = 26 if prb == 15 else 27
+                    args = ["-p", str(prb), "-t", str(tm)] + (["-q"] if q else []) + ["-m", str(mcs)]
+                    yield "../../test/phy", "phy_dl_test" + "".join(args), "phy_dl_test", args
+    yield "../../test/phy", "pucch_ca_test", "pucch_ca_test", []
+    yield "../../test/phy", "phy_dl_nr_test", "phy_dl_nr_test", "-p 100 -m 28".split()
+    yield ("../../test/phy", "phy_dl_nr_test_rvd", "phy_dl_nr_test",
+           "-P 52 -p 52 -m 0 -R 0 52 1 010010010010 00000000010000 -R 0 52 1 100100100100 00000010000000".split())
+    yield "../../test/phy", "phy_dl_nr_test_cfo_delay", "phy_dl_nr_test", "-P 52 -p 52 -m 27 -C 100.0 -D 4 -n 10".split()
+    yield "../../test/phy", "phy_dl_nr_test_52prb", "phy_dl_nr_test", "-P 52 -p 52 -m 27 -T 256qam -v -d 1 1 -n 10".split()
+    yield "../../test/phy", "phy_dl_nr_test_270prb", "phy_dl_nr_test", "-P 270 -p 270 -m 27 -T 256qam -v -d 1 1 -n 10".split()
+
+
 def main():
     exp = exported()
     entries, data = [], {}
@@ -113,6 +133,10 @@ def main():
             v = v if isinstance(v, tuple) else (v,)
             entries.append({"dir": d, "name": name % v[:name.count("%d")], "program": prog, "args": (fmt % v).split(), "binds": len(b),
                             "binds_sample": b[:6], "needs_ldpc_examples": bool(ldpc_file)})
+    for d, name, prog, args in phy_level_lines():
+        b = bound(prog, exp)
+        if b:
+            entries.append({"dir": d, "name": name, "program": prog, "args": args, "binds": len(b), "binds_sample": b[:6]})
     out = os.path.join(ROOT, "tests", "ref_link", "ctest_manifest.json")
     json.dump({"entries": entries, "data_files": sorted(data)}, open(out, "w"), indent=1)
     import numpy as np

@@ -225,6 +225,12 @@ uint32_t orc_sequence_pdsch_seed(uint16_t rnti, int q, uint32_t nslot, uint32_t 
 uint32_t orc_sequence_pusch_seed(uint16_t rnti, uint32_t nslot, uint32_t cell_id);
 /* srsran_predecoding_single (mimo/precoding.c:357-392): single-antenna ZF / MMSE equaliser, double arithmetic */
 int      orc_predecoding_single(const float* y, const float* h, float* x, float* csi, int n, float scaling, float noise_estimate);
+/* lte_tables.c:30-181 / modem_table.c: constellation of srsran_mod_t `mod`, 2^Qm points (re, im), index = bits MSB first */
+int      orc_mod_table(int mod, float* out);
+/* sequence.c:609-650 + mod.c:135-166 (+ vector scaling): packed bits -> [scrambled with c_init = seed] -> points x scaling */
+int      orc_modulate_bytes(int mod, const uint8_t* bits, float* out, uint32_t nbits, uint32_t seed, int scramble, float scaling);
+/* sch.c:660-681 without RI bits: lut[q position] = g position */
+int      orc_ulsch_interleaver_lut(uint32_t nof_sym, uint32_t Qm, uint32_t cols, uint32_t* lut);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "oracle.h"
@@ -343,4 +344,104 @@ int orc_predecoding_single(const float* y, const float* h, float* x, float* csi,
     }
   }
   return n;
+}
+
+/* ---------------- modulator (test infrastructure) ----------------
+ * Constellation tables of lib/src/phy/modem/lte_tables.c:30-181 (TS 36.211 7.1.1-7.1.5), restated from the standard's closed forms
+ *   16-QAM  I = (1 - 2 b0)(2 - (1 - 2 b2)) / sqrt 10                 Q likewise with b1, b3
+ *   64-QAM  I = (1 - 2 b0)(4 - (1 - 2 b2)(2 - (1 - 2 b4))) / sqrt 42
+ *   256-QAM I = (1 - 2 b0)(8 - (1 - 2 b2)(4 - (1 - 2 b4)(2 - (1 - 2 b6)))) / sqrt 170
+ * with the levels evaluated as the reference does: float k / sqrtf(N) (lte_tables.h:30-36), (float)M_SQRT1_2 for BPSK / QPSK.
+ * table index = the symbol's bits, first bit most significant (modem_table.c:60-140 fills symbol_table that way).  out: 2^Qm (re, im). */
+static int orc_qm(int mod)
+{
+  return mod == 0 ? 1 : 2 * mod;
+}
+
+int orc_mod_table(int mod, float* out)
+{
+  if (mod < 0 || mod > 4) {
+    return -1;
+  }
+  const int qm = orc_qm(mod), n = 1 << qm;
+  for (int i = 0; i < n; i++) {
+    int b[8];
+    for (int k = 0; k < qm; k++) {
+      b[k] = (i >> (qm - 1 - k)) & 1;
+    }
+    float re, im;
+    if (mod == 0) {
+      re = im = b[0] ? -(float)M_SQRT1_2 : (float)M_SQRT1_2;
+    } else if (mod == 1) {
+      re = b[0] ? -(float)M_SQRT1_2 : (float)M_SQRT1_2;
+      im = b[1] ? -(float)M_SQRT1_2 : (float)M_SQRT1_2;
+    } else {
+      /* amplitude in units of 1 / sqrt N from the nested form, as an odd integer; the level itself is k / sqrtf(N) in float */
+      int   a[2];
+      float norm = mod == 2 ? sqrtf(10.0f) : (mod == 3 ? sqrtf(42.0f) : sqrtf(170.0f));
+      for (int c = 0; c < 2; c++) {
+        int v = 1; /* innermost (2 - (1 - 2 b)) starts from the last pair */
+        v     = 2 - (1 - 2 * b[qm - 2 + c]);
+        for (int k = qm / 2 - 2; k >= 1; k--) {
+          v = (1 << (qm / 2 - k)) - (1 - 2 * b[2 * k + c]) * v;
+        }
+        a[c] = v;
+      }
+      re = (float)a[0] / norm;
+      im = (float)a[1] / norm;
+      if (b[0]) {
+        re = -re;
+      }
+      if (b[1]) {
+        im = -im;
+      }
+    }
+    out[2 * i]     = re;
+    out[2 * i + 1] = im;
+  }
+  return n;
+}
+
+/* srsran_sequence_apply_packed (sequence.c) + srsran_mod_modulate_bytes (mod.c:135-166) + srsran_vec_sc_prod_cfc: byte-packed bits, MSB first */
+int orc_modulate_bytes(int mod, const uint8_t* bits, float* out, uint32_t nbits, uint32_t seed, int scramble, float scaling)
+{
+  float tab[512];
+  if (orc_mod_table(mod, tab) < 0 || nbits % (uint32_t)orc_qm(mod)) {
+    return -1;
+  }
+  const uint32_t qm = (uint32_t)orc_qm(mod), n = nbits / qm;
+  uint8_t*       c = (uint8_t*)calloc(nbits + 1, 1);
+  if (scramble) {
+    orc_sequence_bits(seed, c, nbits);
+  }
+  for (uint32_t s = 0; s < n; s++) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < qm; k++) {
+      const uint32_t b = s * qm + k;
+      v                = (v << 1) | (((bits[b >> 3] >> (7 - (b & 7))) & 1u) ^ c[b]);
+    }
+    out[2 * s]     = scaling == 1.0f ? tab[2 * v] : tab[2 * v] * scaling;
+    out[2 * s + 1] = scaling == 1.0f ? tab[2 * v + 1] : tab[2 * v + 1] * scaling;
+  }
+  free(c);
+  return (int)n;
+}
+
+/* UL-SCH channel interleaver, TS 36.212 5.2.2.8 without RI / ACK bits (sch.c:660-681 ulsch_interleave_gen with ri_present = NULL): position of
+ * every bit of q in g.  nof_sym groups of Qm bits; the matrix has `cols` columns (SC-FDMA symbols) and is written row by row, read column by column. */
+int orc_ulsch_interleaver_lut(uint32_t nof_sym, uint32_t Qm, uint32_t cols, uint32_t* lut)
+{
+  if (cols == 0 || nof_sym % cols) {
+    return -1;
+  }
+  const uint32_t rows = nof_sym / cols;
+  uint32_t       idx  = 0;
+  for (uint32_t j = 0; j < rows; j++) {
+    for (uint32_t i = 0; i < cols; i++) {
+      for (uint32_t k = 0; k < Qm; k++) {
+        lut[(i * rows + j) * Qm + k] = idx++;
+      }
+    }
+  }
+  return 0;
 }

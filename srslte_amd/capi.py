@@ -132,6 +132,36 @@ class HipDemodJob(C.Structure):
 LLR_SHORT, LLR_BYTE, LLR_FLOAT, MOD_NONE = 0, 1, 2, 5
 
 
+class HipGrantTb(C.Structure):  # srsran_hip_grant_tb_t, include/srsran_amd/phy_chan_abi.h
+    _fields_ = [(n, C.c_uint32) for n in ("mod", "tbs", "rv", "nof_re", "seed", "max_nof_iterations", "llr_is_8bit", "nl")]
+
+
+class HipGrantRes(C.Structure):
+    _fields_ = [("crc_ok", C.c_int32), ("avg_iterations_block", C.c_float), ("epre", C.c_float)]
+
+
+class HipPuschRx(C.Structure):
+    _fields_ = [("tb", HipGrantTb), ("cell_nof_prb", C.c_uint32), ("cp_nsymb", C.c_uint32), ("n_prb_tilde", C.c_uint32 * 2), ("L_prb", C.c_uint32),
+                ("shortened", C.c_uint32), ("noise_estimate", C.c_float), ("meas_epre", C.c_uint32)]
+
+
+class HipPdschRx(C.Structure):
+    _fields_ = [("tb", HipGrantTb), ("scaling", C.c_float), ("noise_estimate", C.c_float)]
+
+
+class HipPdschTx(C.Structure):
+    _fields_ = [("tb", HipGrantTb), ("scaling", C.c_float)]
+
+
+class SoftbufferRx(C.Structure):  # srsran_softbuffer_rx_t, softbuffer.h:40-47
+    _fields_ = [("max_cb", C.c_uint32), ("max_cb_size", C.c_uint32), ("buffer_f", C.POINTER(C.c_void_p)), ("data", C.POINTER(C.c_void_p)),
+                ("cb_crc", C.POINTER(C.c_bool)), ("tb_crc", C.c_bool)]
+
+
+class SoftbufferTx(C.Structure):  # srsran_softbuffer_tx_t, softbuffer.h:49-53
+    _fields_ = [("max_cb", C.c_uint32), ("max_cb_size", C.c_uint32), ("buffer_b", C.POINTER(C.c_void_p))]
+
+
 class LdpcRm(C.Structure):  # srsran_ldpc_rm_t, ldpc_rm.h:37-52
     _fields_ = [("ptr", C.c_void_p), ("bg", C.c_int), ("ls", C.c_uint16), ("N", C.c_uint32), ("E", C.c_uint32), ("K", C.c_uint32),
                 ("F", C.c_uint32), ("k0", C.c_uint32), ("mod_order", C.c_uint32), ("Ncb", C.c_uint32)]
@@ -462,6 +492,15 @@ def lib():
             "srsran_hip_demod_run": (i32, [vp, vp, vp, i32, C.POINTER(HipDemodJob), u32, vp]),
             "srsran_hip_sequence_pdsch_seed": (u32, [C.c_uint16, i32, u32, u32]),
             "srsran_hip_sequence_pusch_seed": (u32, [C.c_uint16, u32, u32]),
+            "srsran_hip_pusch_decode": (i32, [C.POINTER(HipPuschRx), vp, vp, C.POINTER(SoftbufferRx), vp, C.POINTER(HipGrantRes)]),
+            "srsran_hip_pusch_decode_multi": (i32, [u32, C.POINTER(HipPuschRx), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.POINTER(SoftbufferRx)),
+                                                    C.POINTER(vp), C.POINTER(HipGrantRes)]),
+            "srsran_hip_pdsch_decode": (i32, [C.POINTER(HipPdschRx), vp, vp, C.POINTER(SoftbufferRx), vp, C.POINTER(HipGrantRes)]),
+            "srsran_hip_pdsch_encode": (i32, [C.POINTER(HipPdschTx), C.POINTER(SoftbufferTx), vp, vp]),
+            "srsran_hip_pdsch_decode_dbg": (i32, [C.POINTER(HipPdschRx), vp, vp, C.POINTER(SoftbufferRx), vp, C.POINTER(HipGrantRes), vp, vp]),
+            "srsran_hip_pdsch_encode_dbg": (i32, [C.POINTER(HipPdschTx), C.POINTER(SoftbufferTx), vp, vp, vp]),
+            "srsran_hip_ulsch_encode": (i32, [C.POINTER(HipGrantTb), u32, C.POINTER(SoftbufferTx), vp, vp]),
+            "srsran_hip_modulate_bytes": (i32, [u32, vp, vp, u32, u32, u32, C.c_float]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),
             "srsran_hip_cellsearch_free": (None, [vp]),
             "srsran_hip_cellsearch_run": (i32, [vp, vp, u32, i32, vp, vp]),

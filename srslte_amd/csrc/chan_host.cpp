@@ -1,0 +1,502 @@
+// chan_host.cpp -- one device call per grant (include/srsran_amd/phy_chan_abi.h): the stages between the resource grid and the transport
+// block of srsran_pusch_decode (pusch.c:358-478), srsran_pdsch_decode / _encode (pdsch.c:662-760, 949-1015) and srsran_ulsch_encode
+// (sch.c:1194) chained on the calling thread's transport-block stream, nothing but the inputs and the results crossing the bus.
+#include "chan_device.h"
+#include "hip_common.h"
+#include "modem_device.h"
+#include "sch_stage.h"
+#include "srsran_amd/phy_chan_abi.h"
+
+#include <cmath>
+#include <map>
+#include <vector>
+
+using namespace phyhip;
+
+namespace {
+
+inline uint32_t qm_of(uint32_t mod)
+{
+  return mod == 0 ? 1u : 2u * mod;
+}
+inline uint32_t qm_rm(const srsran_hip_grant_tb_t& tb) // what decode_tb / encode_tb get as Qm (sch.c:590,632)
+{
+  return qm_of(tb.mod) * (tb.nl ? tb.nl : 1u);
+}
+
+// per calling thread: pinned images the kernels read the grant's symbols / channel estimates from and write transmit symbols into, device
+// scratch between the front-end kernels, the transform plans of the allocation sizes seen so far
+struct ChanStage {
+  uint8_t* pin     = nullptr;
+  size_t   pin_cap = 0;
+  uint8_t* dev     = nullptr;
+  size_t   dev_cap = 0;
+  std::map<uint32_t, srsran_hip_dft_batch_t*> idft; // L_prb -> backward, normalised plan of 12 L_prb points (srsran_dft_precoding_init_rx)
+  ~ChanStage()
+  {
+    for (auto& kv : idft) {
+      srsran_hip_dft_batch_free(kv.second);
+    }
+    (void)hipFree(dev);
+    (void)hipHostFree(pin);
+  }
+  bool grow(size_t need_pin, size_t need_dev)
+  {
+    if (need_pin > pin_cap) {
+      (void)hipHostFree(pin);
+      pin     = nullptr;
+      pin_cap = 0;
+      if (host_image_alloc(&pin, need_pin + need_pin / 2) != hipSuccess) {
+        return false;
+      }
+      pin_cap = need_pin + need_pin / 2;
+    }
+    if (need_dev > dev_cap) {
+      (void)hipFree(dev);
+      dev     = nullptr;
+      dev_cap = 0;
+      if (hipMalloc((void**)&dev, need_dev + need_dev / 2) != hipSuccess) {
+        return false;
+      }
+      dev_cap = need_dev + need_dev / 2;
+    }
+    return true;
+  }
+  srsran_hip_dft_batch_t* plan(uint32_t L_prb)
+  {
+    auto it = idft.find(L_prb);
+    if (it != idft.end()) {
+      return it->second;
+    }
+    srsran_hip_dft_batch_t* h = nullptr;
+    if (srsran_hip_dft_batch_create(&h, (int)(12 * L_prb), SRSRAN_DFT_BACKWARD, false, false, true) != SRSRAN_SUCCESS) {
+      return nullptr;
+    }
+    idft[L_prb] = h;
+    return h;
+  }
+};
+
+ChanStage& stage()
+{
+  static thread_local ChanStage s;
+  return s;
+}
+
+inline size_t al256(size_t v)
+{
+  return (v + 255) & ~(size_t)255;
+}
+
+bool tb_valid(const srsran_hip_grant_tb_t& tb, const char* who)
+{
+  if (tb.mod > SRSRAN_MOD_256QAM || tb.nl > 2 || tb.nof_re == 0 || tb.tbs == 0 || (tb.tbs & 7u) || tb.rv > 3 ||
+      (uint64_t)tb.nof_re * qm_of(tb.mod) > SRSRAN_HIP_SEQUENCE_MAX_LEN) {
+    set_error("%s: invalid grant (mod %u, %u REs, tbs %u, rv %u)", who, tb.mod, tb.nof_re, tb.tbs, tb.rv);
+    fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
+    return false;
+  }
+  return true;
+}
+
+// the receive front end of one grant, enqueued on `st`: [equaliser] -> [transform de-precoding] -> demodulator + descrambler (+ UL channel
+// de-interleaver in its store) -> d_e.  p_sym / p_ce: the grant's REs in the pinned image; d_x / d_z: device scratch of nof_re points each.
+bool enqueue_rx_front(hipStream_t st, const srsran_hip_grant_tb_t& tb, const uint8_t* p_sym, const uint8_t* p_ce, float scaling, float noise, uint32_t L_prb,
+                      uint32_t nof_symb, uint8_t* d_x, uint8_t* d_z, srsran_hip_dft_batch_t* plan, void* d_e)
+{
+  const uint8_t* cur = p_sym;
+  if (p_ce) {
+    if (modem::launch_eq(p_sym, p_ce, d_x, nullptr, tb.nof_re, scaling, noise, st) != hipSuccess) {
+      set_error("grant front end: equaliser launch failed");
+      return false;
+    }
+    cur = d_x;
+  }
+  if (L_prb) {
+    if (srsran_hip_dft_batch_run(plan, (const cf_t*)cur, (cf_t*)d_z, nof_symb, st) != SRSRAN_SUCCESS) {
+      return false;
+    }
+    cur = d_z;
+  }
+  modem::Params p;
+  if (!modem::params_for(p, tb.llr_is_8bit ? modem::LLR_I8 : modem::LLR_I16)) {
+    return false;
+  }
+  p.in      = cur;
+  p.out     = d_e;
+  p.single  = modem::Job{tb.mod, tb.nof_re, 0, 0, tb.seed, 1u, 0, modem::tiles_of(tb.mod, tb.nof_re), L_prb ? 12 * L_prb : 0u, L_prb ? nof_symb : 0u};
+  p.n_jobs  = 1;
+  p.n_tiles = p.single.ntiles;
+  if (modem::launch(p, st) != hipSuccess) {
+    set_error("grant front end: demodulator launch failed");
+    return false;
+  }
+  return true;
+}
+
+// srsran_vec_avg_power_cf over n points (a measurement: plain left-to-right float sums, not the reference's SIMD order)
+float avg_power(const float* x, size_t n)
+{
+  double acc = 0;
+  for (size_t i = 0; i < 2 * n; i++) {
+    acc += (double)x[i] * x[i];
+  }
+  return n ? (float)(acc / (double)n) : 0.f;
+}
+
+struct PuschPlan { // one grant of a (multi-)call
+  uint32_t                nof_symb = 0;
+  size_t                  o_sym = 0, o_ce = 0, o_x = 0, o_z = 0;
+  srsran_cbsegm_t         seg;
+  srsran_hip_sch_head_t   head;
+  srsran_hip_dft_batch_t* plan = nullptr;
+  sch::FrontEnd           front;
+};
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ PUSCH receive
+
+extern "C" int srsran_hip_pusch_decode_multi(uint32_t n, const srsran_hip_pusch_rx_t* g, const cf_t* const* sf_symbols, const cf_t* const* ce,
+                                             srsran_softbuffer_rx_t* const* softbuffers, uint8_t* const* data, srsran_hip_grant_res_t* res)
+{
+  if (n == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  if (!g || !sf_symbols || !ce || !softbuffers || !data || !res) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pusch_decode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  ChanStage&             s = stage();
+  std::vector<PuschPlan> pl(n);
+  size_t                 pin_need = 0, dev_need = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const srsran_hip_pusch_rx_t& x = g[i];
+    res[i] = {0, 0.f, NAN};
+    if (!tb_valid(x.tb, "srsran_hip_pusch_decode") || !sf_symbols[i] || !ce[i] || !softbuffers[i] || !data[i]) {
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    const uint32_t nsymb = 2 * (x.cp_nsymb - 1) - (x.shortened ? 1u : 0u);
+    if ((x.cp_nsymb != 7 && x.cp_nsymb != 6) || x.L_prb == 0 || !srsran_dft_precoding_valid_prb(x.L_prb) || x.n_prb_tilde[0] + x.L_prb > x.cell_nof_prb ||
+        x.n_prb_tilde[1] + x.L_prb > x.cell_nof_prb || x.tb.nof_re != nsymb * 12 * x.L_prb || x.tb.mod < SRSRAN_MOD_QPSK || x.tb.mod > SRSRAN_MOD_64QAM) {
+      set_error("srsran_hip_pusch_decode: grant %u: allocation (%u PRB at %u / %u of %u, %u REs, mod %u) is not a PUSCH allocation", i, x.L_prb, x.n_prb_tilde[0],
+                x.n_prb_tilde[1], x.cell_nof_prb, x.tb.nof_re, x.tb.mod);
+      fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    PuschPlan& p = pl[i];
+    p.nof_symb   = nsymb;
+    if (srsran_cbsegm(&p.seg, x.tb.tbs) != SRSRAN_SUCCESS) {
+      fprintf(stderr, "Error computing segmentation for TBS=%d\n", x.tb.tbs); // sch.c:1133-1136
+      return SRSRAN_ERROR;
+    }
+    const size_t nb = al256((size_t)x.tb.nof_re * sizeof(cf_t));
+    p.o_sym = pin_need;
+    p.o_ce  = pin_need + nb;
+    pin_need += 2 * nb;
+    p.o_x = dev_need;
+    p.o_z = dev_need + nb;
+    dev_need += 2 * nb;
+    p.plan = s.plan(x.L_prb);
+    if (!p.plan) {
+      return SRSRAN_ERROR;
+    }
+  }
+  if (!s.grow(pin_need, dev_need)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pusch_decode: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  std::vector<sch::TbItem> items(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const srsran_hip_pusch_rx_t& x = g[i];
+    PuschPlan&                   p = pl[i];
+    // pusch.c:48-104 (pusch_get): the allocation's 12 L_prb sub-carriers of every symbol but the slot's reference symbol (and the SRS symbol)
+    const uint32_t L_ref = x.cp_nsymb == 7 ? 3 : 2;
+    const size_t   wid   = (size_t)x.L_prb * 12 * sizeof(cf_t);
+    size_t         at    = 0;
+    for (uint32_t slot = 0; slot < 2; slot++) {
+      const uint32_t nl = x.cp_nsymb - ((x.shortened && slot == 1) ? 1u : 0u);
+      for (uint32_t l = 0; l < nl; l++) {
+        if (l == L_ref) {
+          continue;
+        }
+        const size_t idx = ((size_t)(l + slot * x.cp_nsymb) * x.cell_nof_prb + x.n_prb_tilde[slot]) * 12;
+        memcpy(s.pin + p.o_sym + at, sf_symbols[i] + idx, wid);
+        memcpy(s.pin + p.o_ce + at, ce[i] + idx, wid);
+        at += wid;
+      }
+    }
+    if (x.meas_epre) {
+      res[i].epre = avg_power(reinterpret_cast<const float*>(s.pin + p.o_sym), x.tb.nof_re); // pusch.c:397-401
+    }
+    p.head = {x.tb.max_nof_iterations, 0.f, x.tb.llr_is_8bit != 0};
+    const srsran_hip_grant_tb_t tb = x.tb;
+    const uint8_t *psym = s.pin + p.o_sym, *pce = s.pin + p.o_ce;
+    uint8_t *      dx = s.dev + p.o_x, *dz = s.dev + p.o_z;
+    const float    noise = x.noise_estimate;
+    const uint32_t L_prb = x.L_prb, nsymb = p.nof_symb;
+    auto*          plan  = p.plan;
+    p.front = [=](hipStream_t st, void* d_e) { return enqueue_rx_front(st, tb, psym, pce, 1.0f, noise, L_prb, nsymb, dx, dz, plan, d_e); };
+    items[i] = {&p.head, softbuffers[i], &p.seg, qm_rm(x.tb), x.tb.rv, x.tb.nof_re * qm_of(x.tb.mod), nullptr, &p.front, data[i], false};
+  }
+  sch::decode_tbs_staged(items.data(), n);
+  for (uint32_t i = 0; i < n; i++) {
+    res[i].crc_ok               = items[i].ok ? 1 : 0;
+    res[i].avg_iterations_block = pl[i].head.avg_iterations;
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_pusch_decode(const srsran_hip_pusch_rx_t* g, const cf_t* sf_symbols, const cf_t* ce, srsran_softbuffer_rx_t* softbuffer,
+                                       uint8_t* data, srsran_hip_grant_res_t* res)
+{
+  return srsran_hip_pusch_decode_multi(1, g, &sf_symbols, &ce, &softbuffer, &data, res);
+}
+
+// ------------------------------------------------------------------------------------------------ PDSCH receive, one codeword
+
+extern "C" int srsran_hip_pdsch_decode(const srsran_hip_pdsch_rx_t* g, const cf_t* symbols, const cf_t* ce, srsran_softbuffer_rx_t* softbuffer,
+                                       uint8_t* data, srsran_hip_grant_res_t* res)
+{
+  return srsran_hip_pdsch_decode_dbg(g, symbols, ce, softbuffer, data, res, nullptr, nullptr);
+}
+
+extern "C" int srsran_hip_pdsch_decode_dbg(const srsran_hip_pdsch_rx_t* g, const cf_t* symbols, const cf_t* ce, srsran_softbuffer_rx_t* softbuffer,
+                                           uint8_t* data, srsran_hip_grant_res_t* res, cf_t* d_out, void* e_out)
+{
+  if (!g || !symbols || !softbuffer || !data || !res) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  *res = {0, 0.f, NAN};
+  if (!tb_valid(g->tb, "srsran_hip_pdsch_decode") || (ce && !(g->scaling != 0.f))) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pdsch_decode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  ChanStage&      s = stage();
+  srsran_cbsegm_t seg;
+  if (srsran_cbsegm(&seg, g->tb.tbs) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "Error computing segmentation for TBS=%d\n", g->tb.tbs);
+    return SRSRAN_ERROR;
+  }
+  const size_t nb = al256((size_t)g->tb.nof_re * sizeof(cf_t));
+  const size_t ne = (size_t)g->tb.nof_re * qm_of(g->tb.mod) * (g->tb.llr_is_8bit ? 1 : 2);
+  if (!s.grow(3 * nb + al256(ne), nb)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pdsch_decode: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  memcpy(s.pin, symbols, (size_t)g->tb.nof_re * sizeof(cf_t));
+  if (ce) {
+    memcpy(s.pin + nb, ce, (size_t)g->tb.nof_re * sizeof(cf_t));
+  }
+  srsran_hip_sch_head_t       head = {g->tb.max_nof_iterations, 0.f, g->tb.llr_is_8bit != 0};
+  const srsran_hip_grant_tb_t tb   = g->tb;
+  const uint8_t *             psym = s.pin, *pce = ce ? s.pin + nb : nullptr;
+  uint8_t*                    dx = s.dev;
+  const float                 scaling = g->scaling, noise = g->noise_estimate;
+  uint8_t *                   p_d = s.pin + 2 * nb, *p_e = s.pin + 3 * nb;
+  const bool                  want_d = d_out && ce, want_e = e_out != nullptr;
+  const sch::FrontEnd front = [=](hipStream_t st, void* d_e) {
+    if (!enqueue_rx_front(st, tb, psym, pce, scaling, noise, 0, 0, dx, nullptr, nullptr, d_e)) {
+      return false;
+    }
+    // what the reference leaves in q->d / q->e for its callers to look at
+    if ((want_d && hipMemcpyAsync(p_d, dx, (size_t)tb.nof_re * sizeof(cf_t), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        (want_e && hipMemcpyAsync(p_e, d_e, ne, hipMemcpyDeviceToHost, st) != hipSuccess)) {
+      set_error("grant front end: copy of the intermediate results failed");
+      return false;
+    }
+    return true;
+  };
+  const bool ok = sch::decode_tb_staged(&head, softbuffer, &seg, qm_rm(tb), tb.rv, tb.nof_re * qm_of(tb.mod), nullptr, &front, data);
+  if (want_d) {
+    memcpy(d_out, p_d, (size_t)tb.nof_re * sizeof(cf_t));
+  }
+  if (want_e) {
+    memcpy(e_out, p_e, ne);
+  }
+  res->crc_ok               = ok ? 1 : 0;
+  res->avg_iterations_block = head.avg_iterations;
+  return SRSRAN_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------ transmit side
+
+namespace {
+bool enqueue_mod(hipStream_t st, const uint8_t* d_bits, uint32_t mod, uint32_t n, uint32_t seed, bool scramble, float scale, uint8_t* p_out)
+{
+  modem::Params sp;
+  if (!modem::params_for(sp, modem::LLR_I16)) {
+    return false;
+  }
+  const float2* tab = modem::mod_tables();
+  if (!tab) {
+    return false;
+  }
+  modem::ModParams p;
+  p.bits     = d_bits;
+  p.out      = reinterpret_cast<float2*>(p_out);
+  p.table    = tab;
+  p.mod      = mod;
+  p.n        = n;
+  p.seed     = seed;
+  p.scramble = scramble ? 1u : 0u;
+  p.scale    = scale;
+  p.x1_bits  = sp.x1_bits;
+  p.x2_cols  = sp.x2_cols;
+  if (modem::launch_mod(p, st) != hipSuccess) {
+    set_error("modulator launch failed");
+    return false;
+  }
+  return true;
+}
+} // namespace
+
+extern "C" int srsran_hip_pdsch_encode(const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, cf_t* symbols)
+{
+  return srsran_hip_pdsch_encode_dbg(g, softbuffer, data, symbols, nullptr);
+}
+
+extern "C" int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, cf_t* symbols, uint8_t* e_out)
+{
+  if (!g || !softbuffer || !symbols) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!tb_valid(g->tb, "srsran_hip_pdsch_encode")) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pdsch_encode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  ChanStage&      s = stage();
+  srsran_cbsegm_t seg;
+  if (srsran_cbsegm(&seg, g->tb.tbs) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "Error computing segmentation for TBS=%d\n", g->tb.tbs); // sch.c:637-640
+    return SRSRAN_ERROR;
+  }
+  const size_t nb = (size_t)g->tb.nof_re * sizeof(cf_t);
+  const size_t nw = (((size_t)g->tb.nof_re * qm_of(g->tb.mod) + 31) / 32) * 4; // scrambled bits, whole words
+  if (!s.grow(al256(nb) + al256(nw), al256(nw))) {
+    return SRSRAN_ERROR;
+  }
+  const srsran_hip_grant_tb_t tb    = g->tb;
+  uint8_t *                   pout = s.pin, *p_e = s.pin + al256(nb), *d_scr = s.dev;
+  const float                 scale = g->scaling != 0.f ? g->scaling : 1.0f;
+  const bool                  want_e = e_out != nullptr;
+  const sch::BackEnd          back  = [=](hipStream_t st, const uint8_t* d_e) {
+    if (!want_e) {
+      return enqueue_mod(st, d_e, tb.mod, tb.nof_re, tb.seed, true, scale, pout);
+    }
+    // the scrambled bits are wanted by themselves (q->e): scramble in packed form, hand that to the modulator and to the host
+    modem::Params sp;
+    if (!modem::params_for(sp, modem::LLR_I16)) {
+      return false;
+    }
+    if (modem::launch_scramble_packed(d_e, d_scr, tb.nof_re * qm_of(tb.mod), tb.seed, sp.x1_bits, sp.x2_cols, st) != hipSuccess ||
+        hipMemcpyAsync(p_e, d_scr, nw, hipMemcpyDeviceToHost, st) != hipSuccess) {
+      set_error("packed scrambler launch failed");
+      return false;
+    }
+    return enqueue_mod(st, d_scr, tb.mod, tb.nof_re, 0, false, scale, pout);
+  };
+  const int rc = sch::encode_tb_staged(softbuffer, &seg, qm_rm(tb), tb.rv, tb.nof_re * qm_of(tb.mod), data, nullptr, &back);
+  if (rc != SRSRAN_SUCCESS) {
+    return rc;
+  }
+  memcpy(symbols, s.pin, nb);
+  if (want_e) {
+    memcpy(e_out, p_e, ((size_t)tb.nof_re * qm_of(tb.mod) + 7) / 8);
+  }
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_ulsch_encode(const srsran_hip_grant_tb_t* tbp, uint32_t nof_symb, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, uint8_t* q_bits)
+{
+  if (!tbp || !softbuffer || !q_bits) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  const srsran_hip_grant_tb_t tb = *tbp;
+  if (!tb_valid(tb, "srsran_hip_ulsch_encode") || nof_symb == 0 || tb.nof_re % nof_symb || tb.mod < SRSRAN_MOD_QPSK || tb.mod > SRSRAN_MOD_64QAM) {
+    fprintf(stderr, "Invalid input\n"); // sch.c:1213-1221
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_ulsch_encode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  ChanStage&      s = stage();
+  srsran_cbsegm_t seg;
+  if (srsran_cbsegm(&seg, tb.tbs) != SRSRAN_SUCCESS) {
+    fprintf(stderr, "Error computing segmentation for TBS=%d\n", tb.tbs); // sch.c:1224-1228
+    return SRSRAN_ERROR;
+  }
+  const uint32_t Qm = qm_of(tb.mod);
+  const size_t   nb = ((size_t)tb.nof_re * Qm + 7) / 8;
+  if (!s.grow(al256(nb), 0)) {
+    return SRSRAN_ERROR;
+  }
+  uint8_t*           pout = s.pin;
+  const sch::BackEnd back = [=](hipStream_t st, const uint8_t* d_e) {
+    if (chan::launch_ul_interleave_bits(d_e, pout, tb.nof_re, Qm, nof_symb, st) != hipSuccess) {
+      set_error("channel interleaver launch failed");
+      return false;
+    }
+    return true;
+  };
+  const int rc = sch::encode_tb_staged(softbuffer, &seg, Qm, tb.rv, tb.nof_re * Qm, data, nullptr, &back);
+  if (rc != SRSRAN_SUCCESS) {
+    return rc;
+  }
+  memcpy(q_bits, s.pin, nb);
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_modulate_bytes(uint32_t mod, const uint8_t* bits, cf_t* symbols, uint32_t nbits, uint32_t seed, uint32_t scramble, float scaling)
+{
+  if (mod > SRSRAN_MOD_256QAM || !bits || !symbols) {
+    return -1;
+  }
+  const uint32_t Qm = qm_of(mod);
+  if (nbits % Qm) {
+    fprintf(stderr, "Error modulator expects number of bits (%d) to be multiple of %d\n", nbits, Qm); // mod.c:141-144
+    return -1;
+  }
+  const uint32_t n = nbits / Qm;
+  if (n == 0) {
+    return 0;
+  }
+  if (scramble && nbits > SRSRAN_HIP_SEQUENCE_MAX_LEN) {
+    return -1;
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_modulate_bytes: %s (there is no CPU fallback)\n", get_error());
+    return -1;
+  }
+  bind_thread();
+  hipStream_t st = sch::stage_stream();
+  ChanStage&  s  = stage();
+  const size_t o_out = al256((nbits + 7) / 8 + 1);
+  if (!st || !s.grow(o_out + (size_t)n * sizeof(cf_t), 0)) {
+    return -1;
+  }
+  memcpy(s.pin, bits, (nbits + 7) / 8);
+  if (!enqueue_mod(st, s.pin, mod, n, seed, scramble != 0, scaling != 0.f ? scaling : 1.0f, s.pin + o_out)) {
+    (void)hipStreamSynchronize(st);
+    return -1;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    return -1;
+  }
+  memcpy(symbols, s.pin + o_out, (size_t)n * sizeof(cf_t));
+  return (int)n;
+}

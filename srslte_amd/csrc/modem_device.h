@@ -26,6 +26,11 @@ struct Job {
   uint32_t scramble;
   uint32_t tile0; // first workgroup of this job
   uint32_t ntiles;
+  // UL-SCH channel de-interleaver (TS 36.212 5.2.2.8; sch.c:995-1018 ulsch_deinterleave without RI bits) folded into the store: the job's symbols
+  // are a matrix of il_cols SC-FDMA symbols x il_rows sub-carriers read column by column (symbol s = column s / il_rows, row s % il_rows);
+  // the soft bits of symbol s go to symbol slot (s % il_rows) * il_cols + s / il_rows (row by row).  0 = none.
+  uint32_t il_rows;
+  uint32_t il_cols;
 };
 
 struct Consts { // thresholds of demod_soft.c, evaluated by the host compiler exactly as the reference's are
@@ -49,6 +54,32 @@ struct Params {
   const uint32_t* x2_cols;  // MODEM_SEQ_NCHUNKS x 31
   Consts          k;
 };
+
+// ---- modulator: packed bits (MSB first) -> scrambling with c_init = seed (optional) -> constellation point (x scale), what
+// pdsch.c:1005-1018 chains as srsran_sequence_pdsch_apply_pack + srsran_mod_modulate_bytes (+ srsran_vec_sc_prod_cfc, :1119)
+struct ModParams {
+  const uint8_t*  bits;    // nof_symbols * Qm bits, byte packed, MSB first
+  float2*         out;     // nof_symbols constellation points
+  const float2*   table;   // constellation tables of all modulations (mod_table_offset)
+  uint32_t        mod;     // srsran_mod_t
+  uint32_t        n;       // symbols
+  uint32_t        seed;    // c_init
+  uint32_t        scramble;
+  float           scale;   // 1.0f: none
+  const uint32_t* x1_bits;
+  const uint32_t* x2_cols;
+};
+__host__ __device__ inline uint32_t mod_table_offset(uint32_t mod) // BPSK 2 | QPSK 4 | 16-QAM 16 | 64-QAM 64 | 256-QAM 256 points
+{
+  return mod == 0 ? 0u : (mod == 1 ? 2u : (mod == 2 ? 6u : (mod == 3 ? 22u : 86u)));
+}
+hipError_t launch_mod(const ModParams& p, hipStream_t stream);
+// srsran_sequence_apply_packed (sequence.c): out = in ^ c, byte-packed bits, MSB first; nbits is rounded up to whole 32-bit words (both buffers must hold them)
+hipError_t launch_scramble_packed(const uint8_t* in, uint8_t* out, uint32_t nbits, uint32_t seed, const uint32_t* x1_bits, const uint32_t* x2_cols, hipStream_t stream);
+// host side (modem_host.cpp): parameter block with the sequence tables and thresholds filled in; the constellation tables on the device
+bool          params_for(Params& p, int llr_type);
+const float2* mod_tables();
+void          host_mod_table(uint32_t mod, float2* out);
 
 uint32_t   tiles_of(uint32_t mod, uint32_t n);
 hipError_t launch(const Params& p, hipStream_t stream);

@@ -111,6 +111,80 @@ bool fill_params(modem::Params& p, int llr_type)
   return seq_tables(&p.x1_bits, &p.x2_cols);
 }
 
+// ---- constellation tables of TS 36.211 7.1.1-7.1.5 as lib/src/phy/modem/lte_tables.c:30-181 evaluates them (same float expressions on the host
+// compiler: levels k / sqrtf(10 | 42 | 170), (float)M_SQRT1_2), index = the symbol's bits, first bit most significant
+struct ModTables {
+  std::mutex mu;
+  float2*    d      = nullptr;
+  bool       failed = false;
+};
+ModTables g_mod;
+
+void build_mod_tables(std::vector<float2>& t)
+{
+  t.assign(2 + 4 + 16 + 64 + 256, make_float2(0.f, 0.f));
+  const float l2 = (float)M_SQRT1_2;
+  t[0] = make_float2(l2, l2); // BPSK: 0 -> (1 + j) / sqrt 2
+  t[1] = make_float2(-l2, -l2);
+  for (int i = 0; i < 4; i++) { // QPSK: b0 -> sign of I, b1 -> sign of Q
+    t[2 + i] = make_float2((i & 2) ? -l2 : l2, (i & 1) ? -l2 : l2);
+  }
+  const float q16[2] = {1.0f / sqrtf(10.0f), 3.0f / sqrtf(10.0f)};
+  for (int i = 0; i < 16; i++) { // b0 b1 signs, b2 b3 outer level
+    const float re = q16[(i >> 1) & 1], im = q16[i & 1];
+    t[6 + i]       = make_float2((i & 8) ? -re : re, (i & 4) ? -im : im);
+  }
+  const float q64[4] = {3.0f / sqrtf(42.0f), 1.0f / sqrtf(42.0f), 5.0f / sqrtf(42.0f), 7.0f / sqrtf(42.0f)}; // (b2 b4) / (b3 b5) = 00 01 10 11
+  for (int i = 0; i < 64; i++) {
+    const float re = q64[((i >> 3) & 1) * 2 + ((i >> 1) & 1)], im = q64[((i >> 2) & 1) * 2 + (i & 1)];
+    t[22 + i]      = make_float2((i & 32) ? -re : re, (i & 16) ? -im : im);
+  }
+  for (int i = 0; i < 256; i++) { // lte_tables.c:162-181: the nested form (1 - 2 b0) [8 - (1 - 2 b2) [4 - (1 - 2 b4) [2 - (1 - 2 b6)]]] built from the inside
+    float off = -1, re = 0, im = 0;
+    for (int j = 0; j < 4; j++) {
+      re += off;
+      im += off;
+      off *= 2;
+      re *= (i & (1 << (2 * j + 1))) ? +1 : -1;
+      im *= (i & (1 << (2 * j))) ? +1 : -1;
+    }
+    t[86 + i] = make_float2(re / sqrtf(170), im / sqrtf(170));
+  }
+}
+
+} // namespace
+
+namespace phyhip {
+namespace modem {
+bool params_for(Params& p, int llr_type)
+{
+  return fill_params(p, llr_type);
+}
+const float2* mod_tables()
+{
+  std::lock_guard<std::mutex> lk(g_mod.mu);
+  if (!g_mod.d && !g_mod.failed) {
+    std::vector<float2> t;
+    build_mod_tables(t);
+    if (hipMalloc(&g_mod.d, t.size() * sizeof(float2)) != hipSuccess || upload(g_mod.d, t.data(), t.size() * sizeof(float2)) != hipSuccess) {
+      set_error("modem: cannot allocate the constellation tables on the device");
+      g_mod.failed = true;
+      g_mod.d      = nullptr;
+    }
+  }
+  return g_mod.d;
+}
+void host_mod_table(uint32_t mod, float2* out)
+{
+  std::vector<float2> t;
+  build_mod_tables(t);
+  memcpy(out, t.data() + mod_table_offset(mod), sizeof(float2) << (mod == 0 ? 1 : 2 * mod));
+}
+} // namespace modem
+} // namespace phyhip
+
+namespace {
+
 // ---- host-pointer calls: one job, thread-local staging ----------------------------------------------------------------------
 struct Stage {
   hipStream_t st       = nullptr;

@@ -179,14 +179,14 @@ __device__ __forceinline__ void wave_sync_lds()
 // One lane per 128 chips: x2 register at the chunk start = XOR of the table columns the seed selects, 8 steps of 16
 // chips; the seed-independent x1 chips come packed from a table.  Waves work independently (no workgroup barrier): while
 // one runs its shift registers the others stream.
-__device__ __forceinline__ void make_chips(const Params& p, uint32_t seed, uint32_t bit0, uint32_t nbits, uint32_t* cbw)
+__device__ __forceinline__ void make_chips(const uint32_t* x1_bits, const uint32_t* x2_cols, uint32_t seed, uint32_t bit0, uint32_t nbits, uint32_t* cbw)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t nch  = (nbits + MODEM_SEQ_CHUNK - 1) / MODEM_SEQ_CHUNK;
   if (lane < nch) {
     const uint32_t  j   = bit0 / MODEM_SEQ_CHUNK + lane;
-    const uint32_t* col = p.x2_cols + (size_t)j * 31;
-    const uint4     c1  = *(const uint4*)(p.x1_bits + (size_t)j * (MODEM_SEQ_CHUNK / 32));
+    const uint32_t* col = x2_cols + (size_t)j * 31;
+    const uint4     c1  = *(const uint4*)(x1_bits + (size_t)j * (MODEM_SEQ_CHUNK / 32));
     uint32_t        s2  = 0;
 #pragma unroll
     for (int i = 0; i < 31; i++) {
@@ -345,7 +345,7 @@ __device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint
     x[r]             = s < job.n ? sym[s] : make_float2(0.f, 0.f);
   }
   if (job.scramble & 1u) { // the symbol loads are in flight while the first lanes run the shift registers
-    make_chips(p, job.seed, w0 * QM, min((MODEM_TILE_SYMS / 4) * QM, (job.n - w0) * QM), cbw);
+    make_chips(p.x1_bits, p.x2_cols, job.seed, w0 * QM, min((MODEM_TILE_SYMS / 4) * QM, (job.n - w0) * QM), cbw);
   }
 #pragma unroll
   for (int r = 0; r < R; r++) {
@@ -373,7 +373,10 @@ __device__ __forceinline__ void demod_tile(const Params& p, const Job& job, uint
         v[i] = flip<T>(v[i], (c >> i) & 1u);
       }
     }
-    if (STAGE && al && full) {
+    if (job.il_rows) { // UL channel de-interleaver: symbol s of column-major order -> its row-major slot (modem_device.h)
+      const uint32_t col = s / job.il_rows;
+      store_bits<T, QM>(out + (size_t)((s - col * job.il_rows) * job.il_cols + col) * QM, v, false);
+    } else if (STAGE && al && full) {
       store_bits_staged<T, QM>(out + (size_t)sw * QM, v, strip);
     } else {
       store_bits<T, QM>(out + (size_t)s * QM, v, al);
@@ -395,7 +398,7 @@ __device__ __forceinline__ void pass_tile(const Params& p, const Job& job, uint3
     return;
   }
   if (job.scramble & 1u) {
-    make_chips(p, job.seed, w0, min(MODEM_TILE_BITS / 4, job.n - w0), cbw);
+    make_chips(p.x1_bits, p.x2_cols, job.seed, w0, min(MODEM_TILE_BITS / 4, job.n - w0), cbw);
   }
 #pragma unroll
   for (uint32_t r = 0; r < MODEM_TILE_BITS / 4 / (64 * V); r++) {
@@ -469,6 +472,100 @@ __global__ __launch_bounds__(256) void modem_kernel(const Params p)
   }
 }
 
+// ---- modulator: one workgroup = MODEM_TILE_SYMS symbols, a quarter per wave; the wave's chips as in demod_tile
+template <int MOD>
+__device__ __forceinline__ void mod_tile(const ModParams& p, uint32_t* cbw)
+{
+  constexpr int  QM   = MOD == 0 ? 1 : 2 * MOD;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w0   = blockIdx.x * MODEM_TILE_SYMS + (threadIdx.x >> 6) * (MODEM_TILE_SYMS / 4);
+  if (w0 >= p.n) {
+    return;
+  }
+  if (p.scramble) {
+    make_chips(p.x1_bits, p.x2_cols, p.seed, w0 * QM, min((MODEM_TILE_SYMS / 4) * QM, (p.n - w0) * QM), cbw);
+  }
+  const float2*  tab    = p.table + mod_table_offset(MOD);
+  const uint32_t nbytes = (p.n * QM + 7) / 8;
+#pragma unroll
+  for (int r = 0; r < (int)(MODEM_TILE_SYMS / 256); r++) {
+    const uint32_t s = w0 + r * 64u + lane;
+    if (s >= p.n) {
+      continue;
+    }
+    const uint32_t b  = s * QM, by = b >> 3;
+    const uint32_t hi = p.bits[by], lo = by + 1 < nbytes ? p.bits[by + 1] : 0u;
+    uint32_t       v  = (((hi << 8) | lo) >> (16 - QM - (b & 7u))) & ((1u << QM) - 1u); // bit 0 of the symbol = MSB of v
+    if (p.scramble) {
+      const uint32_t c = chips_at(cbw, (r * 64u + lane) * QM); // chip i of the symbol in bit i
+#pragma unroll
+      for (int i = 0; i < QM; i++) {
+        v ^= ((c >> i) & 1u) << (QM - 1 - i);
+      }
+    }
+    float2 o = tab[v];
+    if (p.scale != 1.0f) {
+      o.x = __fmul_rn(o.x, p.scale);
+      o.y = __fmul_rn(o.y, p.scale);
+    }
+    p.out[s] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void mod_kernel(const ModParams p)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t cb[4][MODEM_TILE_BITS / 128 + 4];
+  if ((threadIdx.x & 63u) == 0) {
+    cb[threadIdx.x >> 6][MODEM_TILE_BITS / 128] = 0;
+  }
+  __syncthreads();
+  uint32_t* cbw = cb[threadIdx.x >> 6];
+  switch (p.mod) {
+    case 0:
+      mod_tile<0>(p, cbw);
+      break;
+    case 1:
+      mod_tile<1>(p, cbw);
+      break;
+    case 2:
+      mod_tile<2>(p, cbw);
+      break;
+    case 3:
+      mod_tile<3>(p, cbw);
+      break;
+    default:
+      mod_tile<4>(p, cbw);
+      break;
+  }
+}
+
+// ---- scrambling of byte-packed bits: one workgroup = MODEM_TILE_BITS bits, a quarter per wave, two words per lane
+__global__ __launch_bounds__(256) void scramble_packed_kernel(const uint32_t* in, uint32_t* out, uint32_t nwords, uint32_t seed, const uint32_t* x1_bits,
+                                                              const uint32_t* x2_cols)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t cb[4][MODEM_TILE_BITS / 128 + 4];
+  if ((threadIdx.x & 63u) == 0) {
+    cb[threadIdx.x >> 6][MODEM_TILE_BITS / 128] = 0;
+  }
+  __syncthreads();
+  uint32_t*      cbw  = cb[threadIdx.x >> 6];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w0   = (blockIdx.x * MODEM_TILE_BITS + (threadIdx.x >> 6) * (MODEM_TILE_BITS / 4)) / 32u; // first word of this wave
+  if (w0 >= nwords) {
+    return;
+  }
+  make_chips(x1_bits, x2_cols, seed, w0 * 32u, min(MODEM_TILE_BITS / 4, (nwords - w0) * 32u), cbw);
+#pragma unroll
+  for (uint32_t r = 0; r < MODEM_TILE_BITS / 4 / 32 / 64; r++) {
+    const uint32_t lw = r * 64u + lane;
+    if (w0 + lw < nwords) {
+      // chip i of the word sits in bit i; the packed bits are MSB first inside every byte: reverse the word, then its bytes
+      const uint32_t c = __builtin_bswap32(__brev(cbw[lw]));
+      out[w0 + lw]     = in[w0 + lw] ^ c;
+    }
+  }
+}
+
 // ---- single-antenna ZF / MMSE equaliser: srsran_predecoding_single (mimo/precoding.c:196-392), the float formulas of its AVX
 // body: x = (y conj(h)) / (|h|^2 + noise) * (1 / scaling); two symbols (one dwordx4 of y and of h) per lane
 __global__ __launch_bounds__(256) void eq_kernel(const float4* y, const float4* h, float4* x, float2* csi, uint32_t n, float inv_scaling,
@@ -520,6 +617,26 @@ hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t
   }
   hipLaunchKernelGGL(eq_kernel, dim3(ceil_div(ceil_div(n, 2u), 256u)), dim3(256), 0, stream, (const float4*)y, (const float4*)h, (float4*)x,
                      (float2*)csi, n, 1.0f / scaling, noise, (csi != nullptr || noise > 0.f) ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_mod(const ModParams& p, hipStream_t stream)
+{
+  if (p.n == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(mod_kernel, dim3(ceil_div(p.n, MODEM_TILE_SYMS)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_scramble_packed(const uint8_t* in, uint8_t* out, uint32_t nbits, uint32_t seed, const uint32_t* x1_bits, const uint32_t* x2_cols, hipStream_t stream)
+{
+  const uint32_t nwords = ceil_div(nbits, 32u);
+  if (nwords == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(scramble_packed_kernel, dim3(ceil_div(nwords * 32u, MODEM_TILE_BITS)), dim3(256), 0, stream, (const uint32_t*)in, (uint32_t*)out, nwords, seed,
+                     x1_bits, x2_cols);
   return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include "rm_device.h"
 #include "srsran_amd/phy_sch_abi.h"
 #include "turbo_device.h"
+#include "sch_stage.h"
 
 #include <algorithm>
 #include <map>
@@ -522,136 +523,316 @@ inline bool all_zero(const uint8_t* p, size_t n)
 
 } // namespace
 
-extern "C" bool srsran_hip_decode_tb_cb(void* qv, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv,
-                                        uint32_t nof_e_bits, void* e_bits, uint8_t* data)
+namespace {
+TbStage& tb_stage()
 {
-  auto* q = static_cast<srsran_hip_sch_head_t*>(qv);
-  if (!q || !softbuffer || !cb_segm || !e_bits || !data || Qm == 0 || rv > 3) {
-    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: invalid arguments\n");
-    return false;
-  }
-  const uint32_t C = cb_segm->C;
-  if (C > 32) { // SRSRAN_MAX_CODEBLOCKS, sch.c:382-385
-    fprintf(stderr, "Error SRSRAN_MAX_CODEBLOCKS=%d\n", 32);
-    return false;
-  }
-  q->avg_iterations = 0; // sch.c:387
-  if (C == 0 || C > softbuffer->max_cb) {
-    return false;
-  }
   static thread_local TbStage s;
+  return s;
+}
+} // namespace
+
+namespace phyhip {
+namespace sch {
+// the calling thread's transport-block stream (created on first use); nullptr without a device
+hipStream_t stage_stream()
+{
+  TbStage& s = tb_stage();
+  return s.ready() ? s.st : nullptr;
+}
+} // namespace sch
+} // namespace phyhip
+
+// decode_tb_cb for n transport blocks on the thread's stage: ONE upload, one de-matching and one early-stop decoder launch per block size over the code
+// blocks of ALL of them, one transport-CRC launch, one download, one host wait (a second one only when a code block failed and its combined soft bits
+// have to come back for the next transmission).  The e bits of a block are either the caller's host array (`e_bits`) or -- `front` given -- produced
+// ON THE DEVICE by the kernels `front(stream, d_e_bits)` enqueues in front of the de-matcher (chan_host.cpp: equaliser, transform de-precoding,
+// demodulator + descrambler never leave the device).  One call takes blocks of one soft-bit width, one iteration limit and one kind of e-bit source;
+// a mixed list is decoded piece by piece.
+static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n)
+{
+  using phyhip::sch::TbItem;
+  for (uint32_t t = 0; t < n; t++) {
+    it[t].ok = false;
+  }
+  TbStage& s = tb_stage();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s (there is no CPU fallback)\n", get_error());
-    return false;
+    return;
   }
-  const bool   llr8 = q->llr_is_8bit;
+  auto*        q0   = static_cast<srsran_hip_sch_head_t*>(it[0].q);
+  const bool   llr8 = q0->llr_is_8bit;
+  const bool   dev_e = it[0].front != nullptr;
   const size_t es   = llr8 ? 1 : 2;
   const size_t row  = (size_t)SRSRAN_HIP_SOFTBUFFER_CB_SIZE * es;
   auto         al   = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t o_soft = 0, o_e = al(o_soft + C * row), o_data = al(o_e + (size_t)nof_e_bits * es);
-  const size_t n_data = cb_segm->tbs / 8 + 6; // the last block's K/8 bytes end 3 bytes behind the transport CRC (:424 writes whole blocks)
-  if (!s.grow(al(o_data + n_data))) {
-    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: staging allocation failed\n");
-    return false;
-  }
-  // per code block: size, payload bytes, soft-buffer span (the layout srsran_rm_turbo_rx_lut{,_8bit} fills for the AUTO decoder of that size)
-  uint8_t  flags[32];
-  uint32_t span[32], rbytes[32];
-  bool     any_flag = false, any_soft = false;
-  int      first = -1, last = -1;
-  for (uint32_t i = 0; i < C; i++) {
-    const uint32_t K   = i < cb_segm->C1 ? cb_segm->K1 : cb_segm->K2;
-    const uint32_t nsb = llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K);
-    span[i]   = nsb ? 3 * (K + 32) + 12 : 3 * K + 12;
-    rbytes[i] = (C == 1 ? K : K - 24) / 8;
-    flags[i]  = softbuffer->cb_crc[i] ? 1 : 0;
-    if (flags[i]) {
-      any_flag = true;
-      // decoded in an earlier round: its stored bytes (sch.c:466-471), which the transport CRC on the device needs too
-      memcpy(s.pin + o_data + (size_t)i * rbytes[i], softbuffer->data[i], rbytes[i]);
-    } else {
-      any_soft = any_soft || !all_zero(reinterpret_cast<const uint8_t*>(softbuffer->buffer_f[i]), span[i] * es);
-      first    = first < 0 ? (int)i : first;
-      last     = (int)i;
-    }
-  }
-  if (any_soft || any_flag) { // a retransmission: the rows hold the earlier transmissions' soft bits
-    for (uint32_t i = 0; i < C; i++) {
-      if (!flags[i]) {
-        memcpy(s.pin + o_soft + i * row, softbuffer->buffer_f[i], span[i] * es);
-      }
-    }
-  }
-  srsran_hip_tb_t    tb  = {cb_segm->tbs, Qm, rv, nof_e_bits, 0, 0, 0};
-  srsran_hip_tb_result_t res = {SRSRAN_ERROR, 0.f, 0};
-  if (first >= 0) {
-    memcpy(s.pin + o_e, e_bits, (size_t)nof_e_bits * es); // (the de-matcher reads them ONCE, coalesced: straight from the pinned image, no copy operation)
-    if (!any_soft && !any_flag) {
-      tb.rv |= SRSRAN_HIP_TB_NEW_DATA; // every row is still zero: the de-matcher writes the rows instead of accumulating into them
-    } else if (hipMemcpyAsync(s.dev + o_soft + first * row, s.pin + o_soft + first * row, (last - first) * row + span[last] * es, hipMemcpyHostToDevice,
-                              s.st) != hipSuccess) {
-      return false;
-    }
-    if (any_flag && hipMemcpyAsync(s.dev + o_data, s.pin + o_data, n_data, hipMemcpyHostToDevice, s.st) != hipSuccess) {
-      return false;
-    }
-  }
-  if (first < 0) {
-    // every code block was decoded in an earlier round (not a state the reference's callers produce: they reset a decoded block's soft buffer):
-    // nothing to launch, the stored bytes are the block (sch.c:466-471), no iteration is counted
-    for (uint32_t i = 0; i < C; i++) {
-      memcpy(&data[(size_t)i * rbytes[i]], softbuffer->data[i], rbytes[i]);
-    }
-    softbuffer->tb_crc = true;
-    return true;
-  }
-  // the decoded bytes come back in front of the call's one host wait; the combined soft bits only when a block failed (second wait, below)
-  const TailCopy tail[1] = {{s.pin + o_data, s.dev + o_data, n_data}};
-  const int rc = sch_decode(s.sch, s.pin + o_e, &tb, 1, q->max_iterations ? q->max_iterations : 1, s.dev + o_soft, flags, s.dev + o_data, &res, s.st, llr8, tail, 1);
-  if (rc != SRSRAN_SUCCESS) {
-    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());
-    return false;
-  }
-  int f_first = -1, f_last = -1; // still undecoded: their rows are the HARQ state the next transmission combines into
-  for (uint32_t i = 0; i < C; i++) {
-    if (!flags[i]) {
-      f_first = f_first < 0 ? (int)i : f_first;
-      f_last  = (int)i;
-    }
-  }
-  if (f_first >= 0 && (hipMemcpyAsync(s.pin + o_soft + f_first * row, s.dev + o_soft + f_first * row, (f_last - f_first) * row + span[f_last] * es,
-                                      hipMemcpyDeviceToHost, s.st) != hipSuccess ||
-                       hipStreamSynchronize(s.st) != hipSuccess)) {
-    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: download of the soft buffer rows failed\n");
-    return false;
-  }
-  // host side effects of sch.c:424-486
-  bool all_ok = true;
-  for (uint32_t i = 0; i < C; i++) {
-    if (softbuffer->cb_crc[i]) {
-      memcpy(&data[(size_t)i * rbytes[i]], softbuffer->data[i], rbytes[i]);
+  struct Plan {
+    uint32_t C = 0, slot0 = 0;        // code blocks, first soft-buffer row of this block in the image
+    size_t   o_e = 0, o_data = 0, n_data = 0;
+    uint8_t  flags[32];
+    uint32_t span[32], rbytes[32];
+    bool     any_flag = false, any_soft = false, live = false; // live: takes part in the launch
+    int      first = -1, last = -1;
+  };
+  std::vector<Plan> pl(n);
+  uint32_t          slots = 0;
+  for (uint32_t t = 0; t < n; t++) {
+    TbItem& x = it[t];
+    auto*   q = static_cast<srsran_hip_sch_head_t*>(x.q);
+    Plan&   p = pl[t];
+    const uint32_t C = x.seg->C;
+    q->avg_iterations = 0; // sch.c:387
+    if (C == 0) { // no code block: the loops of sch.c:389-486 do not run (0 / 0 is what the reference leaves in avg_iterations, too)
+      x.sb->tb_crc      = true;
+      q->avg_iterations = 0.f / 0.f;
+      x.ok              = true;
       continue;
     }
-    const uint32_t K = i < cb_segm->C1 ? cb_segm->K1 : cb_segm->K2;
-    memcpy(&data[(size_t)i * rbytes[i]], s.pin + o_data + (size_t)i * rbytes[i], i + 1 == C ? K / 8 : rbytes[i]);
-    if (flags[i]) {
-      softbuffer->cb_crc[i] = true;
-    } else {
-      all_ok = false;
-      // still undecoded: the next transmission combines into this row
-      memcpy(softbuffer->buffer_f[i], s.pin + o_soft + i * row, span[i] * es);
+    if (C > x.sb->max_cb) {
+      continue;
+    }
+    {
+      // the kernels' work lists are derived from the transport-block size: a segmentation that is not THE segmentation of cb_segm->tbs (a caller's
+      // hand-made struct) would index the per-block arrays below with two different block counts
+      srsran_cbsegm_t chk;
+      if (srsran_cbsegm(&chk, x.seg->tbs) != SRSRAN_SUCCESS || chk.C != C || chk.C1 != x.seg->C1 || chk.K1 != x.seg->K1 ||
+          (chk.C2 && chk.K2 != x.seg->K2) || chk.C2 != x.seg->C2) {
+        fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: cb_segm is not srsran_cbsegm(tbs = %u)\n", x.seg->tbs);
+        continue;
+      }
+    }
+    p.C     = C;
+    p.slot0 = slots;
+    slots += C;
+    p.live = true;
+  }
+  size_t off = al((size_t)slots * row);
+  for (uint32_t t = 0; t < n; t++) {
+    if (pl[t].live) {
+      pl[t].o_e = off;
+      off       = al(off + (size_t)it[t].nof_e_bits * es);
     }
   }
-  softbuffer->tb_crc = all_ok;
-  if (!all_ok) {
-    for (uint32_t i = 0; i < C; i++) {
-      if (softbuffer->cb_crc[i]) {
-        memcpy(softbuffer->data[i], &data[(size_t)i * rbytes[i]], rbytes[i]); // sch.c:476-484
+  const size_t o_data0 = off;
+  for (uint32_t t = 0; t < n; t++) {
+    if (pl[t].live) {
+      pl[t].o_data = off;
+      pl[t].n_data = it[t].seg->tbs / 8 + 6; // the last block's K/8 bytes end 3 bytes behind the transport CRC (:424 writes whole blocks)
+      off          = al(off + pl[t].n_data);
+    }
+  }
+  const size_t total = off;
+  if (slots == 0) {
+    return;
+  }
+  if (!s.grow(total)) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: staging allocation failed\n");
+    return;
+  }
+  std::vector<srsran_hip_tb_t>        tbs;
+  std::vector<srsran_hip_tb_result_t> res;
+  std::vector<uint32_t>               who; // item of each launched block
+  std::vector<uint8_t>                cbflags(slots, 1);
+  bool                                any_data_up = false;
+  for (uint32_t t = 0; t < n; t++) {
+    Plan& p = pl[t];
+    if (!p.live) {
+      continue;
+    }
+    TbItem&                 x  = it[t];
+    srsran_softbuffer_rx_t* sb = x.sb;
+    const size_t            o_soft = (size_t)p.slot0 * row;
+    // per code block: size, payload bytes, soft-buffer span (the layout srsran_rm_turbo_rx_lut{,_8bit} fills for the AUTO decoder of that size)
+    for (uint32_t i = 0; i < p.C; i++) {
+      const uint32_t K   = i < x.seg->C1 ? x.seg->K1 : x.seg->K2;
+      const uint32_t nsb = llr8 ? srsran_tdec_autoimp_get_subblocks_8bit(K) : srsran_tdec_autoimp_get_subblocks(K);
+      p.span[i]   = nsb ? 3 * (K + 32) + 12 : 3 * K + 12;
+      p.rbytes[i] = (p.C == 1 ? K : K - 24) / 8;
+      p.flags[i]  = sb->cb_crc[i] ? 1 : 0;
+      if (p.flags[i]) {
+        p.any_flag = true;
+        // decoded in an earlier round: its stored bytes (sch.c:466-471), which the transport CRC on the device needs too
+        memcpy(s.pin + p.o_data + (size_t)i * p.rbytes[i], sb->data[i], p.rbytes[i]);
+      } else {
+        p.any_soft = p.any_soft || !all_zero(reinterpret_cast<const uint8_t*>(sb->buffer_f[i]), p.span[i] * es);
+        p.first    = p.first < 0 ? (int)i : p.first;
+        p.last     = (int)i;
+      }
+    }
+    if (p.first < 0) {
+      // every code block was decoded in an earlier round (not a state the reference's callers produce: they reset a decoded block's soft buffer):
+      // nothing to launch, the stored bytes are the block (sch.c:466-471), no iteration is counted
+      for (uint32_t i = 0; i < p.C; i++) {
+        memcpy(&x.data[(size_t)i * p.rbytes[i]], sb->data[i], p.rbytes[i]);
+      }
+      sb->tb_crc = true;
+      x.ok       = true;
+      p.live     = false;
+      continue;
+    }
+    uint32_t rv = x.rv;
+    if (p.any_soft || p.any_flag) { // a retransmission: the rows hold the earlier transmissions' soft bits
+      for (uint32_t i = 0; i < p.C; i++) {
+        if (!p.flags[i]) {
+          memcpy(s.pin + o_soft + i * row, sb->buffer_f[i], p.span[i] * es);
+        }
+      }
+      if (hipMemcpyAsync(s.dev + o_soft + p.first * row, s.pin + o_soft + p.first * row, (p.last - p.first) * row + p.span[p.last] * es,
+                         hipMemcpyHostToDevice, s.st) != hipSuccess) {
+        (void)hipStreamSynchronize(s.st);
+        return;
+      }
+    } else {
+      rv |= SRSRAN_HIP_TB_NEW_DATA; // every row is still zero: the de-matcher writes the rows instead of accumulating into them
+    }
+    any_data_up = any_data_up || p.any_flag;
+    if (!dev_e) {
+      memcpy(s.pin + p.o_e, x.e_bits, (size_t)x.nof_e_bits * es); // (the de-matcher reads them ONCE, coalesced: straight from the pinned image, no copy operation)
+    }
+    for (uint32_t i = 0; i < p.C; i++) {
+      cbflags[p.slot0 + i] = p.flags[i];
+    }
+    // offsets in elements of the e-bit type from the image's start, data offsets in bytes from the data region's start
+    tbs.push_back({x.seg->tbs, x.Qm, rv, x.nof_e_bits, (uint32_t)(p.o_e / es), (uint32_t)(p.o_data - o_data0), p.slot0});
+    res.push_back({SRSRAN_ERROR, 0.f, 0});
+    who.push_back(t);
+  }
+  if (tbs.empty()) {
+    return;
+  }
+  if (any_data_up && hipMemcpyAsync(s.dev + o_data0, s.pin + o_data0, total - o_data0, hipMemcpyHostToDevice, s.st) != hipSuccess) {
+    (void)hipStreamSynchronize(s.st);
+    return;
+  }
+  if (dev_e) {
+    for (uint32_t t : who) {
+      if (!(*it[t].front)(s.st, s.dev + pl[t].o_e)) {
+        (void)hipStreamSynchronize(s.st); // nothing of a failed call may still be in flight when the next one re-uses the images
+        fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());
+        return;
       }
     }
   }
-  q->avg_iterations = res.avg_iterations;
-  return all_ok;
+  // the decoded bytes come back in front of the call's one host wait; the combined soft bits only when a block failed (second wait, below)
+  const TailCopy tail[1] = {{s.pin + o_data0, s.dev + o_data0, total - o_data0}};
+  const int      rc = sch_decode(s.sch, dev_e ? s.dev : s.pin, tbs.data(), (uint32_t)tbs.size(), q0->max_iterations ? q0->max_iterations : 1, s.dev,
+                                 cbflags.data(), s.dev + o_data0, res.data(), s.st, llr8, tail, 1);
+  if (rc != SRSRAN_SUCCESS) {
+    (void)hipStreamSynchronize(s.st);
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());
+    return;
+  }
+  // still undecoded: their rows are the HARQ state the next transmission combines into
+  bool second = false;
+  for (uint32_t t : who) {
+    Plan& p = pl[t];
+    int   f_first = -1, f_last = -1;
+    for (uint32_t i = 0; i < p.C; i++) {
+      if (!cbflags[p.slot0 + i]) {
+        f_first = f_first < 0 ? (int)i : f_first;
+        f_last  = (int)i;
+      }
+    }
+    if (f_first >= 0) {
+      const size_t o_soft = (size_t)p.slot0 * row;
+      if (hipMemcpyAsync(s.pin + o_soft + f_first * row, s.dev + o_soft + f_first * row, (f_last - f_first) * row + p.span[f_last] * es,
+                         hipMemcpyDeviceToHost, s.st) != hipSuccess) {
+        (void)hipStreamSynchronize(s.st);
+        fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: download of the soft buffer rows failed\n");
+        return;
+      }
+      second = true;
+    }
+  }
+  if (second && hipStreamSynchronize(s.st) != hipSuccess) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: download of the soft buffer rows failed\n");
+    return;
+  }
+  // host side effects of sch.c:424-486
+  for (size_t k = 0; k < who.size(); k++) {
+    const uint32_t          t  = who[k];
+    Plan&                   p  = pl[t];
+    TbItem&                 x  = it[t];
+    srsran_softbuffer_rx_t* sb = x.sb;
+    const size_t            o_soft = (size_t)p.slot0 * row;
+    bool                    all_ok = true;
+    for (uint32_t i = 0; i < p.C; i++) {
+      if (sb->cb_crc[i]) {
+        memcpy(&x.data[(size_t)i * p.rbytes[i]], sb->data[i], p.rbytes[i]);
+        continue;
+      }
+      const uint32_t K = i < x.seg->C1 ? x.seg->K1 : x.seg->K2;
+      memcpy(&x.data[(size_t)i * p.rbytes[i]], s.pin + p.o_data + (size_t)i * p.rbytes[i], i + 1 == p.C ? K / 8 : p.rbytes[i]);
+      if (cbflags[p.slot0 + i]) {
+        sb->cb_crc[i] = true;
+      } else {
+        all_ok = false;
+        // still undecoded: the next transmission combines into this row
+        memcpy(sb->buffer_f[i], s.pin + o_soft + i * row, p.span[i] * es);
+      }
+    }
+    sb->tb_crc = all_ok;
+    if (!all_ok) {
+      for (uint32_t i = 0; i < p.C; i++) {
+        if (sb->cb_crc[i]) {
+          memcpy(sb->data[i], &x.data[(size_t)i * p.rbytes[i]], p.rbytes[i]); // sch.c:476-484
+        }
+      }
+    }
+    static_cast<srsran_hip_sch_head_t*>(x.q)->avg_iterations = res[k].avg_iterations;
+    x.ok = all_ok;
+  }
+}
+
+void phyhip::sch::decode_tbs_staged(TbItem* it, uint32_t n)
+{
+  // validate, then cut the list into runs of blocks that can share a launch
+  for (uint32_t t = 0; t < n; t++) {
+    TbItem& x = it[t];
+    x.ok      = false;
+    if (!x.q || !x.sb || !x.seg || (!x.e_bits && !x.front) || !x.data || x.Qm == 0 || x.rv > 3) {
+      fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: invalid arguments\n");
+      x.seg = nullptr; // skipped below
+    } else if (x.seg->C > 32) { // SRSRAN_MAX_CODEBLOCKS, sch.c:382-385
+      fprintf(stderr, "Error SRSRAN_MAX_CODEBLOCKS=%d\n", 32);
+      x.seg = nullptr;
+    }
+  }
+  uint32_t a = 0;
+  while (a < n) {
+    if (!it[a].seg) {
+      a++;
+      continue;
+    }
+    auto*    qa = static_cast<srsran_hip_sch_head_t*>(it[a].q);
+    uint32_t b  = a + 1;
+    while (b < n && it[b].seg) {
+      auto* qb = static_cast<srsran_hip_sch_head_t*>(it[b].q);
+      if (qb->llr_is_8bit != qa->llr_is_8bit || qb->max_iterations != qa->max_iterations || (it[b].front != nullptr) != (it[a].front != nullptr)) {
+        break;
+      }
+      b++;
+    }
+    tbs_staged_homogeneous(it + a, b - a);
+    a = b;
+  }
+}
+
+bool phyhip::sch::decode_tb_staged(void* qv, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,
+                                   const void* e_bits, const FrontEnd* front, uint8_t* data)
+{
+  TbItem x = {qv, softbuffer, cb_segm, Qm, rv, nof_e_bits, e_bits, front, data, false};
+  decode_tbs_staged(&x, 1);
+  return x.ok;
+}
+
+extern "C" bool srsran_hip_decode_tb_cb(void* qv, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv,
+                                        uint32_t nof_e_bits, void* e_bits, uint8_t* data)
+{
+  if (!e_bits) {
+    fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: invalid arguments\n");
+    return false;
+  }
+  return phyhip::sch::decode_tb_staged(qv, softbuffer, cb_segm, Qm, rv, nof_e_bits, e_bits, nullptr, data);
 }
 
 extern "C" bool decode_tb_cb(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,

@@ -4,6 +4,7 @@
 #include "srsran_amd/phy_sch_abi.h"
 #include "tables/lte_qpp_table.h"
 #include "tcod_device.h"
+#include "sch_stage.h"
 
 #include <algorithm>
 #include <map>
@@ -598,7 +599,15 @@ struct TxTbStage {
 extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits,
                                     uint8_t* data, uint8_t* e_bits)
 {
-  if (!e_bits || !cb_segm || !softbuffer) {
+  return phyhip::sch::encode_tb_staged(softbuffer, cb_segm, Qm, rv, nof_e_bits, data, e_bits, nullptr);
+}
+
+// `back` given: the e bits stay on the device and the kernels back(stream, d_e_bits) enqueues consume them there (chan_host.cpp: scrambling +
+// modulation, or the UL channel interleaver) -- their results are the caller's to collect after this function's one host wait
+int phyhip::sch::encode_tb_staged(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, uint8_t* data,
+                                  uint8_t* e_bits, const BackEnd* back)
+{
+  if ((!e_bits && !back) || !cb_segm || !softbuffer) {
     fprintf(stderr, "Invalid parameters: e_bits=%d, cb_segm=%d, softbuffer=%d\n", e_bits != 0, cb_segm != 0, softbuffer != 0); // sch.c:351
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -654,8 +663,18 @@ extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_c
   // (the payload goes up with a copy operation: the CRC and encoder kernels read it byte-wise and more than once, which is slow across the bus)
   PHY_HIP_CHECK(hipMemcpyAsync(s.dev + d_pay, s.pin + o_pay, tbs / 8, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
   if (srsran_hip_sch_encode(s.enc, s.dev + d_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
+    (void)hipStreamSynchronize(s.st);
     fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
     return SRSRAN_ERROR;
+  }
+  if (back) {
+    const bool ok = (*back)(s.st, s.dev);
+    PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR); // (also after a failed enqueue: nothing may be in flight when the images are re-used)
+    if (!ok) {
+      fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
+      return SRSRAN_ERROR;
+    }
+    return SRSRAN_SUCCESS;
   }
   PHY_HIP_CHECK(hipMemcpyAsync(s.pin + o_e, s.dev, n_out, hipMemcpyDeviceToHost, s.st), SRSRAN_ERROR);
   PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR);

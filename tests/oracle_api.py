@@ -530,6 +530,34 @@ def sequence_apply(x, seed):
     return out
 
 
+def mod_table(mod):
+    """orc_mod_table: the 2^Qm constellation points of srsran_mod_t `mod` as complex64, index = bits MSB first"""
+    out = np.zeros(1 << QM[mod], np.complex64)
+    f = orc().orc_mod_table
+    f.argtypes = [C.c_int, C.c_void_p]
+    assert f(mod, P(out)) == out.size
+    return out
+
+
+def modulate_bytes(mod, packed, nbits, seed=0, scramble=False, scaling=1.0):
+    """orc_modulate_bytes: byte-packed bits -> [scrambling] -> constellation points x scaling (complex64)"""
+    packed = np.ascontiguousarray(packed, np.uint8)
+    out = np.zeros(nbits // QM[mod], np.complex64)
+    f = orc().orc_modulate_bytes
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_float]
+    assert f(mod, P(packed), P(out), nbits, seed, 1 if scramble else 0, scaling) == out.size
+    return out
+
+
+def ulsch_interleaver_lut(nof_sym, Qm, cols):
+    """orc_ulsch_interleaver_lut: lut[q position] = g position (36.212 5.2.2.8 without RI / ACK)"""
+    lut = np.zeros(nof_sym * Qm, np.uint32)
+    f = orc().orc_ulsch_interleaver_lut
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    assert f(nof_sym, Qm, cols, P(lut)) == 0
+    return lut
+
+
 def pusch_seed(rnti, nslot, cell_id):
     f = orc().orc_sequence_pusch_seed
     f.restype = C.c_uint32

@@ -89,3 +89,54 @@ def test_ctest_line_through_the_transport_block_seam(entry, data_dir):
     args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
     rc, out = run_program("bin_tb", entry["program"], args, data_dir, timeout=900)
     assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])
+
+
+# ---- the grant-level seam (tests/ref_link/Makefile target `chan`, tests/ref_link/chan_bind.c): on top of the transport-block seam, srsran_pusch_decode,
+# srsran_pdsch_decode, srsran_pdsch_encode and srsran_ulsch_encode of the unmodified pusch.o / pdsch.o / sch.o renamed to <name>_ref and the binding in
+# their place: a grant the device path takes is ONE device call (include/srsran_amd/phy_chan_abi.h); UCI on PUSCH, several ports / codewords on the PDSCH
+# receive side fall through to the renamed originals.  CHAN_BIND_REPORT=1 makes the binding print how many grants went which way.
+CHAN_PROGRAMS = {"pusch_test", "pdsch_test", "pmch_test", "phy_dl_test", "pdsch_pdcch_file_test"}
+
+
+def _selected_chan():
+    full = os.environ.get("REF_CTEST_FULL", "0") == "1"
+    seen = {}
+    for e in MANIFEST:
+        if e["program"] not in CHAN_PROGRAMS:
+            continue
+        n = seen.get(e["program"], 0)
+        seen[e["program"]] = n + 1
+        if e["program"] == "phy_dl_test":
+            if full or _phy_dl_default(e):
+                yield e
+        elif full or e["program"] != "pdsch_test" or n % 4 == 0:
+            yield e
+
+
+def _device_share(out):
+    import re
+
+    m = re.search(r"\[chan_bind\] pusch_decode dev (\d+) ref (\d+) \| pdsch_decode dev (\d+) ref (\d+) \| pdsch_encode dev (\d+) ref (\d+) \| ulsch_encode dev (\d+) ref (\d+)", out)
+    return [int(v) for v in m.groups()] if m else None
+
+
+@pytest.mark.parametrize("entry", list(_selected_chan()), ids=lambda e: "chan:%s:%s" % (e["program"], e["name"]))
+def test_ctest_line_through_the_grant_seam(entry, data_dir):
+    args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
+    os.environ["CHAN_BIND_REPORT"] = "1"
+    try:
+        rc, out = run_program("bin_chan", entry["program"], args, data_dir, timeout=900)
+    finally:
+        del os.environ["CHAN_BIND_REPORT"]
+    assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])
+    share = _device_share(out)
+    assert share is not None, out[-1500:]
+    pu_d, pu_r, pdd_d, pdd_r, pde_d, pde_r, ul_d, ul_r = share
+    a = entry["args"]
+    if entry["program"] == "pusch_test":
+        uci = any(x in a for x in ("uci_ack", "cqi", "uci_ri"))
+        assert (pu_r > 0 and pu_d == 0) if uci else (pu_d > 0 and pu_r == 0 and ul_d > 0 and ul_r == 0), (a, share)
+    if entry["program"] == "phy_dl_test":
+        tm = int(a[a.index("-t") + 1])
+        assert pde_d > 0 and pde_r == 0, (a, share)  # every transport block is encoded on the device, whatever the transmission mode
+        assert (pdd_d > 0 and pdd_r == 0) if tm == 1 else (pdd_r > 0), (a, share)  # one port, one antenna: decoded in one call too

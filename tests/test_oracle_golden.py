@@ -368,3 +368,29 @@ def test_decode_tb_restatement_against_the_reference_objects():
                 ok, _, avg = chain.decode_tb(tbs, Qm, 0, e, soft_r, crc_r)
                 ret, _, a2 = O.sch_decode_tb(tbs, Qm, 0, e, soft_o, crc_o, 10, cb_data=data_o)
                 assert np.array_equal(crc_r, crc_o) and abs(avg - a2) < 1e-6 and (0 if ok else -1) == ret, (llr8, tbs, snr, avg, a2)
+
+
+def test_modulator_restatement_against_the_reference_tables():
+    """orc_mod_table / orc_modulate_bytes (lte_tables.c, mod.c:135-166, srsran_sequence_apply_packed) against what the reference's
+    srsran_mod_modulate_bytes produced (tests/golden/mod_ref.npz, tools/gen_golden.py mod): every constellation point of the five tables, bit for bit
+    as float32, and seeded bits scrambled in packed form first; plus the interleaver's involution property"""
+    d = np.load(os.path.join(G, "mod_ref.npz"))
+    for m in range(5):
+        qm = O.QM[m]
+        bits, sym = d["walk_bits_%d" % m], d["walk_sym_%d" % m]
+        got = O.modulate_bytes(m, bits, sym.size * qm)
+        assert np.array_equal(got.view(np.uint32), sym.view(np.uint32)), m
+        if (1 << qm) * qm % 8 == 0:
+            assert np.array_equal(O.mod_table(m).view(np.uint32), sym[:1 << qm].view(np.uint32)), m
+        seed, nb = [int(v) for v in d["rand_seed_%d" % m]]
+        got = O.modulate_bytes(m, d["rand_bits_%d" % m], nb, seed=seed, scramble=True)
+        assert np.array_equal(got.view(np.uint32), d["rand_sym_%d" % m].view(np.uint32)), m
+        # unit average power of the whole constellation (36.211 7.1)
+        assert abs(np.mean(np.abs(O.mod_table(m).astype(np.complex128)) ** 2) - 1.0) < 1e-6
+    for nof_sym, Qm, cols in ((144, 2, 12), (132, 4, 11), (1200, 6, 12), (14400, 6, 12)):
+        lut = O.ulsch_interleaver_lut(nof_sym, Qm, cols)
+        assert np.array_equal(np.sort(lut), np.arange(nof_sym * Qm))  # a permutation
+        rows = nof_sym // cols
+        q = np.arange(nof_sym * Qm)
+        s, k = q // Qm, q % Qm
+        assert np.array_equal(lut, ((s % rows) * cols + s // rows) * Qm + k)  # group (c rows + r) of q = group (r cols + c) of g

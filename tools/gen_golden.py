@@ -16,6 +16,7 @@ No reference source text is stored.
   tests/golden/modem_ref.npz   reference srsran_demod_soft_demodulate{,_s,_b} outputs on seeded symbols (all five
                                modulations, lengths around the SIMD group sizes, in- and out-of-range amplitudes);
                                scrambling chips recovered from srsran_sequence_apply_s / pusch / pdsch apply
+  tests/golden/mod_ref.npz     reference srsran_mod_modulate_bytes outputs (every constellation point of the five tables; seeded bits behind srsran_sequence_apply_packed)
   tests/golden/ldpc_tx_ref.npz reference LDPC encoder (C and AVX2: equal) code words with and without filler bits, srsran_ldpc_rm_tx
                                outputs and srsran_ldpc_rm_rx_{c,s,f} soft buffers (as CRC32) on stored inputs
   tests/golden/sch_tx_ref.npz  transmit side of transport blocks as encode_tb_off (sch.c:238-345) chains the reference's
@@ -568,6 +569,40 @@ def modem():
     print("modem_ref.npz", os.path.getsize(os.path.join(OUT, "modem_ref.npz")))
 
 
+def mod():
+    """tests/golden/mod_ref.npz: the reference's modulator -- srsran_modem_table_lte + srsran_modem_table_bytes + srsran_mod_modulate_bytes (mod.c:135-166) on
+    byte-packed bits that walk every constellation index, and on seeded bits behind srsran_sequence_apply_packed (sequence.c:609-650)"""
+    d = {}
+    rng = np.random.default_rng(77)
+    for m in range(5):
+        qm = O.QM[m]
+        t = C.create_string_buffer(4096)
+        assert ref.srsran_modem_table_lte(t, m) == 0
+        ref.srsran_modem_table_bytes(t)
+        idx = np.arange(1 << qm)
+        bits = ((idx[:, None] >> (qm - 1 - np.arange(qm))) & 1).astype(np.uint8).reshape(-1)
+        if bits.size % 8:
+            bits = np.concatenate([bits, np.zeros(8 - bits.size % 8, np.uint8)] * 4)[:8 * qm]  # BPSK / QPSK: a few repeats to fill bytes
+        packed = np.packbits(bits)
+        n = bits.size // qm
+        out = O.aligned_empty(n, np.complex64)
+        assert ref.srsran_mod_modulate_bytes(t, P(packed), P(out), C.c_uint32(bits.size)) == n
+        d["walk_bits_%d" % m], d["walk_sym_%d" % m] = packed, np.array(out)
+        # seeded bits, scrambled in packed form first (pdsch.c:1005-1018)
+        nsym = 1000 + 37 * m
+        nb = nsym * qm
+        raw = np.packbits(rng.integers(0, 2, (nb + 7) // 8 * 8).astype(np.uint8))
+        scr = np.zeros_like(raw)
+        seed = (0x1234 << 14) + (m << 13) + (3 << 9) + 301
+        ref.srsran_sequence_apply_packed(P(raw), P(scr), C.c_uint32(nb), C.c_uint32(seed))
+        out = O.aligned_empty(nsym, np.complex64)
+        assert ref.srsran_mod_modulate_bytes(t, P(scr), P(out), C.c_uint32(nb)) == nsym
+        d["rand_bits_%d" % m], d["rand_sym_%d" % m], d["rand_seed_%d" % m] = raw, np.array(out), np.array([seed, nb], np.int64)
+        ref.srsran_modem_table_free(t)
+    np.savez_compressed(os.path.join(OUT, "mod_ref.npz"), **d)
+    print("mod_ref.npz", os.path.getsize(os.path.join(OUT, "mod_ref.npz")))
+
+
 def sch_nr():
     """NR transport blocks as sch_nr.c chains the reference's blocks (sch_nr_encode :375-520, sch_nr_decode :522-713; segmentation by
     srsran_cbsegm_ldpc_bg1/2): payload -> e bits -> noisy int8 LLRs -> code-block verdicts, iterations, payload, TB CRC; one case
@@ -712,6 +747,6 @@ def sch_nr():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr", "sync_captures", "ref_link"]
+    which = sys.argv[1:] or ["turbo", "turbo8", "ldpc", "ldpc_fs", "syncglue", "rm", "modem", "ldpc_tx", "sch_tx", "ldpc_flood", "tcod_lut", "sch_nr", "sync_captures", "ref_link", "mod"]
     for name in which:
-        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr, "sync_captures": sync_captures, "ref_link": ref_link}[name]()
+        {"turbo": turbo, "turbo8": turbo8, "ldpc": ldpc, "ldpc_fs": ldpc_fs, "syncglue": syncglue, "rm": rm, "modem": modem, "ldpc_tx": ldpc_tx, "sch_tx": sch_tx, "ldpc_flood": ldpc_flood, "tcod_lut": tcod_lut, "sch_nr": sch_nr, "sync_captures": sync_captures, "ref_link": ref_link, "mod": mod}[name]()

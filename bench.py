@@ -35,6 +35,8 @@ import subprocess
 import sys
 import time
 
+# (before torch initialises the HIP runtime: worker threads overlap only on separate hardware queues, srslte_amd/csrc/common.cpp)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -20,6 +20,17 @@ extern "C" {
 /* ---- device plumbing for C hosts (thin wrappers over hipMalloc/hipMemcpy/hipStreamSynchronize) ---- */
 SRSRAN_API int         srsran_hip_device_count(void);
 SRSRAN_API int         srsran_hip_set_device(int device);
+/* N worker threads of ONE process on N GPUs (the reference runs its PHY workers as threads: lib/include/srsran/common/thread_pool.h:48):
+ * srsran_hip_set_thread_device(d) binds the CALLING thread to device d from now on, whatever srsran_hip_set_device named as the process
+ * default (which stays the device of every thread that has not bound itself); -1 returns the thread to the default.  Every handle, batch
+ * object and staging context records the device it was created on; an entry point called from a thread bound to another device returns an
+ * error (message through srsran_hip_last_error and on stderr) and launches nothing. */
+SRSRAN_API int         srsran_hip_set_thread_device(int device);
+SRSRAN_API int         srsran_hip_get_thread_device(void);
+/* Worker threads overlap their launches only when their streams sit on different hardware queues: the library puts GPU_MAX_HW_QUEUES=8 into the
+ * environment from a constructor unless a value is already there -- which the runtime reads at ITS initialisation.  0: the runtime had been initialised
+ * before the library was loaded (a note is printed once): set the variable in the environment instead.  1 otherwise. */
+SRSRAN_API int         srsran_hip_hw_queues_requested_in_time(void);
 SRSRAN_API void*       srsran_hip_malloc(size_t bytes);
 SRSRAN_API void        srsran_hip_free(void* dptr);
 SRSRAN_API int         srsran_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);

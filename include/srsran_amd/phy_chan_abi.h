@@ -98,6 +98,15 @@ SRSRAN_API int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsra
  * interleaver of 36.212 5.2.2.8 over nof_symb columns.  q_bits: nof_bits = nof_re * Qm bits, byte packed (what pusch.c:322 scrambles next). */
 SRSRAN_API int srsran_hip_ulsch_encode(const srsran_hip_grant_tb_t* tb, uint32_t nof_symb, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, uint8_t* q_bits);
 
+/* ---- warm start.  The first grant of a process / of a worker thread otherwise pays for loading the kernels' device code, creating the thread's staging
+ * context (stream, pinned and device images, decoder / encoder objects, transform plans) and building rate-matching tables: 20-28 ms where a warm
+ * call takes 0.1-0.4 ms.  srsran_hip_warmup(n) builds every rate-matching table and prepares n staging contexts by running real grants (the
+ * largest of a 100-PRB cell, a one-block and a scalar-decoder one; receive and transmit side; 16- and 8-bit soft bits) on short-lived threads; a worker
+ * thread adopts a prepared context at its first call.  srsran_rm_turbo_gentables() -- which srsran_sch_init calls (sch.c:166) -- does the same
+ * for one worker, so an application that does nothing gets a warm first subframe on one thread; srsenb's pool of nof_phy_threads workers
+ * wants srsran_hip_warmup(nof_phy_threads) once after its objects are created.  Idempotent; returns SRSRAN_ERROR without a device. */
+SRSRAN_API int srsran_hip_warmup(uint32_t nof_workers);
+
 /* modulator alone: srsran_mod_modulate_bytes (mod.c:135-166) of byte-packed bits with the tables of lte_tables.c, optional scrambling in front
  * (srsran_sequence_apply_pack) and scaling behind; HOST buffers.  Returns the number of symbols or -1. */
 SRSRAN_API int srsran_hip_modulate_bytes(uint32_t mod, const uint8_t* bits, cf_t* symbols, uint32_t nbits, uint32_t seed, uint32_t scramble, float scaling);

@@ -180,6 +180,8 @@ SRSRAN_API int  srsran_cfo_resize(srsran_cfo_t* h, uint32_t samples);
 SRSRAN_API void srsran_cfo_set_tol(srsran_cfo_t* h, float tol);
 SRSRAN_API void srsran_cfo_correct(srsran_cfo_t* h, const cf_t* input, cf_t* output, float freq);
 SRSRAN_API void srsran_cfo_correct_offset(srsran_cfo_t* h, const cf_t* input, cf_t* output, float freq, int cexp_offset, int nsamples);
+/* cfo.h:63, cfo.c:130-151: CP-based CFO estimate of one uplink subframe (nof_prb -> srsran_symbol_sz), corrected in place; returns the estimate in Hz */
+SRSRAN_API float srsran_cfo_est_corr_cp(cf_t* input_buffer, uint32_t nof_prb);
 
 /* ---- sync/cp.h:30-48 ---- */
 typedef struct {

@@ -5,11 +5,16 @@ sources in `csrc/`).  This package is only a thin ctypes mirror of that ABI for 
 Python callers: no computation happens in Python and there is no CPU fallback.
 """
 import ctypes as C
+import os
 
-import numpy as np
+# Worker threads overlap only when their streams sit on different hardware queues (csrc/common.cpp): the runtime reads GPU_MAX_HW_QUEUES when it
+# initialises, which in a Python process is often before the library is loaded (torch) -- so the package asks here, at import, unless a value is set.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from . import capi
-from .capi import lib  # noqa: F401
+import numpy as np  # noqa: E402
+
+from . import capi  # noqa: E402
+from .capi import lib  # noqa: F401,E402
 
 __all__ = ["capi", "lib", "DeviceBuffer", "TdecBatch", "LdpcBatch", "OfdmBatch"]
 

@@ -43,12 +43,62 @@ def _stale():
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [__file__])
 
 
+# The measured-and-rejected kernel alternatives (turbo launch shapes "waves1" / "persistent", PSS correlation kernels "pair" / "block": DESIGN.md
+# par. 3.2, 3.4) are NOT in the product library: the three kernel files that hold them are compiled a second time with SRSRAN_HIP_WITH_VARIANTS and
+# linked with the product's other objects into tools/probe/lib/libsrsran_phy_hip_variants.so, which tests/test_gpu_variants.py and the variant
+# measurements load through SRSRAN_HIP_LIB.
+VARIANTS_LIB = os.path.join(ROOT, "tools", "probe", "lib", "libsrsran_phy_hip_variants.so")
+VARIANT_SOURCES = ("turbo_kernels.hip", "pss_wave_kernels.hip", "sync_kernels.hip")
+
+
+def _flags_stamp(objdir, flags):
+    """objects are reused only when they were built by the same compiler with the same flags (a -D timing experiment must not leak into the product)"""
+    import hashlib
+
+    tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:16]
+    stamp = os.path.join(objdir, ".flags")
+    same = os.path.exists(stamp) and open(stamp).read().strip() == tag
+    if not same:
+        for f in glob.glob(os.path.join(objdir, "*.o")):
+            os.remove(f)
+        with open(stamp, "w") as fh:
+            fh.write(tag + "\n")
+    return same
+
+
+def build_variants(force=False, verbose=True, jobs=8):
+    build(force=False, verbose=verbose, jobs=jobs)
+    objs_product = [os.path.join(ROOT, "build", "obj", os.path.basename(s) + ".o") for s in SOURCES if os.path.basename(s) not in VARIANT_SOURCES]
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    objdir = os.path.join(ROOT, "build", "obj_variants")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(VARIANTS_LIB), exist_ok=True)
+    _flags_stamp(objdir, [hipcc] + FLAGS + ["-DSRSRAN_HIP_WITH_VARIANTS"])
+    procs, objs = [], []
+    for name in VARIANT_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(objdir, name + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(f) for f in [src, __file__] + HEADERS):
+            continue
+        cmd = [hipcc] + FLAGS + ["-DSRSRAN_HIP_WITH_VARIANTS"] + EXTRA_FLAGS.get(name, []) + ["-x", "hip", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    _drain(procs)
+    if force or not os.path.exists(VARIANTS_LIB) or any(os.path.getmtime(o) > os.path.getmtime(VARIANTS_LIB) for o in objs + objs_product):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", VARIANTS_LIB] + objs_product + objs + ["-ldl"])
+    return VARIANTS_LIB
+
+
 def build(force=False, verbose=True, jobs=8):
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "hipcc")
     objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(objdir, exist_ok=True)
+    if not _flags_stamp(objdir, [hipcc] + FLAGS + _DEV_FLAGS + [k + "=" + " ".join(v) for k, v in sorted(EXTRA_FLAGS.items())]):
+        force = True  # other flags than the objects in the tree were built with: everything is rebuilt
+    if not force and not _stale():
+        return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     procs = []
     objs = []
@@ -65,7 +115,7 @@ def build(force=False, verbose=True, jobs=8):
         if len(procs) >= jobs:
             _drain(procs)
     _drain(procs)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -84,3 +134,5 @@ def _drain(procs):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--variants" in sys.argv:
+        print(build_variants(force="--force" in sys.argv))

@@ -254,6 +254,9 @@ def lib():
         sig = {
             "srsran_hip_device_count": (i32, []),
             "srsran_hip_set_device": (i32, [i32]),
+            "srsran_hip_set_thread_device": (i32, [i32]),
+            "srsran_hip_get_thread_device": (i32, []),
+            "srsran_hip_warmup": (i32, [u32]),
             "srsran_hip_malloc": (vp, [C.c_size_t]),
             "srsran_hip_free": (None, [vp]),
             "srsran_hip_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),

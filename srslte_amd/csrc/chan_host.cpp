@@ -79,8 +79,8 @@ struct ChanStage {
 
 ChanStage& stage()
 {
-  static thread_local ChanStage s;
-  return s;
+  static thread_local StageRef<ChanStage> r;
+  return r.get();
 }
 
 inline size_t al256(size_t v)
@@ -160,6 +160,7 @@ struct PuschPlan { // one grant of a (multi-)call
 extern "C" int srsran_hip_pusch_decode_multi(uint32_t n, const srsran_hip_pusch_rx_t* g, const cf_t* const* sf_symbols, const cf_t* const* ce,
                                              srsran_softbuffer_rx_t* const* softbuffers, uint8_t* const* data, srsran_hip_grant_res_t* res)
 {
+  TraceRange trace_("srsran_hip_pusch_decode");
   if (n == 0) {
     return SRSRAN_SUCCESS;
   }
@@ -268,6 +269,7 @@ extern "C" int srsran_hip_pdsch_decode(const srsran_hip_pdsch_rx_t* g, const cf_
 extern "C" int srsran_hip_pdsch_decode_dbg(const srsran_hip_pdsch_rx_t* g, const cf_t* symbols, const cf_t* ce, srsran_softbuffer_rx_t* softbuffer,
                                            uint8_t* data, srsran_hip_grant_res_t* res, cf_t* d_out, void* e_out)
 {
+  TraceRange trace_("srsran_hip_pdsch_decode");
   if (!g || !symbols || !softbuffer || !data || !res) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -366,6 +368,7 @@ extern "C" int srsran_hip_pdsch_encode(const srsran_hip_pdsch_tx_t* g, srsran_so
 
 extern "C" int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, cf_t* symbols, uint8_t* e_out)
 {
+  TraceRange trace_("srsran_hip_pdsch_encode");
   if (!g || !softbuffer || !symbols) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -421,6 +424,7 @@ extern "C" int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsra
 
 extern "C" int srsran_hip_ulsch_encode(const srsran_hip_grant_tb_t* tbp, uint32_t nof_symb, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, uint8_t* q_bits)
 {
+  TraceRange trace_("srsran_hip_ulsch_encode");
   if (!tbp || !softbuffer || !q_bits) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -499,4 +503,139 @@ extern "C" int srsran_hip_modulate_bytes(uint32_t mod, const uint8_t* bits, cf_t
   }
   memcpy(symbols, s.pin + o_out, (size_t)n * sizeof(cf_t));
   return (int)n;
+}
+
+// ------------------------------------------------------------------------------------------------ warm start
+//
+// The first grant of a process used to cost 20-28 ms (profiles/r03_ref_programs.json: pdsch_test -X 1): the device code of every kernel on the path is
+// loaded at its first launch, the thread's staging contexts create their stream, pinned and device images, decoder and encoder objects, transform plans,
+// and every (block size, redundancy version) brings its rate-matching table.  The reference does that kind of work in srsran_sch_init (sch.c:159-197:
+// allocation, srsran_tdec_init, srsran_rm_turbo_gentables) -- so does the library: srsran_rm_turbo_gentables() builds every rate-matching table in
+// one allocation and warms ONE worker's contexts; srsran_hip_warmup(n) makes that n.  A warm context is made by running real calls -- the largest
+// grant of a 100-PRB cell, a one-block grant and a scalar-decoder grant, receive and transmit side, 16- and 8-bit soft bits -- on a short-lived
+// thread whose contexts go back to the pools (hip_common.h: StagePool) when it ends.
+
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+#include "turbo_device.h"
+namespace phyhip {
+namespace rm {
+bool build_all_tables(); // rm_host.cpp
+}
+} // namespace phyhip
+
+namespace {
+
+struct HostSoftbuffers {
+  std::vector<std::vector<int16_t>> rows;
+  std::vector<std::vector<uint8_t>> keep, txrows;
+  std::vector<int16_t*>             rp;
+  std::vector<uint8_t*>             kp, tp;
+  std::vector<uint8_t>              flags; // bool-sized
+  srsran_softbuffer_rx_t            rx;
+  srsran_softbuffer_tx_t            tx;
+  explicit HostSoftbuffers(uint32_t n) : rows(n), keep(n), txrows(n), rp(n), kp(n), tp(n), flags(n, 0)
+  {
+    for (uint32_t i = 0; i < n; i++) {
+      rows[i].assign(SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 0);
+      keep[i].assign(SRSRAN_HIP_SOFTBUFFER_CB_SIZE / 8, 0);
+      txrows[i].assign(SRSRAN_HIP_SOFTBUFFER_CB_SIZE, 0);
+      rp[i] = rows[i].data();
+      kp[i] = keep[i].data();
+      tp[i] = txrows[i].data();
+    }
+    rx = {n, SRSRAN_HIP_SOFTBUFFER_CB_SIZE, rp.data(), kp.data(), reinterpret_cast<bool*>(flags.data()), false};
+    tx = {n, SRSRAN_HIP_SOFTBUFFER_CB_SIZE, tp.data()};
+  }
+  void reset()
+  {
+    for (auto& r : rows) {
+      std::fill(r.begin(), r.end(), 0);
+    }
+    std::fill(flags.begin(), flags.end(), 0);
+  }
+};
+
+void warm_one_worker()
+{
+  const uint32_t nof_prb = 100, L_prb = 100, nsymb = 12;
+  // transport block sizes without filler bits: C blocks of K = 6144 carry C (6144 - 24) - 24 payload bits (C > 1), one block K - 24
+  const struct {
+    uint32_t tbs, mod, L;
+  } grants[] = {{13 * 6120 - 24, SRSRAN_MOD_64QAM, L_prb}, {6144 - 24, SRSRAN_MOD_16QAM, 12}, {40 - 24, SRSRAN_MOD_QPSK, 1}};
+  HostSoftbuffers      sb(13);
+  std::vector<cf_t>    grid((size_t)14 * 12 * nof_prb, cf_t(0.5f, -0.5f)), ce((size_t)14 * 12 * nof_prb, cf_t(1.f, 0.f)), sym((size_t)nsymb * 12 * L_prb);
+  std::vector<uint8_t> data(13 * 768 + 64, 0x5a), qbits((size_t)nsymb * 12 * L_prb * 6 / 8 + 8);
+  for (uint32_t llr8 = 0; llr8 < 2; llr8++) {
+    for (const auto& gr : grants) {
+      const uint32_t        nof_re = nsymb * 12 * gr.L;
+      srsran_hip_grant_tb_t tb     = {gr.mod, gr.tbs, 0, nof_re, 12345u, 1, llr8, 1};
+      srsran_hip_grant_res_t res;
+      // receive: PUSCH grant from the grid, PDSCH codeword with and without the equaliser
+      srsran_hip_pusch_rx_t pu = {tb, nof_prb, 7, {0, 0}, gr.L, 0, 0.01f, 0};
+      sb.reset();
+      (void)srsran_hip_pusch_decode(&pu, grid.data(), ce.data(), &sb.rx, data.data(), &res);
+      srsran_hip_pdsch_rx_t pd = {tb, 1.0f, 0.01f};
+      sb.reset();
+      (void)srsran_hip_pdsch_decode_dbg(&pd, grid.data(), ce.data(), &sb.rx, data.data(), &res, sym.data(), nullptr);
+      // (a retransmission: the rows that came back are combined into)
+      tb.rv = 2;
+      pd.tb = tb;
+      (void)srsran_hip_pdsch_decode(&pd, grid.data(), nullptr, &sb.rx, data.data(), &res);
+      tb.rv = 0;
+      if (!llr8) { // transmit
+        srsran_hip_pdsch_tx_t tx = {tb, 1.0f};
+        (void)srsran_hip_pdsch_encode_dbg(&tx, &sb.tx, data.data(), sym.data(), qbits.data());
+        (void)srsran_hip_ulsch_encode(&tb, nsymb, &sb.tx, data.data(), qbits.data());
+      }
+    }
+  }
+}
+
+struct WarmState { // per device
+  std::mutex mu;
+  uint32_t   workers = 0;
+};
+
+} // namespace
+
+extern "C" int srsran_hip_warmup(uint32_t nof_workers)
+{
+  if (!device_available()) {
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  WarmState&                  ws = device_local<WarmState>(); // of the calling thread's device
+  std::lock_guard<std::mutex> lk(ws.mu);
+  const int                   dev = current_device();
+  if (!rm::build_all_tables() || !turbo::prebuild_tables()) {
+    return SRSRAN_ERROR;
+  }
+  // the workers' contexts are made by threads that exist TOGETHER (a context goes back to the pool when its thread ends: one after the other they
+  // would all warm the same one)
+  const uint32_t have = ws.workers;
+  if (have < nof_workers) {
+    const uint32_t           n = nof_workers - have;
+    std::mutex               mu;
+    std::condition_variable  cv;
+    uint32_t                 done = 0;
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < n; i++) {
+      th.emplace_back([&] {
+        (void)srsran_hip_set_thread_device(dev);
+        warm_one_worker();
+        std::unique_lock<std::mutex> l(mu);
+        done++;
+        cv.notify_all();
+        cv.wait(l, [&] { return done == n; });
+      });
+    }
+    for (auto& t : th) {
+      t.join(); // their contexts are in the pools now
+    }
+    ws.workers = nof_workers;
+  }
+  return SRSRAN_SUCCESS;
 }

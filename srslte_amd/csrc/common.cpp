@@ -3,6 +3,8 @@
 #include "hip_common.h"
 
 #include <atomic>
+#include <dlfcn.h>
+#include <unistd.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -34,20 +36,90 @@ std::atomic<int> g_device{-1}; // -1: never chosen, every thread stays where HIP
 // their work one behind the other: three workers decoding a transport block each then take 249 us per call instead of 142, with eight queues
 // 146 (tools/probe/seam_threads.c, profiles/r03_seam_threads.txt).  Ask for eight -- before the runtime reads its settings at the process's
 // first HIP call, and only if the application or the user has not chosen a value.
+// The setting only counts when it is in the environment BEFORE the runtime initialises (its first API call in the process).  A host that has used
+// HIP before this library is loaded -- a Python process that imported torch and touched the GPU first -- keeps its four queues, and three workers then
+// serialise (236-249 us per transport block instead of 143-151, profiles/r03_seam_threads_pass.txt).  The runtime opens /dev/kfd when it
+// initialises: if that has happened by the time this constructor runs and nobody had set the variable, say so once (device_available()).
+// srslte_amd/__init__.py and bench.py put the variable into the environment themselves, before torch is imported.
+bool g_queues_too_late = false;
 __attribute__((constructor)) void more_hardware_queues()
 {
+  if (!getenv("GPU_MAX_HW_QUEUES")) {
+    char path[64], target[256];
+    for (int fd = 0; fd < 1024 && !g_queues_too_late; fd++) {
+      snprintf(path, sizeof(path), "/proc/self/fd/%d", fd);
+      const ssize_t n = readlink(path, target, sizeof(target) - 1);
+      if (n > 0) {
+        target[n] = 0;
+        g_queues_too_late = strcmp(target, "/dev/kfd") == 0;
+      }
+    }
+  }
   (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
 }
 }
 
+namespace {
+thread_local int t_device = -1; // srsran_hip_set_thread_device: this thread's device, whatever the process default
+thread_local int t_bound  = -1; // the logical device this thread's HIP context was last set to by us
+
+// development aid (SRSRAN_HIP_LOGICAL_DEVICES = n): n logical devices on whatever is installed, logical d -> physical d mod count.  The
+// per-device bookkeeping (tags, caches, pools) of a process that spreads its workers over several GPUs can then be exercised on a 1-GPU box.
+int physical_count()
+{
+  static int n = -1;
+  if (n < 0) {
+    int c = 0;
+    n     = (hipGetDeviceCount(&c) == hipSuccess) ? c : 0;
+  }
+  return n;
+}
+int logical_count()
+{
+  const int k = knob(KNOB_LOGICAL_DEVICES);
+  const int p = physical_count();
+  return (k > 0 && p > 0) ? (k > kMaxDevices ? kMaxDevices : k) : p;
+}
+int physical_of(int logical)
+{
+  const int p = physical_count();
+  return p > 0 ? logical % p : logical;
+}
+} // namespace
+
+int current_device()
+{
+  if (t_device >= 0) {
+    return t_device;
+  }
+  const int g = g_device.load(std::memory_order_relaxed);
+  if (g >= 0) {
+    return g;
+  }
+  int d = 0; // nobody chose: the thread is wherever HIP (or the application's own hipSetDevice) put it
+  return hipGetDevice(&d) == hipSuccess ? d : 0;
+}
+
 void bind_thread()
 {
-  static thread_local int bound = -1;
-  const int               want  = g_device.load(std::memory_order_relaxed);
-  if (want >= 0 && bound != want) {
-    (void)hipSetDevice(want);
-    bound = want;
+  const int want = t_device >= 0 ? t_device : g_device.load(std::memory_order_relaxed);
+  if (want >= 0 && t_bound != want) {
+    (void)hipSetDevice(physical_of(want));
+    t_bound = want;
   }
+}
+
+bool check_device(const DeviceTag& tag, const char* who)
+{
+  bind_thread();
+  const int here = current_device();
+  if (tag.dev == here || tag.dev < 0) {
+    return true;
+  }
+  set_error("%s: the object lives on device %d, the calling thread is bound to device %d (srsran_hip_set_thread_device / srsran_hip_set_device)", who, tag.dev,
+            here);
+  fprintf(stderr, "[srsran_phy_hip] %s\n", g_err);
+  return false;
 }
 
 bool device_available()
@@ -63,6 +135,10 @@ bool device_available()
       set_error("no HIP device available (%s); the PHY HIP engine has no CPU fallback",
                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
       fprintf(stderr, "[srsran_phy_hip] %s\n", g_err);
+    } else if (g_queues_too_late) {
+      fprintf(stderr, "[srsran_phy_hip] note: the HIP runtime was initialised before this library was loaded, so GPU_MAX_HW_QUEUES=8 could not be requested: "
+                      "with the default of 4 hardware queues more than two concurrent worker threads share queues and run one behind the other.  Set "
+                      "GPU_MAX_HW_QUEUES=8 in the environment, or load the library before the first HIP call.\n");
     }
   });
   if (!ok) {
@@ -71,9 +147,55 @@ bool device_available()
   return ok;
 }
 
+// ---- roctx ranges (hip_common.h)
+namespace {
+struct RoctxFns {
+  int (*push)(const char*) = nullptr;
+  int (*pop)()             = nullptr;
+};
+const RoctxFns* roctx_fns()
+{
+  static const RoctxFns* fns = [] () -> const RoctxFns* {
+    static RoctxFns f;
+    const char*     want = getenv("SRSRAN_HIP_ROCTX");
+    void*           lib  = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); // only what the profiler has already brought in ...
+      if (!lib && want && want[0] == '1') {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); // ... unless asked for
+      }
+      if (lib) {
+        break;
+      }
+    }
+    if (!lib) {
+      return nullptr;
+    }
+    f.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+    f.pop  = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+    return (f.push && f.pop) ? &f : nullptr;
+  }();
+  return fns;
+}
+} // namespace
+
+void trace_push(const char* name)
+{
+  if (const RoctxFns* f = roctx_fns()) {
+    (void)f->push(name);
+  }
+}
+void trace_pop()
+{
+  if (const RoctxFns* f = roctx_fns()) {
+    (void)f->pop();
+  }
+}
+
 // ---- development knobs (hip_common.h)
 namespace {
-const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED", "SRSRAN_HIP_TDEC_LAT"};
+const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED", "SRSRAN_HIP_TDEC_LAT",
+                                          "SRSRAN_HIP_LOGICAL_DEVICES"};
 std::atomic<int>  g_knob[KNOB_COUNT];
 std::atomic<bool> g_knob_read[KNOB_COUNT];
 
@@ -246,18 +368,46 @@ extern "C" uint32_t srsran_hip_coalesce_shapes(void)
 
 extern "C" int srsran_hip_device_count(void)
 {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) {
-    return 0;
-  }
-  return n;
+  return logical_count();
 }
 
 extern "C" int srsran_hip_set_device(int device)
 {
-  PHY_HIP_CHECK(hipSetDevice(device), SRSRAN_ERROR);
-  g_device.store(device, std::memory_order_relaxed); // worker threads follow (bind_thread)
+  if (device < 0 || device >= logical_count()) {
+    set_error("srsran_hip_set_device: no device %d (%d visible)", device, logical_count());
+    fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(hipSetDevice(physical_of(device)), SRSRAN_ERROR);
+  g_device.store(device, std::memory_order_relaxed); // the default of every thread that has not bound itself (bind_thread)
+  if (t_device < 0) {
+    t_bound = device;
+  }
   return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_set_thread_device(int device)
+{
+  if (device < 0) { // back to the process default
+    t_device = -1;
+    t_bound  = -1;
+    bind_thread();
+    return SRSRAN_SUCCESS;
+  }
+  if (device >= logical_count()) {
+    set_error("srsran_hip_set_thread_device: no device %d (%d visible)", device, logical_count());
+    fprintf(stderr, "[srsran_phy_hip] %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  PHY_HIP_CHECK(hipSetDevice(physical_of(device)), SRSRAN_ERROR);
+  t_device = device;
+  t_bound  = device;
+  return SRSRAN_SUCCESS;
+}
+
+extern "C" int srsran_hip_get_thread_device(void)
+{
+  return current_device();
 }
 
 extern "C" void* srsran_hip_malloc(size_t bytes)
@@ -303,6 +453,12 @@ extern "C" int srsran_hip_stream_sync(void* stream)
 extern "C" const char* srsran_hip_last_error(void)
 {
   return get_error();
+}
+
+// 1 when the library could ask for its hardware queues in time (or the application chose a value itself), 0 when the runtime was already initialised
+extern "C" int srsran_hip_hw_queues_requested_in_time(void)
+{
+  return g_queues_too_late ? 0 : 1;
 }
 
 extern "C" const char* srsran_hip_build_info(void)

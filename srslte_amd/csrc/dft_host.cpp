@@ -16,6 +16,7 @@ using namespace phyhip;
 namespace {
 
 struct DftCtx {
+  DeviceTag tag;
   int         N = 0;
   int         npass = 0;
   int         radix[16] = {};
@@ -272,9 +273,15 @@ int run_large(const DftCtx* c, const float2* d_in, float2* d_out, bool backward,
   return SRSRAN_SUCCESS;
 }
 
-DftCtx* ctx_of(srsran_dft_plan_t* plan)
+DftCtx* ctx_raw(srsran_dft_plan_t* plan)
 {
   return reinterpret_cast<DftCtx*>(plan->p);
+}
+// the plan's context -- nullptr (error reported) when it lives on another device than the calling thread's
+DftCtx* ctx_of(srsran_dft_plan_t* plan)
+{
+  DftCtx* c = ctx_raw(plan);
+  return (c && !check_device(c->tag, "srsran_dft")) ? nullptr : c;
 }
 
 void plan_defaults(srsran_dft_plan_t* plan, int n, srsran_dft_dir_t dir, bool guru)
@@ -434,7 +441,7 @@ extern "C" void srsran_dft_plan_free(srsran_dft_plan_t* plan)
     free(plan->in);
     free(plan->out);
   }
-  ctx_free(ctx_of(plan));
+  ctx_free(ctx_raw(plan));
   memset(plan, 0, sizeof(srsran_dft_plan_t));
 }
 
@@ -612,6 +619,7 @@ extern "C" int srsran_hip_dft_batch_run(srsran_hip_dft_batch_t* h, const cf_t* d
     set_error("dft batch: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
+  PHY_DEV_GUARD(h->c->tag, "srsran_hip_dft_batch_run", SRSRAN_ERROR);
   dft::Params p;
   fill_params(&p, h->c, d_in, d_out, h->backward, h->mirror, h->dc, h->norm, false);
   p.how_many = (int)how_many;

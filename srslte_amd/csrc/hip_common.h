@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "srsran_amd/phy_abi.h"
 #include "srsran_amd/phy_batch.h"
@@ -42,10 +44,34 @@ const char* get_error();
 // true when a HIP device is usable; prints one diagnostic otherwise
 bool device_available();
 
-// The device chosen with srsran_hip_set_device() is the PROCESS's device (one process per GPU): HIP keeps the current device per
-// thread and starts every new thread on device 0, so the handle-API entry points bind the calling worker thread to the process's
-// device before they touch a stream (a thread-local compare after the first call).
+// Devices.  srsran_hip_set_device(d) names the PROCESS's default device (one process per GPU: bench.py, the N-rank launches); a thread that calls
+// srsran_hip_set_thread_device(d) is bound to d from then on, whatever the default -- N worker threads of ONE process on N GPUs, the reference's
+// own threading model (lib/include/srsran/common/thread_pool.h:48, srsenb nof_phy_threads).  HIP keeps the current device per thread and starts every
+// new thread on device 0, so every entry point binds the calling thread first (bind_thread: a thread-local compare after the first call).
+// Everything that owns device memory or a stream RECORDS its device (DeviceTag) and every entry point compares it with the calling thread's
+// (check_device): a handle created on one device and used from a thread bound to another is refused with an error, never launched.  Process-wide
+// caches of device constants and the pools of staging contexts exist once per device (DeviceLocal).
 void bind_thread();
+int  current_device(); // the (logical) device the calling thread works on
+constexpr int kMaxDevices = 16;
+struct DeviceTag { // member of everything that owns device memory or a stream: stamped with the constructing thread's device
+  int dev;
+  DeviceTag() : dev(current_device()) {}
+};
+// false (error text set, one line on stderr) when `tag` is another device than the calling thread's
+bool check_device(const DeviceTag& tag, const char* who);
+#define PHY_DEV_GUARD(tag, who, retval)                                                                                \
+  do {                                                                                                                 \
+    if (!phyhip::check_device((tag), (who))) {                                                                         \
+      return retval;                                                                                                   \
+    }                                                                                                                  \
+  } while (0)
+#define PHY_DEV_GUARD_VOID(tag, who)                                                                                   \
+  do {                                                                                                                 \
+    if (!phyhip::check_device((tag), (who))) {                                                                         \
+      return;                                                                                                          \
+    }                                                                                                                  \
+  } while (0)
 
 // Table uploads (object creation, first use of a new block size / generator).  A hipMemcpy from pageable memory returns when the HOST
 // buffer may be reused; a small copy is staged and reaches the device in null-stream order -- and every kernel of this library runs on
@@ -81,9 +107,121 @@ enum Knob {
   KNOB_LDPC_SLOTS,        // LDPC_SLOTS
   KNOB_LDPC_PACKED,       // LDPC_PACKED
   KNOB_TDEC_LAT,          // SRSRAN_HIP_TDEC_LAT: 0 never use the latency kernel, 1 always (where it exists), unset: by batch size
+  KNOB_LOGICAL_DEVICES,   // SRSRAN_HIP_LOGICAL_DEVICES: n logical devices on the installed ones (development: the per-device bookkeeping on a 1-GPU box)
   KNOB_COUNT
 };
 int knob(Knob k);
+
+// Per-thread staging contexts (stream, pinned + device images, decoder / plan objects) live in a process-wide POOL: a thread takes one at its first call
+// and gives it back when it ends, so (i) what srsran_hip_warmup() -- or the init-time hook srsran_rm_turbo_gentables(), which the reference calls from
+// srsran_sch_init (sch.c:166) -- prepared on a short-lived thread is what a PHY worker finds at its first subframe (the reference creates its objects on one
+// thread and runs them on others), and (ii) worker churn does not re-create streams and pinned memory.  The pool itself is never destroyed (the HIP runtime
+// may be gone by the time static destructors run).
+// one T per device, made on first use, never destroyed (they own device memory; the runtime may be gone at static destruction)
+template <class T>
+T& device_local()
+{
+  static std::mutex mu;
+  static T*         slot[kMaxDevices] = {};
+  const int         d = current_device();
+  const int         i = (d >= 0 && d < kMaxDevices) ? d : 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!slot[i]) {
+    slot[i] = new T;
+  }
+  return *slot[i];
+}
+// one T per (thread, device): the thread-local staging contexts of the host-pointer entry points
+template <class T>
+T& thread_device_local()
+{
+  struct Holder {
+    T* slot[kMaxDevices] = {};
+    ~Holder()
+    {
+      for (T* p : slot) {
+        delete p;
+      }
+    }
+  };
+  static thread_local Holder h;
+  const int                  d = current_device();
+  const int                  i = (d >= 0 && d < kMaxDevices) ? d : 0;
+  if (!h.slot[i]) {
+    h.slot[i] = new T;
+  }
+  return *h.slot[i];
+}
+
+template <class T>
+class StagePool {
+public:
+  static StagePool& get() // the pool of the calling thread's device
+  {
+    return device_local<StagePool>();
+  }
+  T* take()
+  {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!idle_.empty()) {
+        T* s = idle_.back();
+        idle_.pop_back();
+        return s;
+      }
+    }
+    return new T;
+  }
+  void give(T* s)
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    idle_.push_back(s);
+  }
+  size_t idle()
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    return idle_.size();
+  }
+
+private:
+  std::mutex      mu_;
+  std::vector<T*> idle_;
+};
+template <class T>
+struct StageRef { // one per thread (thread_local): the thread's context on each device it has worked on
+  T*            p[kMaxDevices]    = {};
+  StagePool<T>* home[kMaxDevices] = {};
+  ~StageRef()
+  {
+    for (int i = 0; i < kMaxDevices; i++) {
+      if (p[i]) {
+        home[i]->give(p[i]);
+      }
+    }
+  }
+  T& get()
+  {
+    const int d = current_device();
+    const int i = (d >= 0 && d < kMaxDevices) ? d : 0;
+    if (!p[i]) {
+      home[i] = &StagePool<T>::get();
+      p[i]    = home[i]->take();
+    }
+    return *p[i];
+  }
+};
+
+// roctx ranges around the batch / grant entry points (what pusch.c:368-372's meas_time_en is to the reference): a range shows up in a
+// `rocprofv3 --marker-trace` timeline with the kernels of the call under it.  Active when the profiler's roctx library is already in the process
+// (rocprofv3 preloads it) or when SRSRAN_HIP_ROCTX=1 asks for it to be loaded; otherwise a pointer test.
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+  explicit TraceRange(const char* name) { trace_push(name); }
+  ~TraceRange() { trace_pop(); }
+  TraceRange(const TraceRange&)            = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
 
 static inline uint32_t ceil_div(uint32_t a, uint32_t b)
 {

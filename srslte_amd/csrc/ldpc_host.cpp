@@ -117,6 +117,7 @@ static int choose_cpb(int Z, size_t soft_bytes_per_cw)
 
 
 struct srsran_hip_ldpc_batch {
+  DeviceTag tag;
   int      bg = 0, Z = 0, N = 0, M = 0, K = 0, E = 0;
   int      max_iter = 0;
   int      sf       = 0;
@@ -309,6 +310,10 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
                           uint32_t msg_stride, uint32_t n_cw, uint32_t cdwd_rm_length, uint8_t* d_iter_msgs, void* d_soft,
                           void* stream, uint32_t crc_poly, int crc_order, int* d_n_iter, const uint32_t* d_cw_map)
 {
+  TraceRange trace_("srsran_hip_ldpc_batch_run");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_ldpc_batch_run", SRSRAN_ERROR);
+  }
   if (h && n_cw == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
   }
@@ -440,6 +445,9 @@ extern "C" int srsran_hip_ldpc_batch_run_crc_map(srsran_hip_ldpc_batch_t* h, con
                                                  uint32_t msg_stride, const uint32_t* d_cw_map, uint32_t n_cw, uint32_t cdwd_rm_length,
                                                  uint32_t crc_polynom, uint32_t crc_order, int32_t* d_nof_iterations, void* stream)
 {
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_ldpc_batch_run_crc_map", SRSRAN_ERROR);
+  }
   if (!crc_order || !d_nof_iterations || !d_cw_map) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -451,6 +459,7 @@ extern "C" int srsran_hip_ldpc_batch_run_crc_map(srsran_hip_ldpc_batch_t* h, con
 
 namespace {
 struct LdpcCtx {
+  DeviceTag tag;
   srsran_hip_ldpc_batch_t* b      = nullptr;
   hipStream_t              stream = nullptr;
   size_t                   esz    = 1;       // bytes per LLR (1 / 2 / 4)
@@ -530,7 +539,7 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
   if (!c) {
     return -1;
   }
-  bind_thread();
+  PHY_DEV_GUARD(c->tag, "srsran_ldpc_decoder_decode", -1);
   const uint32_t n_llr     = q->liftN - 2 * q->ls; // init_ldpc_dec_c reads all of them
   const uint32_t liftK     = q->liftK;
   // callers inside this function right now (any handle): with a handful of them the private streams overlap their one-workgroup
@@ -550,7 +559,7 @@ int ldpc_decode_any(void* o, const void* llrs, uint8_t* message, uint32_t cdwd_r
     char           key[160];
     // the engine depends on decoder type, base graph, lifting size, scaling and iteration budget; the rate-matched length and the CRC
     // change with every grant and are run-time parameters of a launch: they travel as the request's grouping tag
-    snprintf(key, sizeof(key), "ldpc:t%d:bg%d:z%u:sf%a:it%u", c->dec_type, (int)q->bg, (unsigned)q->ls, (double)q->scaling_fctr, q->max_nof_iter);
+    snprintf(key, sizeof(key), "ldpc:d%d:t%d:bg%d:z%u:sf%a:it%u", current_device(), c->dec_type, (int)q->bg, (unsigned)q->ls, (double)q->scaling_fctr, q->max_nof_iter);
     const uint64_t tag = (uint64_t)cdwd_rm_length | ((uint64_t)order << 16) | ((uint64_t)poly << 24);
     const size_t esz  = c->esz;
     std::shared_ptr<Coalescer> co = coalescer_for(key, [&]() -> Coalescer* {

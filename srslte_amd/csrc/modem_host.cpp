@@ -27,7 +27,7 @@ struct SeqTables {
   uint32_t*  d_x2   = nullptr;
   bool       failed = false;
 };
-SeqTables g_seq;
+#define g_seq (device_local<SeqTables>()) // the sequence tables of the calling thread's device
 
 bool seq_tables(const uint32_t** x1, const uint32_t** x2)
 {
@@ -118,7 +118,7 @@ struct ModTables {
   float2*    d      = nullptr;
   bool       failed = false;
 };
-ModTables g_mod;
+#define g_mod (device_local<ModTables>())
 
 void build_mod_tables(std::vector<float2>& t)
 {
@@ -232,8 +232,7 @@ struct Stage {
 
 Stage& stage()
 {
-  static thread_local Stage s;
-  return s;
+  return thread_device_local<Stage>(); // this thread's staging context on the device it is bound to
 }
 
 int run_host(uint32_t mod, const void* in, void* out, int llr_type, uint32_t n, uint32_t seed, bool scramble, const char* who)
@@ -349,6 +348,7 @@ extern "C" uint32_t srsran_hip_sequence_pusch_seed(uint16_t rnti, uint32_t nslot
 
 // ---- batched, device resident --------------------------------------------------------------------------------------------------
 struct srsran_hip_demod {
+  DeviceTag tag;
   modem::Job* d_jobs  = nullptr;
   modem::Job* h_jobs  = nullptr; // pinned
   size_t      cap     = 0;
@@ -396,6 +396,10 @@ extern "C" void srsran_hip_demod_free(srsran_hip_demod_t* h)
 extern "C" int srsran_hip_demod_run(srsran_hip_demod_t* h, const void* d_in, void* d_llr, int llr_type,
                                     const srsran_hip_demod_job_t* jobs, uint32_t n_jobs, void* stream)
 {
+  TraceRange trace_("srsran_hip_demod_run");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_demod_run", SRSRAN_ERROR);
+  }
   if (!h || (n_jobs && (!jobs || !d_in || !d_llr)) || llr_type < 0 || llr_type > 2) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }

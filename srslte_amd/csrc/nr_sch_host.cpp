@@ -168,6 +168,7 @@ uint32_t enc_layers(const Graph& g, uint32_t cdwd_rm_length)
 
 // ------------------------------------------------------------------------------------------------ batch object
 struct srsran_hip_nr_sch {
+  DeviceTag tag;
   std::map<uint32_t, Graph> graphs; // bg << 16 | Z
   nrsch::CbJob*             d_jobs  = nullptr;
   nrsch::CbJob*             h_jobs  = nullptr; // pinned
@@ -260,6 +261,9 @@ extern "C" void srsran_hip_nr_sch_free(srsran_hip_nr_sch_t* h)
 static int rm_batch(srsran_hip_nr_sch_t* h, bool tx, int llr_type, const void* d_in, void* d_out, const srsran_hip_ldpc_cb_t* cbs, uint32_t n_cb,
                     uint32_t F, int bg, uint32_t ls, uint32_t rv, int mod, uint32_t Nref, hipStream_t st, const uint8_t* new_data = nullptr)
 {
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_ldpc_rm_batch", SRSRAN_ERROR);
+  }
   if (!h || (n_cb && (!cbs || !d_in || !d_out)) || llr_type < 0 || llr_type > 2) {
     set_error("ldpc rate matching: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -337,6 +341,9 @@ extern "C" int srsran_hip_ldpc_rm_tx_batch(srsran_hip_nr_sch_t* h, const uint8_t
 extern "C" int srsran_hip_ldpc_encode_batch(srsran_hip_nr_sch_t* h, const uint8_t* d_messages, uint8_t* d_codewords, const srsran_hip_ldpc_cb_t* cbs,
                                             uint32_t n_cb, srsran_basegraph_t bg, uint32_t ls, void* stream)
 {
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_ldpc_encode_batch", SRSRAN_ERROR);
+  }
   if (!h || (n_cb && (!cbs || !d_messages || !d_codewords))) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
@@ -374,6 +381,7 @@ extern "C" int srsran_hip_ldpc_encode_batch(srsran_hip_nr_sch_t* h, const uint8_
 namespace {
 
 struct HostCtx { // behind srsran_ldpc_rm_t.ptr / srsran_ldpc_encoder_t.ptr
+  DeviceTag tag;
   srsran_hip_nr_sch_t* h     = nullptr;
   hipStream_t          st    = nullptr;
   void*                d_in  = nullptr;
@@ -450,6 +458,7 @@ int rm_host(srsran_ldpc_rm_t* q, bool tx, int llr_type, size_t es, const void* i
   }
   q->N = c.N, q->E = E, q->K = c.K, q->F = F, q->ls = (uint16_t)ls, q->mod_order = c.Qm, q->bg = (srsran_basegraph_t)bg, q->Ncb = c.Ncb, q->k0 = c.k0;
   HostCtx*     x        = (HostCtx*)q->ptr;
+  PHY_DEV_GUARD(x->tag, "srsran_ldpc_rm", -1);
   const size_t in_bytes = tx ? c.N : E * es, out_bytes = tx ? E : c.N * es;
   if (!ctx_grow(&x->d_in, &x->cap_in, in_bytes) || !ctx_grow(&x->d_out, &x->cap_out, out_bytes)) {
     return -1;
@@ -531,6 +540,9 @@ static int enc_encode(void* o, const uint8_t* input, uint8_t* output, uint32_t i
 {
   srsran_ldpc_encoder_t* q = (srsran_ldpc_encoder_t*)o;
   HostCtx*               x = (HostCtx*)q->ptr;
+  if (x) {
+    PHY_DEV_GUARD(x->tag, "srsran_ldpc_encoder_encode", -1);
+  }
   if (input_length / q->bgK != q->ls) {
     fprintf(stderr, "Dimension mismatch.\n"); // ldpc_encoder.c:59-62
     return -1;

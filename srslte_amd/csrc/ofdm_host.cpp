@@ -180,6 +180,7 @@ void make_shift(const Geometry& g, cf_t* tab)
 // ------------------------------------------------------------------------------------------------ batch object
 
 struct srsran_hip_ofdm_batch {
+  DeviceTag tag;
   Geometry g;
   int      region  = 2; // non-MBSFN region length of an MBSFN subframe (default of ofdm.c:198)
   bool     tx      = false;
@@ -315,6 +316,10 @@ extern "C" uint32_t srsran_hip_ofdm_batch_sf_re(srsran_hip_ofdm_batch_t* h)
 static int batch_run(srsran_hip_ofdm_batch_t* h, const void* d_in, void* d_out, uint32_t n_sf, bool tx, bool with_shift,
                      hipStream_t stream, bool with_ramp = true)
 {
+  TraceRange trace_("srsran_hip_ofdm_batch");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_ofdm_batch", SRSRAN_ERROR);
+  }
   if (h && n_sf == 0 && h->tx == tx) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
   }
@@ -377,6 +382,7 @@ extern "C" int srsran_hip_ofdm_batch_tx(srsran_hip_ofdm_batch_t* h, const cf_t* 
 
 namespace {
 struct OfdmCtx {
+  DeviceTag                tag;
   srsran_hip_ofdm_batch_t* b      = nullptr;
   hipStream_t              stream = nullptr;
   float2*                  d_time = nullptr; // sf_sz
@@ -387,9 +393,15 @@ struct OfdmCtx {
   srsran_dft_dir_t         dir = SRSRAN_DFT_FORWARD;
 };
 
-OfdmCtx* ctx_of(srsran_ofdm_t* q)
+OfdmCtx* ctx_raw(srsran_ofdm_t* q)
 {
   return reinterpret_cast<OfdmCtx*>(q->tmp);
+}
+// nullptr (error reported) when the object lives on another device than the calling thread's
+OfdmCtx* ctx_of(srsran_ofdm_t* q)
+{
+  OfdmCtx* c = ctx_raw(q);
+  return (c && !check_device(c->tag, "srsran_ofdm")) ? nullptr : c;
 }
 
 void ctx_free(OfdmCtx* c)
@@ -574,7 +586,7 @@ int ctx_sync(srsran_ofdm_t* q)
 
 void ofdm_free_(srsran_ofdm_t* q)
 {
-  ctx_free(ctx_of(q));
+  ctx_free(ctx_raw(q));
   free(q->shift_buffer);
   free(q->window_offset_buffer);
   memset(q, 0, sizeof(srsran_ofdm_t)); // ofdm.c:240

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+#ifdef SRSRAN_HIP_WITH_VARIANTS // measured-and-rejected alternatives are compiled into tools/probe/lib/libsrsran_phy_hip_variants.so only (srslte_amd/build.py --variants)
 // ================================================================================================================================
 // MEASURED ALTERNATIVE (SRSRAN_HIP_PSS_VARIANT=pair), not the product: two waves per block, 128 lanes x 32 points.  The one-wave
 // kernel above cannot have more than two waves per SIMD (128 registers of data per lane) and a wave issues at most one vector
@@ -538,14 +539,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+#endif // SRSRAN_HIP_WITH_VARIANTS
+
 hipError_t launch_pss_wave_blocks(const PssParams& p, hipStream_t stream)
 {
-  const bool pair = knob(KNOB_PSS_VARIANT) == 1; // development knob: "pair" = the measured alternative with two waves per block
-  if (pair) {
+#ifdef SRSRAN_HIP_WITH_VARIANTS
+  if (knob(KNOB_PSS_VARIANT) == 1) { // development knob: "pair" = the measured alternative with two waves per block
     hipLaunchKernelGGL(pss_pair_kernel, dim3(p.n_blocks, p.n_cap), dim3(128), 0, stream, p);
-  } else {
-    hipLaunchKernelGGL(pss_wave_kernel, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
+    return hipGetLastError();
   }
+#endif
+  hipLaunchKernelGGL(pss_wave_kernel, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -72,14 +72,14 @@ struct TablePool {
   std::mutex                       mu;
   std::map<uint32_t, uint16_t*>    dev;  // key = K | rv << 16 | nof_sb << 20 (bit 31: forward table of the transmit side)
   std::map<uint32_t, uint32_t>     fwd_len;
-  ~TablePool()
-  {
-    for (auto& kv : dev) {
-      (void)hipFree(kv.second);
-    }
-  }
+  bool                             all = false; // build_all_tables() has run
+  // (the tables are the process's: never freed -- entries may point into one big allocation, and the runtime may be gone at static destruction)
 };
-TablePool g_pool;
+TablePool& g_pool_ref()
+{
+  return device_local<TablePool>(); // the tables of the calling thread's device
+}
+#define g_pool (g_pool_ref())
 
 const uint16_t* table_on_device(uint32_t K, uint32_t rv, uint32_t nof_sb)
 {
@@ -205,7 +205,7 @@ int rx_host(const T* input, T* output, uint32_t in_len, uint32_t cb_idx, uint32_
     printf("Invalid inputs rv_idx=%d, cb_idx=%d\n", rv, cb_idx);
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  static thread_local HostStage s;
+  HostStage& s = thread_device_local<HostStage>();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_rx_lut: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;
@@ -232,16 +232,80 @@ int rx_host(const T* input, T* output, uint32_t in_len, uint32_t cb_idx, uint32_
 
 } // namespace
 
-extern "C" void srsran_rm_turbo_gentables(void) {}
+// rm_turbo.c:276-340 builds every table of every block size here, and srsran_sch_init calls it (sch.c:166): the init-time hook of the transport-block
+// path.  All 188 sizes x 4 redundancy versions x {16-bit decoder layout, 8-bit decoder layout, transmit side} in one allocation and one upload
+// (about 40 MB, 0.1 s), then one worker's staging contexts warmed (chan_host.cpp: srsran_hip_warmup).
+extern "C" int srsran_hip_warmup(uint32_t nof_workers);
+extern "C" void srsran_rm_turbo_gentables(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) == hipSuccess && n > 0) { // (without a device every later call fails loudly by itself)
+    (void)srsran_hip_warmup(1); // idempotent per device
+  }
+}
 
-extern "C" void srsran_rm_turbo_free_tables(void)
+// srsran_sch_free calls this for EVERY object (sch.c:201) while other objects may still be decoding: the tables stay (they are the process's)
+extern "C" void srsran_rm_turbo_free_tables(void) {}
+
+namespace phyhip {
+namespace rm {
+bool build_all_tables()
 {
   std::lock_guard<std::mutex> lk(g_pool.mu);
-  for (auto& kv : g_pool.dev) {
-    (void)hipFree(kv.second);
+  if (g_pool.all) {
+    return true;
   }
-  g_pool.dev.clear();
+  struct Item {
+    uint32_t key;
+    size_t   off, len;
+  };
+  std::vector<Item>     items;
+  std::vector<uint16_t> img;
+  auto                  add = [&](uint32_t key, const std::vector<uint16_t>& t) {
+    if (g_pool.dev.count(key)) {
+      return;
+    }
+    const size_t off = (img.size() + 63) & ~(size_t)63; // 128-byte aligned tables
+    img.resize(off);
+    img.insert(img.end(), t.begin(), t.end());
+    items.push_back({key, off, t.size()});
+  };
+  for (int i = 0; i < 188; i++) {
+    const uint32_t K      = (uint32_t)srsran_cbsegm_cbsize((uint32_t)i);
+    const uint32_t nsb[2] = {srsran_tdec_autoimp_get_subblocks(K), srsran_tdec_autoimp_get_subblocks_8bit(K)};
+    for (uint32_t rv = 0; rv < 4; rv++) {
+      for (int v = 0; v < 2; v++) {
+        if (v == 1 && nsb[1] == nsb[0]) {
+          continue;
+        }
+        const std::vector<uint16_t> fwd = build_table(K, rv, nsb[v]);
+        std::vector<uint16_t>       t(nsb[v] ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12, 0xffffu);
+        for (size_t k = 0; k < fwd.size(); k++) {
+          t[fwd[k]] = (uint16_t)k;
+        }
+        add(K | (rv << 16) | (nsb[v] << 20), t);
+      }
+      const std::vector<uint16_t> f = build_table(K, rv, 0);
+      add(K | (rv << 16) | (1u << 31), f);
+      g_pool.fwd_len[K | (rv << 16) | (1u << 31)] = (uint32_t)f.size();
+    }
+  }
+  if (!items.empty()) {
+    uint16_t* d = nullptr;
+    if (hipMalloc(&d, img.size() * sizeof(uint16_t)) != hipSuccess || upload(d, img.data(), img.size() * sizeof(uint16_t)) != hipSuccess) {
+      set_error("rm_turbo: cannot place the rate-matching tables on the device");
+      (void)hipFree(d);
+      return false;
+    }
+    for (const Item& it : items) {
+      g_pool.dev[it.key] = d + it.off;
+    }
+  }
+  g_pool.all = true;
+  return true;
 }
+} // namespace rm
+} // namespace phyhip
 
 extern "C" int srsran_rm_turbo_rx_lut_(int16_t* input, int16_t* output, uint32_t in_len, uint32_t cb_idx, uint32_t rv_idx,
                                        bool enable_input_tdec)

@@ -63,14 +63,17 @@ extern "C" int srsran_cbsegm(srsran_cbsegm_t* s, uint32_t tbs)
 // ------------------------------------------------------------------------------------------------ batch decoder
 
 struct srsran_hip_sch {
+  DeviceTag tag;
   // one turbo batch object per (K, arithmetic is 16 bit), grown on demand
   std::map<uint32_t, std::pair<srsran_hip_tdec_batch_t*, uint32_t>> dec; // K | 8-bit flag << 31 -> (object, capacity)
+  turbo::WsArena arena;       // the one workspace all its decoders run in (turbo_device.h)
   void*  d_scratch = nullptr; // job / descriptor / result arrays
   void*  h_scratch = nullptr; // ... and their pinned host image: descriptors go up and verdicts come down with one asynchronous copy each
   size_t scratch_cap = 0;
   // transport-block CRC: one row of 256 lane multipliers per block size seen so far (rm::tb_crc_multipliers), resident on the device
   std::map<uint32_t, uint32_t> crc_row; // tbs -> row
   uint32_t*                    d_crc_mult = nullptr;
+  uint32_t*                    h_crc_mult = nullptr; // pinned mirror: a new row goes up asynchronously on the call's stream, in front of the CRC kernel
   uint32_t                     crc_rows_cap = 0;
 };
 
@@ -98,6 +101,7 @@ extern "C" void srsran_hip_sch_free(srsran_hip_sch_t* h)
   (void)hipFree(h->d_scratch);
   (void)hipHostFree(h->h_scratch);
   (void)hipFree(h->d_crc_mult);
+  (void)hipHostFree(h->h_crc_mult);
   delete h;
 }
 
@@ -116,9 +120,11 @@ srsran_hip_tdec_batch_t* decoder_for(srsran_hip_sch_t* h, uint32_t K, uint32_t n
     h->dec.erase(it);
   }
   srsran_hip_tdec_batch_t* b = nullptr;
-  if (llr8 ? srsran_hip_tdec_batch_create_8bit(&b, K, n, SRSRAN_TDEC_AUTO) : srsran_hip_tdec_batch_create(&b, K, n, SRSRAN_TDEC_AUTO)) {
+  // (capacity: whatever the caller asks for, rounded up generously -- the object owns no memory, the workspace is the arena's)
+  if (turbo::batch_create_shared(&b, K, n < 64 ? 64 : n, llr8, &h->arena)) {
     return nullptr;
   }
+  n = n < 64 ? 64 : n;
   h->dec[key] = std::make_pair(b, n);
   return b;
 }
@@ -136,6 +142,10 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
                       uint8_t* cb_crc, uint8_t* d_data, srsran_hip_tb_result_t* results, void* stream, bool llr8, const TailCopy* tail = nullptr,
                       int n_tail = 0)
 {
+  TraceRange trace_("srsran_hip_sch_decode");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_sch_decode", SRSRAN_ERROR);
+  }
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
   }
@@ -282,21 +292,29 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
     const uint32_t row = (uint32_t)h->crc_row.size();
     if (row >= h->crc_rows_cap) {
       const uint32_t cap = h->crc_rows_cap ? 2 * h->crc_rows_cap : 16;
-      uint32_t*      nd  = nullptr;
-      if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
+      uint32_t *     nd = nullptr, *nh = nullptr;
+      if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&nh, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
+          hipDeviceSynchronize() != hipSuccess || // nothing may still read the old table / copy from the old mirror when they are freed below
           (h->d_crc_mult && (hipMemcpy(nd, h->d_crc_mult, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
-                             hipDeviceSynchronize() != hipSuccess))) { // nothing may still read the old table when it is freed below
+                             hipDeviceSynchronize() != hipSuccess))) {
         (void)hipFree(nd);
+        (void)hipHostFree(nh);
         set_error("sch decode: device allocation of the CRC multiplier table failed");
         return 0xffffffffu;
       }
+      if (h->h_crc_mult) {
+        memcpy(nh, h->h_crc_mult, (size_t)row * 256 * sizeof(uint32_t));
+      }
       (void)hipFree(h->d_crc_mult);
+      (void)hipHostFree(h->h_crc_mult);
       h->d_crc_mult   = nd;
+      h->h_crc_mult   = nh;
       h->crc_rows_cap = cap;
     }
-    uint32_t m[256];
+    uint32_t* m = h->h_crc_mult + (size_t)row * 256;
     rm::tb_crc_multipliers(tbs_bits, CRC24A, m);
-    if (upload(h->d_crc_mult + (size_t)row * 256, m, sizeof(m)) != hipSuccess) {
+    // (stream order puts the row in front of the CRC kernel of this call; the pinned source stays where it is)
+    if (hipMemcpyAsync(h->d_crc_mult + (size_t)row * 256, m, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) {
       set_error("sch decode: upload of the CRC multiplier table failed");
       return 0xffffffffu;
     }
@@ -526,8 +544,8 @@ inline bool all_zero(const uint8_t* p, size_t n)
 namespace {
 TbStage& tb_stage()
 {
-  static thread_local TbStage s;
-  return s;
+  static thread_local StageRef<TbStage> r;
+  return r.get();
 }
 } // namespace
 
@@ -550,6 +568,7 @@ hipStream_t stage_stream()
 // a mixed list is decoded piece by piece.
 static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n)
 {
+  TraceRange trace_("decode_tb_cb (staged)");
   using phyhip::sch::TbItem;
   for (uint32_t t = 0; t < n; t++) {
     it[t].ok = false;

@@ -154,6 +154,7 @@ extern "C" int srsran_cbsegm_ldpc_bg2(srsran_cbsegm_t* s, uint32_t tbs)
 }
 
 struct srsran_hip_sch_nr {
+  DeviceTag tag;
   float    scaling = 0.8f;
   uint32_t max_iter = 10, max_cb = 0;
   srsran_hip_nr_sch_t*                         rm = nullptr;
@@ -277,6 +278,10 @@ static int sch_nr_decode(srsran_hip_sch_nr_t* h, const int8_t* d_e_bits, const s
                          uint32_t sb_stride, uint8_t* cb_crc, uint8_t* d_cb_data, uint32_t data_stride, uint8_t* d_payload,
                          srsran_hip_nr_tb_result_t* res, void* stream, const TailCopy* tail, int n_tail)
 {
+  TraceRange trace_("srsran_hip_sch_nr_decode");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_sch_nr_decode", SRSRAN_ERROR);
+  }
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS;
   }
@@ -630,7 +635,7 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
   if (softbuffer->max_cb < c.C || softbuffer->max_cb_size < c.N || c.C > NrTbStage::MAX_CB) { // :556-559
     return SRSRAN_ERROR;
   }
-  static thread_local NrTbStage s;
+  NrTbStage& s = thread_device_local<NrTbStage>();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] sch_nr decode: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;
@@ -740,6 +745,10 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
 extern "C" int srsran_hip_sch_nr_encode(srsran_hip_sch_nr_t* h, const uint8_t* d_payload, const srsran_hip_nr_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
                                         void* stream)
 {
+  TraceRange trace_("srsran_hip_sch_nr_encode");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_sch_nr_encode", SRSRAN_ERROR);
+  }
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS;
   }
@@ -855,7 +864,7 @@ extern "C" int srsran_hip_sch_nr_encode_tb(const srsran_hip_nr_tb_t* tb_in, cons
     fprintf(stderr, "[srsran_phy_hip] sch_nr encode: invalid transport block (tbs %u, mod %u, layers %u)\n", tb_in->tbs, tb_in->mod, tb_in->N_L);
     return SRSRAN_ERROR;
   }
-  static thread_local NrTbStage s;
+  NrTbStage& s = thread_device_local<NrTbStage>();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] sch_nr encode: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;

@@ -68,7 +68,7 @@ struct Stage {
 
 Stage& stage()
 {
-  static thread_local Stage s;
+  Stage& s = thread_device_local<Stage>();
   return s;
 }
 
@@ -344,6 +344,35 @@ extern "C" void srsran_cfo_correct_offset(srsran_cfo_t* h, const cf_t* input, cf
   if (glue::prod(&h->cur_cexp[cexp_offset], input, output, nsamples, false)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_cfo_correct_offset: %s\n", get_error());
   }
+}
+
+// cfo.c:130-151: CP-based CFO estimate of an uplink subframe (one symbol's cyclic prefix against its tail), in place: the half-sub-carrier shift of
+// SC-FDMA is taken out first and put back, corrected by the estimate, at the end.  Three device round trips (the reference's three vector calls).
+extern "C" float srsran_cfo_est_corr_cp(cf_t* input_buffer, uint32_t nof_prb)
+{
+  const int nFFT = srsran_symbol_sz(nof_prb);
+  if (!input_buffer || nFFT <= 0) {
+    return 0.f;
+  }
+  const int   sf_n_samples = nFFT * 15;
+  const float tFFT         = (float)(1 / 15000.0);
+  auto        cp_norm      = [&](int symbol) { return (symbol == 0 ? 160 * nFFT + 2047 : 144 * nFFT + 2047) / 2048; }; // SRSRAN_CP_LEN_NORM, phy_common.h:125-128
+  const int   cp_size      = cp_norm(1);
+  if (glue::apply_cfo(input_buffer, input_buffer, sf_n_samples, (float)(1 / (nFFT * 15e3)) * (float)(15e3 / 2.0))) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_cfo_est_corr_cp: %s\n", get_error());
+    return 0.f;
+  }
+  glue::Dot job = {&input_buffer[nFFT + cp_norm(0)], &input_buffer[2 * nFFT + cp_norm(0)], cp_size, glue::CONJ};
+  cf_t      est(0.f, 0.f);
+  if (glue::dots(&job, 1, &est)) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_cfo_est_corr_cp: %s\n", get_error());
+    return 0.f;
+  }
+  const float cfo = (float)(-1 * atan2f(est.imag(), est.real()) / (float)(2 * M_PI * tFFT));
+  if (glue::apply_cfo(input_buffer, input_buffer, sf_n_samples, (float)(1 / (nFFT * 15e3)) * (float)((-15e3 / 2.0) - cfo))) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_cfo_est_corr_cp: %s\n", get_error());
+  }
+  return cfo;
 }
 
 // ------------------------------------------------------------------------------------------------ srsran_cp_synch_t

@@ -376,6 +376,7 @@ void sss_params(sync::SssParams* p, const SssEngine* e, const void* d_in, size_t
 
 namespace {
 struct PssCtx {
+  DeviceTag tag;
   PssEngine*  e = nullptr;
   hipStream_t stream = nullptr;
   float2*     d_in = nullptr;
@@ -585,6 +586,7 @@ extern "C" int srsran_pss_find_pss(srsran_pss_t* q, const cf_t* input, float* co
   if (!c || !c->e) {
     return SRSRAN_ERROR;
   }
+  PHY_DEV_GUARD(c->tag, "srsran_pss_find_pss", SRSRAN_ERROR);
   const bool direct = q->frame_size < q->fft_size;
   // samples the reference reads: frame_size * decimate (pss.c:462), or frame_size + fft_size - 1 in the
   // sliding dot-product mode (pss.c:477-479)
@@ -723,6 +725,7 @@ extern "C" void srsran_pss_sic(srsran_pss_t* q, cf_t* input)
 
 namespace {
 struct SssCtx {
+  DeviceTag tag;
   SssEngine*  e = nullptr;
   hipStream_t stream = nullptr;
   float2*     d_in = nullptr;
@@ -910,6 +913,7 @@ static int sss_run(srsran_sss_t* q, const cf_t* input, int M, cf_t* ce, uint32_t
   if (!c || !c->e) {
     return SRSRAN_ERROR;
   }
+  PHY_DEV_GUARD(c->tag, "srsran_sss", SRSRAN_ERROR);
   const uint32_t N = q->fft_size;
   memcpy(c->h_in, input, N * sizeof(cf_t));
   PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, c->h_in, N * sizeof(cf_t), hipMemcpyHostToDevice, c->stream), SRSRAN_ERROR);
@@ -959,6 +963,7 @@ extern "C" int srsran_sss_m0m1_diff(srsran_sss_t* q, const cf_t* input, uint32_t
 // ------------------------------------------------------------------------------------------------ batched cell search
 
 struct srsran_hip_cellsearch {
+  DeviceTag tag;
   PssEngine*  pss = nullptr;
   SssEngine*  sss = nullptr;
   sync::SssResult* d_sss = nullptr;
@@ -1002,6 +1007,10 @@ extern "C" void srsran_hip_cellsearch_free(srsran_hip_cellsearch_t* h)
 extern "C" int srsran_hip_cellsearch_run(srsran_hip_cellsearch_t* h, const cf_t* d_captures, uint32_t n_captures, int n_id_2_mask,
                                          srsran_hip_cell_t* d_cells, void* stream)
 {
+  TraceRange trace_("srsran_hip_cellsearch_run");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_cellsearch_run", SRSRAN_ERROR);
+  }
   if (!h || !d_captures || !d_cells || n_captures == 0 || n_captures > h->max_caps || !(n_id_2_mask & 7)) {
     set_error("cellsearch: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;

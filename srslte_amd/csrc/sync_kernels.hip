@@ -72,6 +72,7 @@ struct PowerStore {
   }
 };
 
+#ifdef SRSRAN_HIP_WITH_VARIANTS // round 1's workgroup-per-block correlation kernel: a measured alternative, compiled into the variants library only
 __global__ __launch_bounds__(256) void pss_block_kernel(const PssParams p)
 {
   extern __shared__ float2 lds_all[];
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void pss_block_kernel(const PssParams p)
     __syncthreads();
   }
 }
+#endif // SRSRAN_HIP_WITH_VARIANTS
 
 // Per (capture, hypothesis): global arg-max from the block partials, then the peak / side-lobe ratio of
 // pss.c:408-437 evaluated on the correlation-power array.
@@ -465,21 +467,22 @@ hipError_t launch_pack(const PssResult* a, const SssResult* b, CellResult* out, 
 
 hipError_t launch_pss(const PssParams& p, PssResult* d_res, hipStream_t stream)
 {
-  static bool attr_set = false;
-  const size_t lds = (lds_elems(4096) + 4096) * sizeof(float2);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pss_block_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      return e;
+#ifdef SRSRAN_HIP_WITH_VARIANTS
+  // development knob (tests/test_gpu_variants.py, in the variants library): "block" = the workgroup-per-block kernel of round 1
+  if (knob(KNOB_PSS_VARIANT) == 2) {
+    static bool  attr_set = false;
+    const size_t lds      = (lds_elems(4096) + 4096) * sizeof(float2);
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pss_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        return e;
+      }
+      attr_set = true;
     }
-    attr_set = true;
-  }
-  // development knob (tests/test_gpu_variants.py switches it through srsran_hip_dev_knob): "block" = the workgroup-per-block kernel of round 1
-  const bool by_workgroup = knob(KNOB_PSS_VARIANT) == 2;
-  if (by_workgroup) {
     hipLaunchKernelGGL(pss_block_kernel, dim3(p.n_blocks, p.n_cap), dim3(256), lds, stream, p);
-  } else {
+  } else
+#endif
+  {
     hipError_t e = launch_pss_wave_blocks(p, stream);
     if (e != hipSuccess) {
       return e;

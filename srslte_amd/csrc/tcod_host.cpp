@@ -33,6 +33,7 @@ bool qpp_params(uint32_t K, uint32_t* f1, uint32_t* f2)
 }
 
 struct Ctx { // behind srsran_tcod_t.temp
+  DeviceTag tag;
   hipStream_t st    = nullptr;
   uint8_t*    d_in  = nullptr;
   uint8_t*    d_out = nullptr;
@@ -116,6 +117,7 @@ extern "C" int srsran_tcod_encode(srsran_tcod_t* h, uint8_t* input, uint8_t* out
   if (!c) {
     return -1;
   }
+  PHY_DEV_GUARD(c->tag, "srsran_tcod_encode", -1);
   PHY_HIP_CHECK(hipMemcpyAsync(c->d_in, input, long_cb, hipMemcpyHostToDevice, c->st), -1);
   if (srsran_hip_tcod_encode_batch(c->d_in, long_cb, c->d_out, 3 * long_cb + 12, 1, long_cb, c->st) != SRSRAN_SUCCESS) {
     return -1;
@@ -141,6 +143,7 @@ extern "C" int srsran_tcod_encode_lut(srsran_tcod_t* h, srsran_crc_t* crc_tb, sr
   if (!c) {
     return -1;
   }
+  PHY_DEV_GUARD(c->tag, "srsran_tcod_encode_lut", -1);
   if (crc_tb->order != 24 || (crc_cb && crc_cb->order != 24)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_tcod_encode_lut: only 24-bit CRCs are supported\n");
     return -1;
@@ -229,7 +232,7 @@ extern "C" int srsran_rm_turbo_tx_lut(uint8_t* w_buff, uint8_t* systematic, uint
   if (rv_idx >= 4 || cb_idx >= 188 || !w_buff || !output) {
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
-  static thread_local TxStage s;
+  TxStage& s = thread_device_local<TxStage>();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] srsran_rm_turbo_tx_lut: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;
@@ -288,6 +291,7 @@ extern "C" int srsran_rm_turbo_tx_lut(uint8_t* w_buff, uint8_t* systematic, uint
 
 // ------------------------------------------------------------------------------------------------ transport blocks, transmit side
 struct srsran_hip_sch_enc {
+  DeviceTag tag;
   void*  d_scratch = nullptr;
   void*  h_scratch = nullptr; // pinned
   size_t cap       = 0;
@@ -296,6 +300,7 @@ struct srsran_hip_sch_enc {
   // lane multipliers of the two CRCs, one row of 64 per message length seen so far (key: length | generator << 31), resident on the device
   std::map<uint32_t, uint32_t> mult_row;
   uint32_t*                    d_mult = nullptr;
+  uint32_t*                    h_mult = nullptr; // pinned mirror: a new row goes up by an asynchronous copy on the call's stream, in front of the kernel
   uint32_t                     mult_rows_cap = 0;
 };
 
@@ -334,7 +339,7 @@ void phyhip::tcod::crc_lane_multipliers(uint32_t n_units, uint32_t bits_per_unit
 
 // row of lane multipliers for a message of n units (bytes for the transport CRC24A, bits for the code-block CRC24B): computed and uploaded
 // the first time the length is seen by this object
-static uint32_t enc_mult_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb)
+static uint32_t enc_mult_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb, hipStream_t st)
 {
   const uint32_t key = n_units | (cb ? 0x80000000u : 0u);
   auto           it  = h->mult_row.find(key);
@@ -342,21 +347,29 @@ static uint32_t enc_mult_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb)
     const uint32_t row = (uint32_t)h->mult_row.size();
     if (row >= h->mult_rows_cap) {
       const uint32_t cap = h->mult_rows_cap ? 2 * h->mult_rows_cap : 32;
-      uint32_t*      nd  = nullptr;
-      if (hipMalloc(&nd, (size_t)cap * 64 * sizeof(uint32_t)) != hipSuccess ||
+      uint32_t *     nd = nullptr, *nh = nullptr;
+      if (hipMalloc(&nd, (size_t)cap * 64 * sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&nh, (size_t)cap * 64 * sizeof(uint32_t)) != hipSuccess ||
+          hipDeviceSynchronize() != hipSuccess || // nothing may still read the old table / copy from the old mirror when they are freed below
           (h->d_mult && (hipMemcpy(nd, h->d_mult, (size_t)row * 64 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
-                         hipDeviceSynchronize() != hipSuccess))) { // nothing may still read the old table when it is freed below
+                         hipDeviceSynchronize() != hipSuccess))) {
         (void)hipFree(nd);
+        (void)hipHostFree(nh);
         set_error("sch encode: device allocation of the CRC multiplier table failed");
         return 0xffffffffu;
       }
+      if (h->h_mult) {
+        memcpy(nh, h->h_mult, (size_t)row * 64 * sizeof(uint32_t));
+      }
       (void)hipFree(h->d_mult);
+      (void)hipHostFree(h->h_mult);
       h->d_mult        = nd;
+      h->h_mult        = nh;
       h->mult_rows_cap = cap;
     }
-    uint32_t m[64];
+    uint32_t* m = h->h_mult + (size_t)row * 64;
     tcod::crc_lane_multipliers(n_units, cb ? 1u : 8u, cb ? 0x800063u : 0x864CFBu, m);
-    if (upload(h->d_mult + (size_t)row * 64, m, sizeof(m)) != hipSuccess) {
+    // (stream order puts the row in front of the kernel that reads it; the pinned source stays where it is)
+    if (hipMemcpyAsync(h->d_mult + (size_t)row * 64, m, 64 * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) {
       set_error("sch encode: upload of the CRC multiplier table failed");
       return 0xffffffffu;
     }
@@ -394,6 +407,7 @@ extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
   (void)hipFree(h->d_scratch);
   (void)hipHostFree(h->h_scratch);
   (void)hipFree(h->d_mult);
+  (void)hipHostFree(h->h_mult);
   (void)hipEventDestroy(h->done);
   delete h;
 }
@@ -401,6 +415,10 @@ extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
 extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_data, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint8_t* d_e_bits,
                                      void* stream)
 {
+  TraceRange trace_("srsran_hip_sch_encode");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_sch_encode", SRSRAN_ERROR);
+  }
   if (h && n_tb == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
   }
@@ -471,7 +489,7 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
     const srsran_cbsegm_t& cs = seg[t];
-    crcs[t]                   = {tb.data_offset, tb.tbs / 8, enc_mult_row(h, tb.tbs / 8, false), 0};
+    crcs[t]                   = {tb.data_offset, tb.tbs / 8, enc_mult_row(h, tb.tbs / 8, false, st), 0};
     if (crcs[t].crc_mult_row == 0xffffffffu) {
       return SRSRAN_ERROR;
     }
@@ -499,7 +517,7 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
       j.f2                = ki->f2;
       j.table             = ki->table;
       j.table_len         = ki->table_len;
-      j.crc_mult_row      = j.crc24b ? enc_mult_row(h, j.n_src_bits + (last ? 24u : 0u), true) : 0u;
+      j.crc_mult_row      = j.crc24b ? enc_mult_row(h, j.n_src_bits + (last ? 24u : 0u), true, st) : 0u;
       if (j.crc_mult_row == 0xffffffffu) {
         return SRSRAN_ERROR;
       }
@@ -627,7 +645,8 @@ int phyhip::sch::encode_tb_staged(srsran_softbuffer_tx_t* softbuffer, srsran_cbs
   if (C == 0 || tbs == 0 || nof_e_bits == 0) {
     return SRSRAN_SUCCESS; // the loop over code blocks does not run
   }
-  static thread_local TxTbStage s;
+  static thread_local StageRef<TxTbStage> ref;
+  TxTbStage&                             s = ref.get();
   if (!s.ready()) {
     fprintf(stderr, "[srsran_phy_hip] encode_tb: %s (there is no CPU fallback)\n", get_error());
     return SRSRAN_ERROR;

@@ -102,6 +102,19 @@ static inline uint32_t lat_waves(int nb, uint32_t n_cb)
 struct srsran_hip_tdec_batch;
 namespace phyhip {
 namespace turbo {
+// One workspace for all the decoders of a transport-block stage (sch_host.cpp): its launches run one after the other on the stage's stream and every
+// launch is a complete run, so the decoders of different block sizes can work in the same memory -- a block size the stage has not seen yet then
+// needs no allocation.  ensure() grows the arena (after waiting for `stream`, whose launches may still be using the old one).
+struct WsArena {
+  void*  p   = nullptr;
+  size_t cap = 0;
+  void*  ensure(size_t bytes, hipStream_t stream);
+  ~WsArena();
+};
+// decoder object (AUTO implementation) whose workspace is the arena's
+int batch_create_shared(srsran_hip_tdec_batch** h, uint32_t long_cb, uint32_t max_nof_cb, bool llr8_api, WsArena* arena);
+// every table a decoder of any block size needs (exchange / interleaver tables, CRC multipliers of both generators), in one allocation
+bool prebuild_tables();
 // host side (turbo_host.cpp), used by the transport-block decoder
 int batch_run_early_stop(srsran_hip_tdec_batch* h, const void* d_input, bool in_is8, const CbDesc* d_desc, uint8_t* d_output,
                          uint32_t n_cb, uint32_t max_iterations, int sb_layout, uint32_t crc_poly, int* d_noi, uint8_t* d_crc_ok,

@@ -10,6 +10,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace phyhip;
@@ -139,6 +140,7 @@ extern "C" uint32_t srsran_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb)
 // ------------------------------------------------------------------------------------------------ batch object
 
 struct srsran_hip_tdec_batch {
+  DeviceTag tag;
   uint32_t K       = 0;
   uint32_t max_cb  = 0;
   int      nb      = 0; // 32, 16, 8 (window decoders) or 0 (scalar decoder)
@@ -164,7 +166,67 @@ struct srsran_hip_tdec_batch {
   uint32_t  lat_cap       = 0;
   std::map<uint32_t, uint32_t*> crc_mult_lat; // per generator: one multiplier per 32-bit word of the kernel's hard-bit image
   bool      state_in_lat  = false; // the decoder state of the last launch lives in the latency kernel's workspace
+  // tables borrowed from the process-wide cache (never freed by the object); workspace taken from a caller's arena at every launch
+  bool              tables_cached = false;
+  turbo::WsArena*   arena         = nullptr;
 };
+
+// ---- process-wide cache of the small device constants a decoder of (K, sub-blocks) needs: exchange tables, interleaver tables, CRC multipliers.
+// Built on first use -- or all at once, in ONE allocation, by turbo::prebuild_tables() (the init-time warm-up): creating the decoder of a block size
+// a thread has not seen yet then costs no allocation, no upload and no device-wide wait.
+namespace {
+struct ConstCache {
+  std::mutex                mu;
+  std::map<uint64_t, void*> dev;
+  // bulk mode (prebuild): constants are collected in one host image and placed with one upload
+  bool                                         bulk = false;
+  std::thread::id                              bulk_owner; // only the prebuilding thread collects; any other thread keeps the normal path
+  std::vector<uint8_t>                         img;
+  std::vector<std::pair<uint64_t, size_t>>     pending; // key -> offset in img
+};
+ConstCache& ccache()
+{
+  return device_local<ConstCache>(); // the constants of the calling thread's device; never destroyed
+}
+enum { CK_DEINT = 1, CK_INTER, CK_INTER16, CK_DEINTER16, CK_CRC_WIN, CK_CRC_LAT };
+inline uint64_t ckey(int kind, uint32_t K, int nb, uint32_t poly)
+{
+  return ((uint64_t)kind << 56) | ((uint64_t)K << 40) | ((uint64_t)(uint32_t)nb << 32) | poly;
+}
+// device copy of the constant `key`, made from fill() on first use; nullptr on failure (in bulk mode: a non-null placeholder, valid after the upload)
+template <class Fill>
+void* cached_const(uint64_t key, size_t bytes, Fill fill)
+{
+  ConstCache&                 c = ccache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  auto                        it = c.dev.find(key);
+  if (it != c.dev.end()) {
+    return it->second;
+  }
+  if (c.bulk && c.bulk_owner == std::this_thread::get_id()) {
+    for (auto& pd : c.pending) {
+      if (pd.first == key) {
+        return &c; // placeholder
+      }
+    }
+    const size_t off = (c.img.size() + 255) & ~(size_t)255;
+    c.img.resize(off + bytes);
+    fill(c.img.data() + off);
+    c.pending.emplace_back(key, off);
+    return &c;
+  }
+  std::vector<uint8_t> host(bytes);
+  fill(host.data());
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess || upload(d, host.data(), bytes) != hipSuccess) {
+    (void)hipFree(d);
+    set_error("turbo decoder: cannot place a table on the device");
+    return nullptr;
+  }
+  c.dev[key] = d;
+  return d;
+}
+} // namespace
 
 // which kernel takes a launch of n_cb blocks starting at half iteration n_begin (a resumed run stays where its state is)
 static bool want_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
@@ -229,7 +291,7 @@ static int impl_to_cfg(int impl, bool llr8_api, uint32_t K, int* nb, bool* arith
   }
 }
 
-static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api);
+static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api, turbo::WsArena* arena = nullptr);
 
 extern "C" int srsran_hip_tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl)
 {
@@ -241,7 +303,7 @@ extern "C" int srsran_hip_tdec_batch_create_8bit(srsran_hip_tdec_batch_t** hh, u
   return tdec_batch_create(hh, long_cb, max_nof_cb, impl, true);
 }
 
-static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api)
+static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uint32_t max_nof_cb, int impl, bool llr8_api, turbo::WsArena* arena)
 {
   if (!hh || max_nof_cb == 0) {
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -273,8 +335,8 @@ static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uin
   h->max_cb = max_nof_cb;
   h->nb     = nb;
   h->arith8 = arith8;
-  std::vector<uint16_t> f, r;
-  qpp_natural(long_cb, f, r);
+  h->arena  = arena;
+  h->tables_cached = true;
   const uint32_t K = long_cb;
   if (nb) {
     const uint32_t lpc = nb / 2, long_sb = K / nb, nblk = (long_sb + 7) / 8;
@@ -284,19 +346,21 @@ static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uin
     //   bits 16..20 source sub-block whose output lands in destination sub-block 2p'
     //   bits 21..25 source sub-block whose output lands in destination sub-block 2p'+1
     // deint: app2[reverse[n]] = ext1[n]   inter: app1[forward[n]] = ext2[n]   (turbodecoder_iter.h:118,124)
-    std::vector<uint32_t> deint(nblk * lpc * 8, 0), inter(nblk * lpc * 8, 0);
-    for (int dir = 0; dir < 2; dir++) {
+    const size_t tb = (size_t)nblk * lpc * 8 * sizeof(uint32_t);
+    bool         contention = false;
+    auto         fill_dir = [&](int dir, void* dst) {
+      std::vector<uint16_t> f, r;
+      qpp_natural(K, f, r);
       const std::vector<uint16_t>& tab = dir == 0 ? r : f;
-      std::vector<uint32_t>&       out = dir == 0 ? deint : inter;
+      uint32_t*                    out = static_cast<uint32_t*>(dst);
+      memset(out, 0, tb);
       for (uint32_t k = 0; k < long_sb; k++) {
         uint32_t src_of[32];
         uint32_t row = tab[k] % long_sb;
         for (uint32_t j = 0; j < (uint32_t)nb; j++) {
           uint32_t t = tab[j * long_sb + k];
           if (t % long_sb != row) {
-            set_error("QPP interleaver of K=%u is not contention free for %d windows", K, nb);
-            delete h;
-            return SRSRAN_ERROR;
+            contention = true;
           }
           src_of[t / long_sb] = j;
         }
@@ -304,22 +368,39 @@ static int tdec_batch_create(srsran_hip_tdec_batch_t** hh, uint32_t long_cb, uin
           out[((k >> 3) * lpc + pp) * 8 + (k & 7)] = row | (src_of[2 * pp] << 16) | (src_of[2 * pp + 1] << 21);
         }
       }
+    };
+    h->d_deint = static_cast<uint32_t*>(cached_const(ckey(CK_DEINT, K, nb, 0), tb, [&](void* d) { fill_dir(0, d); }));
+    h->d_inter = static_cast<uint32_t*>(cached_const(ckey(CK_INTER, K, nb, 0), tb, [&](void* d) { fill_dir(1, d); }));
+    if (contention) {
+      set_error("QPP interleaver of K=%u is not contention free for %d windows", K, nb);
+      delete h;
+      return SRSRAN_ERROR;
     }
-    size_t tb = deint.size() * sizeof(uint32_t);
-    // one slab per wave (64/lpc code blocks); round the block count up to whole waves
-    const uint32_t cpw = 64 / lpc;
-    PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * ceil_div(max_nof_cb, cpw) * cpw * sizeof(uint32_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMalloc(&h->d_deint, tb), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMalloc(&h->d_inter, tb), SRSRAN_ERROR);
-    PHY_HIP_CHECK(upload(h->d_deint, deint.data(), tb), SRSRAN_ERROR);
-    PHY_HIP_CHECK(upload(h->d_inter, inter.data(), tb), SRSRAN_ERROR);
+    if (!h->d_deint || !h->d_inter) {
+      delete h;
+      return SRSRAN_ERROR;
+    }
+    if (!arena) {
+      // one slab per wave (64/lpc code blocks); round the block count up to whole waves
+      const uint32_t cpw = 64 / lpc;
+      PHY_HIP_CHECK(hipMalloc(&h->d_ws, (size_t)h->ws_stride * ceil_div(max_nof_cb, cpw) * cpw * sizeof(uint32_t)), SRSRAN_ERROR);
+    }
   } else {
-    size_t nwaves = ceil_div(max_nof_cb, 64);
-    PHY_HIP_CHECK(hipMalloc(&h->d_ws_gen, turbo::gen_ws_shorts(K) * nwaves * sizeof(short)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMalloc(&h->d_inter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(hipMalloc(&h->d_deinter16, K * sizeof(uint16_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(upload(h->d_inter16, f.data(), K * sizeof(uint16_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(upload(h->d_deinter16, r.data(), K * sizeof(uint16_t)), SRSRAN_ERROR);
+    auto fill16 = [&](int dir, void* dst) {
+      std::vector<uint16_t> f, r;
+      qpp_natural(K, f, r);
+      memcpy(dst, (dir == 0 ? f : r).data(), K * sizeof(uint16_t));
+    };
+    h->d_inter16   = static_cast<uint16_t*>(cached_const(ckey(CK_INTER16, K, 0, 0), K * sizeof(uint16_t), [&](void* d) { fill16(0, d); }));
+    h->d_deinter16 = static_cast<uint16_t*>(cached_const(ckey(CK_DEINTER16, K, 0, 0), K * sizeof(uint16_t), [&](void* d) { fill16(1, d); }));
+    if (!h->d_inter16 || !h->d_deinter16) {
+      delete h;
+      return SRSRAN_ERROR;
+    }
+    if (!arena) {
+      size_t nwaves = ceil_div(max_nof_cb, 64);
+      PHY_HIP_CHECK(hipMalloc(&h->d_ws_gen, turbo::gen_ws_shorts(K) * nwaves * sizeof(short)), SRSRAN_ERROR);
+    }
   }
   *hh = h;
   return SRSRAN_SUCCESS;
@@ -330,20 +411,13 @@ extern "C" void srsran_hip_tdec_batch_free(srsran_hip_tdec_batch_t* h)
   if (!h) {
     return;
   }
-  hipFree(h->d_ws);
-  hipFree(h->d_ws_lat);
-  hipFree(h->d_deint);
-  hipFree(h->d_inter);
-  hipFree(h->d_ws_gen);
-  hipFree(h->d_inter16);
-  hipFree(h->d_deinter16);
+  if (!h->arena) {
+    hipFree(h->d_ws);
+    hipFree(h->d_ws_lat);
+    hipFree(h->d_ws_gen);
+  }
   hipFree(h->d_dec_llr);
-  for (auto& kv : h->crc_mult) {
-    hipFree(kv.second);
-  }
-  for (auto& kv : h->crc_mult_lat) {
-    hipFree(kv.second);
-  }
+  // (exchange / interleaver tables and CRC multipliers belong to the process-wide cache)
   delete h;
 }
 
@@ -352,6 +426,10 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
                                 uint8_t* d_output, uint32_t out_stride, uint32_t n_cb, uint32_t n_begin, uint32_t n_end,
                                 int sb_layout, bool want_llr, hipStream_t stream)
 {
+  TraceRange trace_("srsran_hip_tdec_batch_run");
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "srsran_hip_tdec_batch_run", SRSRAN_ERROR);
+  }
   const int16_t* d_input = static_cast<const int16_t*>(d_input_v);
   if (h && n_cb == 0) {
     return SRSRAN_SUCCESS; // an empty batch is a no-op
@@ -362,6 +440,10 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
   }
   if (sb_layout && !h->nb) {
     set_error("tdec batch: sub-block input layout needs a window decoder");
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (h->arena) {
+    set_error("tdec batch: a decoder on a shared workspace runs whole transport-block launches only");
     return SRSRAN_ERROR_INVALID_INPUTS;
   }
   const uint32_t need_in = sb_layout ? 3 * (h->K + 32) + 12 : 3 * h->K + 12;
@@ -520,6 +602,9 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
                                         uint8_t* d_output, uint32_t n_cb, uint32_t max_iterations, int sb_layout, uint32_t crc_poly,
                                         int* d_noi, uint8_t* d_crc_ok, hipStream_t stream)
 {
+  if (h) {
+    PHY_DEV_GUARD(h->tag, "tdec early stop", SRSRAN_ERROR);
+  }
   if (!h || !d_input || !d_output || !d_desc || n_cb == 0 || n_cb > h->max_cb || max_iterations == 0 || !crc_poly || (sb_layout && !h->nb)) {
     set_error("tdec early stop: invalid arguments");
     return SRSRAN_ERROR_INVALID_INPUTS;
@@ -529,7 +614,10 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     turbo::GenParams g = {};
     g.input     = static_cast<const short*>(d_input);
     g.output    = d_output;
-    g.ws        = h->d_ws_gen;
+    g.ws        = h->arena ? static_cast<short*>(h->arena->ensure(turbo::gen_ws_shorts(h->K) * ceil_div(n_cb, 64) * sizeof(short), stream)) : h->d_ws_gen;
+    if (!g.ws) {
+      return SRSRAN_ERROR;
+    }
     g.inter     = h->d_inter16;
     g.deinter   = h->d_deinter16;
     g.ws_stride = turbo::gen_ws_shorts(h->K);
@@ -545,15 +633,16 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     PHY_HIP_CHECK(turbo::launch_gen(g, stream), SRSRAN_ERROR);
     return SRSRAN_SUCCESS;
   }
-  uint32_t*& d_mult = h->crc_mult[crc_poly];
-  if (!d_mult) {
-    std::vector<uint32_t> m(h->nb);
-    const uint64_t        W = h->K / h->nb;
-    for (int d = 0; d < h->nb; d++) {
-      m[d] = xpow_mod(W * (uint64_t)(h->nb - 1 - d), crc_poly);
+  const uint32_t nbq = (uint32_t)h->nb, Kq = h->K;
+  uint32_t*      d_mult = static_cast<uint32_t*>(cached_const(ckey(CK_CRC_WIN, Kq, h->nb, crc_poly), nbq * sizeof(uint32_t), [&](void* dst) {
+    uint32_t*      m = static_cast<uint32_t*>(dst);
+    const uint64_t W = Kq / nbq;
+    for (uint32_t d = 0; d < nbq; d++) {
+      m[d] = xpow_mod(W * (uint64_t)(nbq - 1 - d), crc_poly);
     }
-    PHY_HIP_CHECK(hipMalloc(&d_mult, m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
-    PHY_HIP_CHECK(upload(d_mult, m.data(), m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
+  }));
+  if (!d_mult) {
+    return SRSRAN_ERROR;
   }
   turbo::WinParams p = {};
   p.input      = static_cast<const short*>(d_input);
@@ -575,25 +664,31 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
   p.crc_ok     = d_crc_ok;
   if (want_lat(h, n_cb, 0)) {
     // a subframe's worth of code blocks: one block per wave instead of eight (turbo_lat_kernels.hip)
-    if (ensure_lat_ws(h, n_cb)) {
+    if (h->arena) {
+      h->d_ws_lat = static_cast<uint32_t*>(h->arena->ensure((size_t)turbo::lat_ws_dwords(h->K, h->nb) * ((n_cb + 1u) & ~1u) * sizeof(uint32_t), stream));
+      if (!h->d_ws_lat) {
+        return SRSRAN_ERROR;
+      }
+    } else if (ensure_lat_ws(h, n_cb)) {
       return SRSRAN_ERROR;
     }
     // the latency kernel forms the CRC from 32-bit words of its hard-bit image (sub-block d at d * sbs4 bytes): word (d, w) holds the steps
     // 32 w ... of sub-block d and is shifted into place with x^(bits behind it) mod g
-    uint32_t*& d_ml = h->crc_mult_lat[crc_poly];
-    if (!d_ml) {
-      const uint32_t W = h->K / h->nb, nblk = (W + 7) / 8, wps = (((nblk + 1 + 3) & ~3u) >> 2);
-      std::vector<uint32_t> m((size_t)h->nb * wps, 0u);
-      for (uint32_t d = 0; d < (uint32_t)h->nb; d++) {
+    const uint32_t Wl = h->K / h->nb, nblkl = (Wl + 7) / 8, wps = (((nblkl + 1 + 3) & ~3u) >> 2);
+    uint32_t*      d_ml = static_cast<uint32_t*>(cached_const(ckey(CK_CRC_LAT, Kq, h->nb, crc_poly), (size_t)nbq * wps * sizeof(uint32_t), [&](void* dst) {
+      uint32_t* m = static_cast<uint32_t*>(dst);
+      memset(m, 0, (size_t)nbq * wps * sizeof(uint32_t));
+      for (uint32_t d = 0; d < nbq; d++) {
         for (uint32_t w = 0; w < wps; w++) {
-          if (32 * w < W) {
-            const uint32_t nbit = W - 32 * w > 32 ? 32 : W - 32 * w;
-            m[d * wps + w]      = xpow_mod((uint64_t)h->K - ((uint64_t)d * W + 32 * w + nbit), crc_poly);
+          if (32 * w < Wl) {
+            const uint32_t nbit = Wl - 32 * w > 32 ? 32 : Wl - 32 * w;
+            m[d * wps + w]      = xpow_mod((uint64_t)Kq - ((uint64_t)d * Wl + 32 * w + nbit), crc_poly);
           }
         }
       }
-      PHY_HIP_CHECK(hipMalloc(&d_ml, m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
-      PHY_HIP_CHECK(upload(d_ml, m.data(), m.size() * sizeof(uint32_t)), SRSRAN_ERROR);
+    }));
+    if (!d_ml) {
+      return SRSRAN_ERROR;
     }
     p.crc_mult  = d_ml;
     p.ws        = h->d_ws_lat;
@@ -603,14 +698,133 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     return SRSRAN_SUCCESS;
   }
   h->state_in_lat = false;
+  if (h->arena) {
+    const uint32_t cpw = 64 / (nbq / 2);
+    p.ws = static_cast<uint32_t*>(h->arena->ensure((size_t)h->ws_stride * ceil_div(n_cb, cpw) * cpw * sizeof(uint32_t), stream));
+    if (!p.ws) {
+      return SRSRAN_ERROR;
+    }
+  }
   PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;
+}
+
+void* phyhip::turbo::WsArena::ensure(size_t bytes, hipStream_t stream)
+{
+  if (bytes <= cap) {
+    return p;
+  }
+  if (p) {
+    (void)hipStreamSynchronize(stream); // a launch enqueued earlier may still be working in the old arena
+    (void)hipFree(p);
+    p   = nullptr;
+    cap = 0;
+  }
+  const size_t want = bytes + bytes / 4;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    p = nullptr;
+    set_error("turbo decoder: workspace allocation of %zu bytes failed", want);
+    return nullptr;
+  }
+  cap = want;
+  return p;
+}
+phyhip::turbo::WsArena::~WsArena()
+{
+  (void)hipFree(p);
+}
+
+int phyhip::turbo::batch_create_shared(srsran_hip_tdec_batch** h, uint32_t long_cb, uint32_t max_nof_cb, bool llr8_api, WsArena* arena)
+{
+  return tdec_batch_create(h, long_cb, max_nof_cb, SRSRAN_TDEC_AUTO, llr8_api, arena);
+}
+
+// all 188 block sizes x the decoders AUTO selects for 16- and 8-bit soft bits: exchange / interleaver tables and the CRC multipliers of both
+// generators, collected in one host image and placed with one allocation and one upload
+bool phyhip::turbo::prebuild_tables()
+{
+  struct Done {
+    std::mutex mu;
+    int        state = 0; // 0 not yet, 1 ok, -1 failed
+  };
+  Done&                       done = device_local<Done>();
+  std::lock_guard<std::mutex> dl(done.mu);
+  if (done.state) {
+    return done.state > 0;
+  }
+  bool ok = false;
+  {
+    ConstCache& c = ccache();
+    {
+      std::lock_guard<std::mutex> lk(c.mu);
+      c.bulk       = true;
+      c.bulk_owner = std::this_thread::get_id();
+    }
+    const uint32_t polys[2] = {0x1864CFBu, 0x1800063u}; // CRC24A, CRC24B
+    for (int i = 0; i < LTE_QPP_NOF_SIZES; i++) {
+      const uint32_t K = lte_qpp_table[i][0];
+      for (int api8 = 0; api8 < 2; api8++) {
+        srsran_hip_tdec_batch_t* b = nullptr;
+        WsArena                  none; // (no workspace is needed to collect tables)
+        if (tdec_batch_create(&b, K, 1, SRSRAN_TDEC_AUTO, api8 != 0, &none) != SRSRAN_SUCCESS) {
+          continue;
+        }
+        if (b->nb) {
+          const uint32_t nbq = (uint32_t)b->nb;
+          for (uint32_t poly : polys) {
+            (void)cached_const(ckey(CK_CRC_WIN, K, b->nb, poly), nbq * sizeof(uint32_t), [&](void* dst) {
+              uint32_t* m = static_cast<uint32_t*>(dst);
+              for (uint32_t d = 0; d < nbq; d++) {
+                m[d] = xpow_mod((uint64_t)(K / nbq) * (uint64_t)(nbq - 1 - d), poly);
+              }
+            });
+            if (turbo::lat_exists(b->nb, b->arith8)) {
+              const uint32_t Wl = K / nbq, nblkl = (Wl + 7) / 8, wps = (((nblkl + 1 + 3) & ~3u) >> 2);
+              (void)cached_const(ckey(CK_CRC_LAT, K, b->nb, poly), (size_t)nbq * wps * sizeof(uint32_t), [&](void* dst) {
+                uint32_t* m = static_cast<uint32_t*>(dst);
+                memset(m, 0, (size_t)nbq * wps * sizeof(uint32_t));
+                for (uint32_t d = 0; d < nbq; d++) {
+                  for (uint32_t w = 0; w < wps; w++) {
+                    if (32 * w < Wl) {
+                      const uint32_t nbit = Wl - 32 * w > 32 ? 32 : Wl - 32 * w;
+                      m[d * wps + w]      = xpow_mod((uint64_t)K - ((uint64_t)d * Wl + 32 * w + nbit), poly);
+                    }
+                  }
+                }
+              });
+            }
+          }
+        }
+        delete b; // (its table pointers are placeholders: nothing to free)
+      }
+    }
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.bulk = false;
+    ok     = true;
+    if (!c.pending.empty()) {
+      void* d = nullptr;
+      if (hipMalloc(&d, c.img.size()) != hipSuccess || upload(d, c.img.data(), c.img.size()) != hipSuccess) {
+        (void)hipFree(d);
+        ok = false;
+      } else {
+        for (auto& pd : c.pending) {
+          c.dev[pd.first] = static_cast<uint8_t*>(d) + pd.second;
+        }
+      }
+    }
+    c.pending.clear();
+    c.img.clear();
+    c.img.shrink_to_fit();
+  }
+  done.state = ok ? 1 : -1;
+  return ok;
 }
 
 // ------------------------------------------------------------------------------------------------ handle ABI
 
 namespace {
 struct TdecCtx {
+  DeviceTag   tag;
   hipStream_t stream = nullptr;
   // one batch object (max_cb = 1) per (K, nb), created on first use
   std::map<uint64_t, srsran_hip_tdec_batch_t*> dec;
@@ -622,9 +836,15 @@ struct TdecCtx {
   bool     dev_state_valid = false; // the handle's own batch object holds the decoder state of the current code block
 };
 
-TdecCtx* ctx_of(srsran_tdec_t* h)
+TdecCtx* ctx_raw(srsran_tdec_t* h)
 {
   return reinterpret_cast<TdecCtx*>(h->dec16_hdlr[0]);
+}
+// nullptr (error reported) when the decoder lives on another device than the calling thread's
+TdecCtx* ctx_of(srsran_tdec_t* h)
+{
+  TdecCtx* c = ctx_raw(h);
+  return (c && !check_device(c->tag, "srsran_tdec")) ? nullptr : c;
 }
 } // namespace
 
@@ -683,7 +903,7 @@ extern "C" int srsran_tdec_init_manual(srsran_tdec_t* h, uint32_t max_long_cb, s
 
 extern "C" void srsran_tdec_free(srsran_tdec_t* h)
 {
-  TdecCtx* c = ctx_of(h);
+  TdecCtx* c = ctx_raw(h);
   if (c) {
     for (auto& kv : c->dec) {
       srsran_hip_tdec_batch_free(kv.second);
@@ -711,7 +931,7 @@ extern "C" int srsran_tdec_new_cb(srsran_tdec_t* h, uint32_t long_cb)
     fprintf(stderr, "TDEC was initialized for max_long_cb=%d\n", h->max_long_cb);
     return -1;
   }
-  if (TdecCtx* c = ctx_of(h)) {
+  if (TdecCtx* c = ctx_raw(h)) {
     c->dev_state_valid = false;
   }
   h->n_iter          = 0;
@@ -827,7 +1047,7 @@ static bool tdec_run_all_queued(srsran_tdec_t* h, ELEM* input, uint8_t* output, 
   const int    sb_layout = (!h->force_not_sb && (arith8 || (auto_mode && nb > 0))) ? 1 : 0;
   const size_t in_len    = sb_layout ? 3 * ((size_t)K + 32) + 12 : 3 * (size_t)K + 12;
   char         key[96];
-  snprintf(key, sizeof(key), "tdec:K%u:nb%d:a%d:sb%d:e%d:it%u", K, nb, arith8 ? 1 : 0, sb_layout, in8 ? 1 : 0, nit);
+  snprintf(key, sizeof(key), "tdec:d%d:K%u:nb%d:a%d:sb%d:e%d:it%u", current_device(), K, nb, arith8 ? 1 : 0, sb_layout, in8 ? 1 : 0, nit);
   std::shared_ptr<Coalescer> q = coalescer_for(key, [&]() -> Coalescer* {
     const uint32_t cap  = 64;
     const int      impl = arith8 ? (nb == 32 ? SRSRAN_TDEC_AVX8_WINDOW : SRSRAN_TDEC_SSE8_WINDOW)

@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   tdec_win_unit<LPC, AR, ES>(p, blockIdx.x, blockIdx.x, threadIdx.x, Bl, Tr);
 }
 
+#ifdef SRSRAN_HIP_WITH_VARIANTS // compiled into tools/probe/lib/libsrsran_phy_hip_variants.so only (srslte_amd/build.py --variants)
 // ---- measured alternatives of the launch shape (profiles/r02_turbo_variants.txt, DESIGN.md par. 3.2); selected with
 // SRSRAN_HIP_TDEC_VARIANT for the 16-sub-block int16 decoder without early stop only, never by default.
 // "waves1": one wave per SIMD (half the code blocks in flight, up to 512 VGPRs per lane).
@@ -1118,6 +1119,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
+#endif // SRSRAN_HIP_WITH_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // Scalar decoder (turbodecoder_gen.c): one lane per code block, wrapping int16, beta kept in HBM.
 // Used for K <= 400 (AUTO) or SRSRAN_TDEC_GENERIC.  Vectors are stored lane-interleaved
@@ -1339,6 +1341,7 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(const GenParams p)
 #undef GV
 }
 
+
 // ------------------------------------------------------------------------------------------------ launchers
 
 template <bool ES>
@@ -1346,11 +1349,14 @@ static hipError_t launch_win_es(int nb, bool arith8, const WinParams& p, hipStre
 {
   const int lpc = nb / 2;
   dim3      grid(ceil_div(p.n_cb, 64 / lpc));
+#ifdef SRSRAN_HIP_WITH_VARIANTS
   if (!ES && !arith8 && nb == 16 && p.variant == 1) {
     hipLaunchKernelGGL(tdec_win_kernel_waves1, grid, dim3(64), 0, stream, p);
   } else if (!ES && !arith8 && nb == 16 && p.variant == 2 && p.unit_counter) {
     hipLaunchKernelGGL(tdec_win_kernel_persistent, dim3(p.n_units < p.max_resident ? p.n_units : p.max_resident), dim3(64), 0, stream, p);
-  } else if (!arith8 && nb == 16) {
+  } else
+#endif
+  if (!arith8 && nb == 16) {
     hipLaunchKernelGGL((tdec_win_kernel<8, Ar16, ES>), grid, dim3(64), 0, stream, p);
   } else if (!arith8 && nb == 8) {
     hipLaunchKernelGGL((tdec_win_kernel<4, Ar16, ES>), grid, dim3(64), 0, stream, p);

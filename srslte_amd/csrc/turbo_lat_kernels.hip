@@ -351,7 +351,7 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
   // with one wave-wide ballot per sub-block of a pair: the 8 lanes of a pair hold the 8 steps of a block = one byte.  History: walking D one block
   // per memory round trip cost a third of an early-stop half iteration; collecting the bits inside the block loop (LDS atomics, byte stores into a
   // scratch, two 64-bit registers per lane) cost 11.5 of its 69.5 us whichever way; this form costs the same per half iteration (the store 6.7 us,
-  // the pass over D 5 us: tools/dbg/es_time.py against builds without either) but needs no image clearing and 25 registers fewer (72 instead of
+  // the pass over D 5 us: tools/measure/es_time.py against builds without either) but needs no image clearing and 25 registers fewer (72 instead of
   // 97 AGPRs of spilled state), which shows in the launch's fixed part: 832 blocks 0.182 -> 0.158 ms at one half iteration.
   uint8_t*       simg   = reinterpret_cast<uint8_t*>(&simg_all[grp][0]);
   const uint32_t sbs4   = (nblk + 1 + 3) & ~3u; // bytes per sub-block in the image

@@ -116,7 +116,7 @@ int srsran_pusch_decode(srsran_pusch_t* q, srsran_ul_sf_cfg_t* sf, srsran_pusch_
                                                     .rv                 = (uint32_t)cfg->grant.tb.rv,
                                                     .nof_re             = cfg->grant.nof_re,
                                                     .seed               = srsran_hip_sequence_pusch_seed(cfg->rnti, nslot, q->cell.id),
-                                                    .max_nof_iterations = cfg->max_nof_iterations,
+                                                    .max_nof_iterations = 0, /* below */
                                                     .llr_is_8bit        = q->llr_is_8bit,
                                                     .nl                 = 1},
                                  .cell_nof_prb   = q->cell.nof_prb,
@@ -127,7 +127,8 @@ int srsran_pusch_decode(srsran_pusch_t* q, srsran_ul_sf_cfg_t* sf, srsran_pusch_
                                  .noise_estimate = channel->noise_estimate,
                                  .meas_epre      = cfg->meas_epre_en};
   srsran_hip_grant_res_t r;
-  srsran_sch_set_max_noi(&q->ul_sch, cfg->max_nof_iterations); /* :452 */
+  srsran_sch_set_max_noi(&q->ul_sch, cfg->max_nof_iterations); /* :452 (0 = the reference's default) */
+  g.tb.max_nof_iterations = q->ul_sch.max_iterations;
   srsran_cbsegm_t seg;
   if (srsran_cbsegm(&seg, g.tb.tbs) == SRSRAN_SUCCESS) {
     cfg->K_segm = seg.C1 * seg.K1 + seg.C2 * seg.K2; /* sch.c:1141 */

@@ -187,7 +187,7 @@ def test_pusch_grant_harq_and_failure(hiplib):
     cb_data = np.zeros((seg["C"], 768), np.uint8)
     lut = O.ulsch_interleaver_lut(nof_re, Qm, nsymb)
     outcomes = []
-    for rv, snr in ((0, 1.5), (2, 7.0), (3, 13.0)):
+    for rv, snr in ((0, 9.0), (2, 13.0), (3, 15.0)):
         grid, ce, seed = _pusch_signal(rng, nof_prb, cp_nsymb, n_prb, L_prb, 0, mod, tbs, rv, rnti, tti, cell_id, snr, payload_bits)
         g = capi.HipPuschRx(capi.HipGrantTb(mod, tbs, rv, nof_re, seed, iters, 0, 1), nof_prb, cp_nsymb, (C.c_uint32 * 2)(*n_prb), L_prb, 0, noise, 0)
         data = np.zeros(tbs // 8 + 16, np.uint8)

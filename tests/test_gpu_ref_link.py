@@ -50,7 +50,7 @@ def test_turbodecoder_test(args, data_dir):
 @pytest.mark.parametrize("length", [504, 1024, 6144])
 def test_turbodecoder_test_error_free_at_high_snr(length, data_dir):
     """(K = 40 is not in this list: 40-bit blocks at this noise level do fail now and then -- seen once in three runs, with the device output
-    equal to the oracle's on 3,600 such blocks (tools/dbg/k40_check.py) -- and the program's noise is not reproducible here: it draws from
+    equal to the oracle's on 3,600 such blocks (tools/measure/k40_check.py) -- and the program's noise is not reproducible here: it draws from
     rand(), whose state the HIP runtime's threads share)"""
     rc, out = _run("turbodecoder_test", ("-n 30 -s 1 -l %d -e 6.0" % length).split(), data_dir)
     assert rc == 0 and "Done" in out and "Errors" not in out, out[-2000:]

@@ -231,6 +231,29 @@ def test_no_gpu_means_loud_failure(L):
     assert L.srsran_tdec_init(C.byref(t), 6144) == capi.SRSRAN_ERROR
 
 
+def test_device_binding_bookkeeping_without_a_device(L):
+    """srsran_hip_set_device / srsran_hip_set_thread_device on a box without a GPU: no device to bind to -> an error and a message, never a crash;
+    returning a thread to the process default always works; the grant-level entry points and the warm-up fail loudly too"""
+    from srslte_amd import capi
+
+    if L.srsran_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    capi.lib()
+    assert L.srsran_hip_set_device(0) == capi.SRSRAN_ERROR and b"no device 0" in L.srsran_hip_last_error()
+    assert L.srsran_hip_set_thread_device(0) == capi.SRSRAN_ERROR and b"no device 0" in L.srsran_hip_last_error()
+    assert L.srsran_hip_set_thread_device(3) == capi.SRSRAN_ERROR
+    assert L.srsran_hip_set_thread_device(-1) == capi.SRSRAN_SUCCESS
+    assert L.srsran_hip_get_thread_device() == 0
+    assert L.srsran_hip_warmup(2) == capi.SRSRAN_ERROR
+    L.srsran_rm_turbo_gentables()  # the init-time hook of srsran_sch_init: a no-op without a device
+    g = capi.HipPdschRx(capi.HipGrantTb(2, 6200, 0, 2400, 1, 8, 0, 1), 1.0, 0.0)
+    x = (C.c_float * 4800)()
+    rows = (C.c_void_p * 2)()
+    sb = capi.SoftbufferRx(2, 18600, rows, rows, None, False)
+    res = capi.HipGrantRes()
+    assert L.srsran_hip_pdsch_decode(C.byref(g), x, None, C.byref(sb), x, C.byref(res)) == capi.SRSRAN_ERROR
+
+
 def test_product_never_touches_the_oracle():
     """nothing under srslte_amd/ or include/ may reference oracle/ (the oracle is the checker, not the product)"""
     bad = []

@@ -353,7 +353,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
     own transmit side; channel estimation (out of scope) is replaced by the known flat channel.
     sf = 184: 64 x 184 x 11 code blocks are eight rounds of the 2048 waves the early-stop decoder keeps resident.  The end of a launch runs
     on a part of the chip (waves take 2 ... 8 half iterations, CUs differ in speed): 46 subframes (two rounds) 44.8 Gbit/s, 92 50.6, 184 53.6
-    on one box (tools/dbg/uplink_sf.py)."""
+    on one box (tools/measure/uplink_sf.py)."""
     import torch
 
     import srslte_amd as S
@@ -629,7 +629,7 @@ def host_fed_turbo(S, capi, torch, dev, d_llr, in_stride, K, nit, llr8, chunk=81
     import oracle_api as O
 
     lib = S.lib()
-    chunk, n_streams = int(os.environ.get('HOSTFED_CHUNK', chunk)), int(os.environ.get('HOSTFED_STREAMS', n_streams))  # (tools/dbg/hostfed.py sweeps them)
+    chunk, n_streams = int(os.environ.get('HOSTFED_CHUNK', chunk)), int(os.environ.get('HOSTFED_STREAMS', n_streams))  # (tools/measure/hostfed.py sweeps them)
     n = chunk * n_chunks
     if llr8:
         _, pool = O.turbo_llrs_8bit(K, 64, 1.0, seed=5)

@@ -18,8 +18,8 @@ python tools/bench_tti.py --out $OUT/tti.json > /dev/null 2> $OUT/tti.err &&
 ( rocprofv3 --kernel-trace --stats -d $OUT/trace_tti -o t -- python tools/bench_tti.py --calls 100 --snrs 6.0 --ntb 1,64 > /dev/null 2> $OUT/trace_tti.err; python tools/rocpd_summary.py $OUT/trace_tti > $OUT/tti_kernel_stats.txt; rm -rf $OUT/trace_tti ) &&
 python tools/seam_bench.py > $OUT/seam_time.json 2> $OUT/seam_time.err &&
 python tools/bench_ref_programs.py > $OUT/ref_programs.json 2> $OUT/ref_programs.err &&
-python tools/dbg/es_time.py 1 > $OUT/es_time.txt 2> /dev/null && python tools/dbg/es_time.py 64 >> $OUT/es_time.txt 2> /dev/null &&
-( python tools/dbg/lat_time.py 6144 0; python tools/dbg/lat_time.py 5824 1; python tools/dbg/lat_time.py 6144 0 8 ) > $OUT/lat_time.txt 2> /dev/null &&
+python tools/measure/es_time.py 1 > $OUT/es_time.txt 2> /dev/null && python tools/measure/es_time.py 64 >> $OUT/es_time.txt 2> /dev/null &&
+( python tools/measure/lat_time.py 6144 0; python tools/measure/lat_time.py 5824 1; python tools/measure/lat_time.py 6144 0 8 ) > $OUT/lat_time.txt 2> /dev/null &&
 python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
 python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
 python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&
@@ -49,10 +49,10 @@ for V in product waves1 persistent; do
 done
 unset SRSRAN_HIP_TDEC_VARIANT
 # ---- the 8-bit decoders (what srsenb / srsue run): time against the 16-bit one and the reference's, traffic and VALU counters
-python tools/dbg/turbo8_time.py > $OUT/turbo8_time.txt 2> /dev/null
+python tools/measure/turbo8_time.py > $OUT/turbo8_time.txt 2> /dev/null
 : > $OUT/pmc_turbo8.txt
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
-  rocprofv3 --pmc $C -d $OUT/t8 -o p -- python tools/dbg/turbo8_time.py > /dev/null 2> $OUT/v.err &&
+  rocprofv3 --pmc $C -d $OUT/t8 -o p -- python tools/measure/turbo8_time.py > /dev/null 2> $OUT/v.err &&
   python tools/rocpd_summary.py $OUT/t8 | grep -E "tdec_win" >> $OUT/pmc_turbo8.txt
   rm -rf $OUT/t8
 done
@@ -72,7 +72,7 @@ unset SRSRAN_HIP_PSS_VARIANT
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o roundtrip_probe roundtrip_probe.hip -lpthread 2> /dev/null; ./roundtrip_probe 0 ) > $OUT/roundtrip_probe.txt 2>&1
 ( cd tools/probe && gcc -O2 -I../../include seam_threads.c -o seam_threads -L../../srslte_amd/lib -lsrsran_phy_hip -Wl,-rpath,'$ORIGIN/../../srslte_amd/lib' -lpthread -lm 2> /dev/null
   echo "== the library's default (it asks for 8 hardware queues)"; ./seam_threads; echo "== GPU_MAX_HW_QUEUES=4 (the runtime's own default)"; GPU_MAX_HW_QUEUES=4 ./seam_threads ) > $OUT/seam_threads.txt 2>&1
-python tools/dbg/enc_time.py > $OUT/enc_time.txt 2> /dev/null
+python tools/measure/enc_time.py > $OUT/enc_time.txt 2> /dev/null
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -o acs_layout_probe acs_layout_probe.hip 2> /dev/null; ./acs_layout_probe ) > $OUT/acs_layout_probe.txt 2>&1
 cat $OUT/acs_layout_probe.txt
 echo "profile pass rc=$?"

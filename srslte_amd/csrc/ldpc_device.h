@@ -46,6 +46,9 @@ struct Params {
   // (x * M) >> 9 == x * sf / 100 for every x in 0..127, or 0 when there is no such M
   int             packed;
   int             sf_m9;
+  // packed kernel, small batches: the check-to-variable messages of a workgroup's code word live in LDS next to its soft words (one word per
+  // workgroup; n_edges * Z more bytes) -- a row then waits for LDS, not for the L2 / HBM round trip of its message loads
+  int             c2v_lds;
   // optional indirection: code word i of the batch reads its LLRs from / writes its message to row cw_map[i] (the NR
   // transport-block loop decodes the not-yet-decoded code blocks of a soft buffer in place); n_iter_out stays indexed by i
   const uint32_t* cw_map;
@@ -57,6 +60,7 @@ hipError_t launch(const Params& p, hipStream_t stream);
 size_t     lds_bytes(const Params& p);
 bool       packed_applies(const Params& p); // int8, layered, even lifting size, no per-iteration / soft-bit side outputs
 hipError_t launch_packed(const Params& p, hipStream_t stream);
+bool       packed_c2v_lds_fits(const Params& p); // one code word per workgroup with its messages in LDS fits a CU's LDS
 
 } // namespace ldpc
 } // namespace phyhip

@@ -408,7 +408,8 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
     }
     p.sf_m9 = ok ? M : 0;
   }
-  p.packed = 0;
+  p.packed  = 0;
+  p.c2v_lds = 0;
   if (ldpc::packed_applies(p)) {
     // code words per workgroup for Z / 2 lanes per word (26 KB of soft words for BG1 Z = 384: four words, 12 waves)
     const int cap  = h->slots * h->cpb; // code-word slabs allocated
@@ -423,6 +424,14 @@ static int ldpc_batch_run(srsran_hip_ldpc_batch_t* h, const void* d_llrs, uint32
     p.cpb       = pcpb;
     p.max_slots = cap / pcpb;
     p.packed    = 1;
+    // Small batches (a transport block's code blocks, a single srsran_ldpc_decoder_decode_c call): no more words than the chip has CUs, so a word may
+    // have a CU's LDS to itself -- its check-to-variable messages then live there (BG1 Z = 384: 121 KB next to 26 KB of soft words) and a row waits
+    // for LDS instead of the L2 / HBM round trip of its message loads (SRSRAN_HIP_LDPC_C2V_LDS=0: never)
+    if ((int)n_cw <= 256 && knob(KNOB_LDPC_C2V_LDS) != 0 && ldpc::packed_c2v_lds_fits(p)) {
+      p.cpb       = 1;
+      p.max_slots = cap;
+      p.c2v_lds   = 1;
+    }
   }
   PHY_HIP_CHECK(ldpc::launch(p, (hipStream_t)stream), SRSRAN_ERROR);
   return SRSRAN_SUCCESS;

@@ -54,9 +54,10 @@ static __device__ __forceinline__ s2v clip(s2v x, short lim)
 constexpr short kBias = 128; // stored bytes are value + 128 (layer_packed)
 // KEEP_A: keep the magnitudes in registers between the two passes (the early-stop instantiation recomputes them instead:
 // its extra state would push the 19-edge rows into scratch)
-template <int DEG, bool KEEP_A>
+// CL: the check-to-variable words of this code word are in LDS at byte address c2v_lds (+ edge * Z + 2 c) instead of the global slab
+template <int DEG, bool KEEP_A, bool CL>
 __device__ __forceinline__ void layer_packed(const __attribute__((address_space(4))) int* ec, char* sbase, __amdgpu_buffer_rsrc_t c2v, uint32_t coff, int e0, int c, uint32_t Z, uint32_t H,
-                                             unsigned short m9, bool active)
+                                             unsigned short m9, bool active, uint32_t c2v_lds)
 {
   int ed[DEG];
 #pragma unroll
@@ -94,7 +95,8 @@ __device__ __forceinline__ void layer_packed(const __attribute__((address_space(
     wsel[i]             = swp ? 0x0c0c0002u : 0x0c0c0200u;
     idx[i]              = (int)(cb + (wrap ? negZ : 0u) + (((uint32_t)ed[i] & 0xffffu) + sh2));
     const uint32_t sw   = *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>((uintptr_t)idx[i]);
-    const uint32_t cw   = __builtin_amdgcn_raw_buffer_load_b16(c2v, coffb, rowb + (uint32_t)i * Z, 0);
+    const uint32_t cw   = CL ? (uint32_t)*reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>((uintptr_t)(c2v_lds + coffb + rowb + (uint32_t)i * Z))
+                             : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(c2v, coffb, rowb + (uint32_t)i * Z, 0);
     // bytes 0 / 1 to the halves of the lane's pair, zero-extended (swapped pairs: byte 1 is the low half)
     s[i]  = as_s2(__builtin_amdgcn_perm(0u, sw, swp ? 0x0c000c01u : 0x0c010c00u));
     co[i] = as_s2(__builtin_amdgcn_perm(0u, cw, 0x0c010c00u));
@@ -138,7 +140,12 @@ __device__ __forceinline__ void layer_packed(const __attribute__((address_space(
     const s2v mag = pmax(s0, c1 - av * splat2(129)); // 129: a multiply-add, and 129 * 127 + 127 still fits 16 bits
     const s2v sg  = (as_s2(sgn ^ as_u32(x[i])) >> 15) | splat2(1); // -1 where the product of the OTHER signs is negative, else 1
     const s2v cnb = mag * sg + kb;                                 // the new message, biased
-    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)__builtin_amdgcn_perm(0u, as_u32(cnb), 0x0c0c0200u), c2v, coffb, rowb + (uint32_t)i * Z, 0);
+    if (CL) {
+      *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)(c2v_lds + coffb + rowb + (uint32_t)i * Z)) =
+          (uint16_t)__builtin_amdgcn_perm(0u, as_u32(cnb), 0x0c0c0200u);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)__builtin_amdgcn_perm(0u, as_u32(cnb), 0x0c0c0200u), c2v, coffb, rowb + (uint32_t)i * Z, 0);
+    }
     // :308-315: t > 63 -> 127, t < -63 -> -127, kept in the soft words as +-64 (only this kernel reads them, and only their sign leaves it)
     const s2v res = pmin(pmax(cnb + x[i], splat2(kBias - 64)), splat2(kBias + 64));
     *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)idx[i]) =
@@ -150,10 +157,11 @@ static size_t lds_bytes_packed(const Params& p)
 {
   const size_t per_cw = (size_t)p.bgN * (p.Z / 2) * 2;
   const size_t red    = p.crc_order ? (p.cpb == 1 ? (size_t)16 : (size_t)((p.cpb * (p.Z / 2) + 63) / 64) * 64 + 8) : 0;
-  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + red * sizeof(int);
+  const size_t c2v    = p.c2v_lds ? (((size_t)p.n_edges * p.Z + 15) & ~(size_t)15) : 0; // behind the soft words and the reduction words
+  return (((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + red * sizeof(int) + c2v;
 }
 
-template <bool ES>
+template <bool ES, bool CL>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) void ldpc_packed_kernel(const Params p)
 {
   extern __shared__ int8_t lds[];
@@ -173,6 +181,10 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   typedef const __attribute__((address_space(4))) int* cint_p;
   const cint_p ec = (cint_p)p.edges, row_start = (cint_p)p.row_start;
   const unsigned short m9 = (unsigned short)p.sf_m9;
+  // CL: this workgroup's (one) code word keeps its messages in LDS behind the soft words and the CRC reduction words
+  const uint32_t c2v_lds = CL ? (uint32_t)(reinterpret_cast<char*>(lds) - static_cast<char*>(nullptr)) +
+                                    (uint32_t)((((size_t)p.cpb * per_cw + 15) & ~(size_t)15) + (p.crc_order ? (p.cpb == 1 ? 16u : (uint32_t)((p.cpb * H + 63) / 64) * 64u + 8u) : 0u) * sizeof(int))
+                              : 0u;
 
   // Code words are handed out by a counter, not in fixed shares: a workgroup takes words blockIdx.x * cpb ... first and asks for more when
   // it is done.  The CUs do not all run at the same speed (with 1280 persistent workgroups and 12.8 words each by a fixed stride the launch
@@ -200,7 +212,11 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         soft2[n * H + c] = (uint16_t)(lo | (hi << 8));
       }
       for (int e = 0; e < p.n_edges; e++) {
-        c2v[(uint32_t)e * H + coff] = (uint16_t)(kBias | (kBias << 8));
+        if (CL) {
+          *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>((uintptr_t)(c2v_lds + (uint32_t)e * Z + (uint32_t)c * 2u)) = (uint16_t)(kBias | (kBias << 8));
+        } else {
+          c2v[(uint32_t)e * H + coff] = (uint16_t)(kBias | (kBias << 8));
+        }
       }
     }
     __syncthreads();
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         switch (deg) {
 #define LDPC_CASE(D)                                                                                                   \
   case D:                                                                                                              \
-    layer_packed<D, !ES>(ec, sbase, c2v_rsrc, coff, e0, c, Z, H, m9, active);                                               \
+    layer_packed<D, !ES, CL>(ec, sbase, c2v_rsrc, coff, e0, c, Z, H, m9, active, c2v_lds);                                  \
     break;
           LDPC_CASE(1)
           LDPC_CASE(2)
@@ -370,29 +386,42 @@ int grid_slots_packed(const Params& p)
   return groups < slots ? groups : slots;
 }
 
-template <bool ES>
+template <bool ES, bool CL>
 static hipError_t launch_packed_es(const Params& p, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_packed_kernel<ES>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  static bool attr_set[kMaxDevices] = {};
+  const int   dev = current_device();
+  if (!attr_set[dev < kMaxDevices && dev >= 0 ? dev : 0]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_packed_kernel<ES, CL>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (e != hipSuccess) {
       return e;
     }
-    attr_set = true;
+    attr_set[dev < kMaxDevices && dev >= 0 ? dev : 0] = true;
   }
   int threads = p.cpb * (p.Z / 2);
   threads     = ((threads + 63) / 64) * 64;
-  hipLaunchKernelGGL((ldpc_packed_kernel<ES>), dim3(grid_slots_packed(p)), dim3(threads), lds_bytes_packed(p), stream, p);
+  hipLaunchKernelGGL((ldpc_packed_kernel<ES, CL>), dim3(grid_slots_packed(p)), dim3(threads), lds_bytes_packed(p), stream, p);
   return hipGetLastError();
+}
+
+// messages in LDS: one code word per workgroup, soft words + messages within the LDS of a CU
+bool packed_c2v_lds_fits(const Params& p)
+{
+  Params q  = p;
+  q.cpb     = 1;
+  q.c2v_lds = 1;
+  return lds_bytes_packed(q) <= 156 * 1024;
 }
 
 hipError_t launch_packed(const Params& p, hipStream_t stream)
 {
-  if (lds_bytes_packed(p) > 156 * 1024 || p.cpb * (p.Z / 2) > 768) {
+  if (lds_bytes_packed(p) > 156 * 1024 || p.cpb * (p.Z / 2) > 768 || (p.c2v_lds && p.cpb != 1)) {
     return hipErrorInvalidValue;
   }
-  return p.crc_order ? launch_packed_es<true>(p, stream) : launch_packed_es<false>(p, stream);
+  if (p.c2v_lds) {
+    return p.crc_order ? launch_packed_es<true, true>(p, stream) : launch_packed_es<false, true>(p, stream);
+  }
+  return p.crc_order ? launch_packed_es<true, false>(p, stream) : launch_packed_es<false, false>(p, stream);
 }
 
 } // namespace ldpc

@@ -27,12 +27,12 @@ struct TbCbJob { // one code block of a transport block
   uint32_t table_len;
   uint32_t pad;
   uint32_t crc_mult_row; // CRC24B: row of TbParams::crc_mult with lane l's x^(bits behind its stretch) mod g for a block of this many bits
-  uint32_t pad2;
+  uint32_t crc_mult256_row; // latency kernel: row of TbParams::crc_mult256 (256 lanes, stretches counted from the END of the message)
 };
 struct TbCrcJob { // CRC24A of one transport block
   uint32_t src_byte, n_bytes;
   uint32_t crc_mult_row; // row of TbParams::crc_mult with lane l's x^(8 bytes behind its stretch) mod g for this many bytes
-  uint32_t pad;
+  uint32_t crc_mult256_row; // latency kernel: row of TbParams::crc_mult256
 };
 // the lanes' stretches of an n-unit message and what lies behind them: lane l takes units [min(l L, n), min((l + 1) L, n)), L = ceil(n / 64)
 void crc_lane_multipliers(uint32_t n_units, uint32_t bits_per_unit, uint32_t poly24, uint32_t* m64);
@@ -44,7 +44,15 @@ struct TbParams {
   uint32_t*       tb_crc; // n_tb checksums (device scratch)
   const uint32_t* crc_mult; // rows of 64 lane multipliers (host: crc_lane_multipliers)
   uint32_t        n_cb, n_tb;
+  const uint32_t* crc_mult256; // latency kernel: rows of 256 lane multipliers (host: crc_lane_multipliers256)
 };
+// Latency kernel's split of an n-unit message over 256 lanes: stretches of L = ceil(n / 256) units counted from the END (lane 255 takes the last L
+// units, lane l the units [n - (256 - l) L, n - (255 - l) L) clipped at 0 -- leading zeros do not change a CRC with a zero start), so every lane has
+// (255 - l) L units behind it: m[l] = x^(bits_per_unit L (255 - l)) mod g.
+void crc_lane_multipliers256(uint32_t n_units, uint32_t bits_per_unit, uint32_t poly24, uint32_t* m256);
+// One launch for a transport block (or a subframe's worth of them): one workgroup of 256 lanes per code block -- payload bits, transport CRC24A (by the
+// workgroup of the block that carries it), CRC24B, both constituent encoders, rate matching.  Same TbParams; tb_crc scratch unused.
+hipError_t launch_tb_encode_lat(const TbParams& p, hipStream_t stream);
 hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream);
 
 struct LutEncParams { // srsran_tcod_encode_lut for one code block

@@ -302,6 +302,11 @@ struct srsran_hip_sch_enc {
   uint32_t*                    d_mult = nullptr;
   uint32_t*                    h_mult = nullptr; // pinned mirror: a new row goes up by an asynchronous copy on the call's stream, in front of the kernel
   uint32_t                     mult_rows_cap = 0;
+  // the latency kernel's rows of 256 lane multipliers (tcod_device.h: crc_lane_multipliers256), same scheme
+  std::map<uint32_t, uint32_t> mult256_row;
+  uint32_t*                    d_mult256 = nullptr;
+  uint32_t*                    h_mult256 = nullptr;
+  uint32_t                     mult256_rows_cap = 0;
 };
 
 namespace {
@@ -334,6 +339,17 @@ void phyhip::tcod::crc_lane_multipliers(uint32_t n_units, uint32_t bits_per_unit
   for (uint32_t l = 0; l < 64; l++) {
     const uint32_t i1 = std::min((l + 1) * L, n_units);
     m64[l]            = h_xpow24(bits_per_unit * (n_units - i1), poly24);
+  }
+}
+
+void phyhip::tcod::crc_lane_multipliers256(uint32_t n_units, uint32_t bits_per_unit, uint32_t poly24, uint32_t* m256)
+{
+  // m[l] = (x^(bits per stretch))^(255 - l): one exponentiation, then one multiplication per lane
+  const uint32_t L    = (n_units + 255u) / 256u;
+  const uint32_t step = h_xpow24(bits_per_unit * L, poly24);
+  m256[255]           = 1;
+  for (int l = 254; l >= 0; l--) {
+    m256[l] = h_mulmod24(m256[l + 1], step, poly24);
   }
 }
 
@@ -378,6 +394,44 @@ static uint32_t enc_mult_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb,
   return it->second; // (a row INDEX: the table may move while a call's jobs are still being written)
 }
 
+static uint32_t enc_mult256_row(srsran_hip_sch_enc_t* h, uint32_t n_units, bool cb, hipStream_t st)
+{
+  const uint32_t key = n_units | (cb ? 0x80000000u : 0u);
+  auto           it  = h->mult256_row.find(key);
+  if (it == h->mult256_row.end()) {
+    const uint32_t row = (uint32_t)h->mult256_row.size();
+    if (row >= h->mult256_rows_cap) {
+      const uint32_t cap = h->mult256_rows_cap ? 2 * h->mult256_rows_cap : 16;
+      uint32_t *     nd = nullptr, *nh = nullptr;
+      if (hipMalloc(&nd, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess || hipHostMalloc(&nh, (size_t)cap * 256 * sizeof(uint32_t)) != hipSuccess ||
+          hipDeviceSynchronize() != hipSuccess ||
+          (h->d_mult256 && (hipMemcpy(nd, h->d_mult256, (size_t)row * 256 * sizeof(uint32_t), hipMemcpyDeviceToDevice) != hipSuccess ||
+                            hipDeviceSynchronize() != hipSuccess))) {
+        (void)hipFree(nd);
+        (void)hipHostFree(nh);
+        set_error("sch encode: device allocation of the CRC multiplier table failed");
+        return 0xffffffffu;
+      }
+      if (h->h_mult256) {
+        memcpy(nh, h->h_mult256, (size_t)row * 256 * sizeof(uint32_t));
+      }
+      (void)hipFree(h->d_mult256);
+      (void)hipHostFree(h->h_mult256);
+      h->d_mult256        = nd;
+      h->h_mult256        = nh;
+      h->mult256_rows_cap = cap;
+    }
+    uint32_t* m = h->h_mult256 + (size_t)row * 256;
+    tcod::crc_lane_multipliers256(n_units, cb ? 1u : 8u, cb ? 0x800063u : 0x864CFBu, m);
+    if (hipMemcpyAsync(h->d_mult256 + (size_t)row * 256, m, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+      set_error("sch encode: upload of the CRC multiplier table failed");
+      return 0xffffffffu;
+    }
+    it = h->mult256_row.emplace(key, row).first;
+  }
+  return it->second;
+}
+
 extern "C" int srsran_hip_sch_enc_create(srsran_hip_sch_enc_t** hh)
 {
   if (!hh) {
@@ -408,6 +462,8 @@ extern "C" void srsran_hip_sch_enc_free(srsran_hip_sch_enc_t* h)
   (void)hipHostFree(h->h_scratch);
   (void)hipFree(h->d_mult);
   (void)hipHostFree(h->h_mult);
+  (void)hipFree(h->d_mult256);
+  (void)hipHostFree(h->h_mult256);
   (void)hipEventDestroy(h->done);
   delete h;
 }
@@ -485,12 +541,15 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
     }
     return &c;
   };
+  // A subframe's worth of code blocks or less: ONE launch, a workgroup of 256 lanes per code block (tcod_kernels.hip: tb_encode_lat_kernel) -- the
+  // throughput kernels give a block to one wave and need a launch of their own for the transport CRCs (SRSRAN_HIP_TCOD_LAT=0 keeps them)
+  const bool lat = n_cb <= 64 && knob(KNOB_TCOD_LAT) != 0;
   size_t at = 0;
   for (uint32_t t = 0; t < n_tb; t++) {
     const srsran_hip_tb_t& tb = tbs[t];
     const srsran_cbsegm_t& cs = seg[t];
-    crcs[t]                   = {tb.data_offset, tb.tbs / 8, enc_mult_row(h, tb.tbs / 8, false, st), 0};
-    if (crcs[t].crc_mult_row == 0xffffffffu) {
+    crcs[t]                   = {tb.data_offset, tb.tbs / 8, lat ? 0u : enc_mult_row(h, tb.tbs / 8, false, st), lat ? enc_mult256_row(h, tb.tbs / 8, false, st) : 0u};
+    if (crcs[t].crc_mult_row == 0xffffffffu || crcs[t].crc_mult256_row == 0xffffffffu) {
       return SRSRAN_ERROR;
     }
     // sch.c:254-330: bits per block and rate-matched lengths
@@ -517,8 +576,9 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
       j.f2                = ki->f2;
       j.table             = ki->table;
       j.table_len         = ki->table_len;
-      j.crc_mult_row      = j.crc24b ? enc_mult_row(h, j.n_src_bits + (last ? 24u : 0u), true, st) : 0u;
-      if (j.crc_mult_row == 0xffffffffu) {
+      j.crc_mult_row      = (j.crc24b && !lat) ? enc_mult_row(h, j.n_src_bits + (last ? 24u : 0u), true, st) : 0u;
+      j.crc_mult256_row   = (j.crc24b && lat) ? enc_mult256_row(h, j.n_src_bits + (last ? 24u : 0u), true, st) : 0u;
+      if (j.crc_mult_row == 0xffffffffu || j.crc_mult256_row == 0xffffffffu) {
         return SRSRAN_ERROR;
       }
       src += j.n_src_bits;
@@ -537,6 +597,7 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
   p.n_cb   = (uint32_t)n_cb;
   p.n_tb   = n_tb;
   p.crc_mult = h->d_mult;
+  p.crc_mult256 = h->d_mult256;
   // the code blocks OR their partial bytes into the output: clear every transport block's range first (adjacent ranges merged)
   std::vector<std::pair<uint32_t, uint32_t>> rng;
   for (uint32_t t = 0; t < n_tb; t++) {
@@ -550,8 +611,12 @@ extern "C" int srsran_hip_sch_encode(srsran_hip_sch_enc_t* h, const uint8_t* d_d
     }
     PHY_HIP_CHECK(hipMemsetAsync(d_e_bits + b0, 0, b1 - b0, st), SRSRAN_ERROR);
   }
-  PHY_HIP_CHECK(tcod::launch_tb_crc24a(p, st), SRSRAN_ERROR);
-  PHY_HIP_CHECK(tcod::launch_tb_encode(p, st), SRSRAN_ERROR);
+  if (lat) {
+    PHY_HIP_CHECK(tcod::launch_tb_encode_lat(p, st), SRSRAN_ERROR);
+  } else {
+    PHY_HIP_CHECK(tcod::launch_tb_crc24a(p, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(tcod::launch_tb_encode(p, st), SRSRAN_ERROR);
+  }
   PHY_HIP_CHECK(hipEventRecord(h->done, st), SRSRAN_ERROR);
   h->pending = true;
   return SRSRAN_SUCCESS;
@@ -679,9 +744,13 @@ int phyhip::sch::encode_tb_staged(srsran_softbuffer_tx_t* softbuffer, srsran_cbs
     return SRSRAN_ERROR;
   }
   const srsran_hip_tb_t tb = {tbs, Qm, rv, nof_e_bits, 0, 0, 0};
-  // (the payload goes up with a copy operation: the CRC and encoder kernels read it byte-wise and more than once, which is slow across the bus)
-  PHY_HIP_CHECK(hipMemcpyAsync(s.dev + d_pay, s.pin + o_pay, tbs / 8, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
-  if (srsran_hip_sch_encode(s.enc, s.dev + d_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
+  // The one-launch kernel of a transport block reads the payload ONCE, a dword per lane: straight from the pinned image.  (The throughput kernels read it
+  // byte-wise and more than once, which is slow across the bus: for them -- more than 64 code blocks never happen here, SRSRAN_HIP_TCOD_LAT=0 does -- it goes up with a copy.)
+  const bool direct = C <= 64 && knob(KNOB_TCOD_LAT) != 0;
+  if (!direct) {
+    PHY_HIP_CHECK(hipMemcpyAsync(s.dev + d_pay, s.pin + o_pay, tbs / 8, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  }
+  if (srsran_hip_sch_encode(s.enc, direct ? s.pin + o_pay : s.dev + d_pay, &tb, 1, s.dev, s.st) != SRSRAN_SUCCESS) {
     (void)hipStreamSynchronize(s.st);
     fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
     return SRSRAN_ERROR;

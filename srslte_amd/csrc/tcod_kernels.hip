@@ -245,6 +245,227 @@ __global__ __launch_bounds__(64) void tb_encode_kernel(const TbParams p)
   }
 }
 
+// ---- latency kernel: one workgroup of 256 lanes per code block, everything of sch.c:238-345 for that block in one launch ----------------------
+//
+// The throughput kernel above gives a code block to ONE wave: 96 trellis steps per lane and encoder, twice (once from the zero state to learn the
+// lanes' exit states, once more from the true entry state), behind a 63-step serial hand-over of the entry states -- 55 us for a transport block,
+// whatever its size, next to a separate CRC24A launch.  Here a block has 256 lanes (24 steps each at K = 6144), every encoder runs ONCE from the zero
+// state keeping its parity bits in a register, the entry states come from a logarithmic scan of the lanes' affine maps (state' = A^len state + v;
+// A has period 7), and because the encoder is linear the true parity bits are the zero-state ones XOR the zero-input response of the entry
+// state (period 7).  The transport-block CRC is formed by the workgroup of the block that carries it.
+
+// A^e s for e = 0..6, s = 0..7 (zero-input steps of the constituent encoder), 3 bits per entry
+struct RscTables {
+  uint32_t pow[7];  // pow[e] >> (3 s) & 7 = A^e s
+  uint32_t resp[8]; // resp[s]: bit j = parity output of zero-input step j from state s, j = 0..6 (period 7), repeated up to bit 27
+};
+__device__ __forceinline__ RscTables rsc_tables()
+{
+  RscTables t;
+#pragma unroll
+  for (int e = 0; e < 7; e++) {
+    t.pow[e] = 0;
+  }
+#pragma unroll
+  for (uint32_t s0 = 0; s0 < 8; s0++) {
+    uint32_t s = s0, r = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      t.pow[j] |= s << (3 * s0);
+      uint32_t o;
+      s = rsc_step(s, 0u, &o);
+      r |= o << j;
+    }
+    t.resp[s0] = r | (r << 7) | (r << 14) | (r << 21);
+  }
+  return t;
+}
+__device__ __forceinline__ uint32_t rsc_resp(const RscTables& t, uint32_t s)
+{
+  uint32_t w = t.resp[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) {
+    w = s == (uint32_t)k ? t.resp[k] : w;
+  }
+  return w;
+}
+__device__ __forceinline__ uint32_t rsc_apply(const RscTables& t, uint32_t e, uint32_t s) // A^e s
+{
+  uint32_t w = t.pow[0];
+#pragma unroll
+  for (int k = 1; k < 7; k++) {
+    w = e == (uint32_t)k ? t.pow[k] : w;
+  }
+  return (w >> (3u * s)) & 7u;
+}
+
+// XOR over the 256 lanes of the workgroup (4 waves); red: 4 words of LDS
+__device__ __forceinline__ uint32_t wg_xor(uint32_t v, uint32_t* red)
+{
+  v = wave_xor(v);
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) {
+    red[threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  return red[0] ^ red[1] ^ red[2] ^ red[3];
+}
+
+__global__ __launch_bounds__(256) void tb_encode_lat_kernel(const TbParams p)
+{
+  extern __shared__ uint8_t sm[]; // the natural code word d (bit per byte), 3 K + 12
+  __shared__ uint32_t       red[4];
+  __shared__ uint32_t       wtot[2][4]; // per encoder: the four waves' (exponent << 3 | v) maps
+  const TbCbJob  job  = p.cbs[blockIdx.x];
+  const uint32_t K    = job.K;
+  const uint32_t lane = threadIdx.x;
+  // ---- payload bits of this block, a dword of payload per lane and pass
+  {
+    const uint32_t b0 = job.src_bit, nb = job.n_src_bits;
+    const uint32_t w0 = b0 >> 5; // first payload word that holds a bit of this block
+    const uint32_t nw = ((b0 + nb + 31u) >> 5) - w0;
+    const uint32_t* dw    = reinterpret_cast<const uint32_t*>(p.data);
+    const uint32_t  lastb = (b0 + nb - 1u) >> 3; // last payload byte of this block: nothing behind it is read
+    for (uint32_t w = lane; w < nw; w += 256) {
+      uint32_t v; // payload bytes are MSB first: bit k of the word (from the left) = bit 31 - k
+      if (4u * (w0 + w) + 3u <= lastb) {
+        v = __builtin_bswap32(dw[w0 + w]);
+      } else {
+        v = 0;
+        for (uint32_t b = 4u * (w0 + w), sh = 24; b <= lastb; b++, sh -= 8) {
+          v |= (uint32_t)p.data[b] << sh;
+        }
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 32; k++) {
+        const uint32_t gb = (w0 + w) * 32u + k;
+        if (gb >= b0 && gb < b0 + nb) {
+          sm[3u * (gb - b0)] = (uint8_t)((v >> (31u - k)) & 1u);
+        }
+      }
+    }
+  }
+  uint32_t n = job.n_src_bits;
+  if (job.tb_crc != 0xffffffffu) { // the transport-block CRC closes the last block (sch.c:268-273): this workgroup forms it over the whole payload
+    const TbCrcJob  tj = p.tbs[job.tb_crc];
+    const uint8_t*  d  = p.data + tj.src_byte;
+    const uint32_t  L  = (tj.n_bytes + 255u) / 256u;
+    const int64_t   e1 = (int64_t)tj.n_bytes - (int64_t)(255u - lane) * L; // end of this lane's stretch (exclusive)
+    const int64_t   e0 = e1 - (int64_t)L;
+    uint32_t        c  = 0;
+    for (int64_t i = e0 < 0 ? 0 : e0; i < e1; i++) {
+      const uint32_t b = d[i];
+#pragma unroll
+      for (int k = 7; k >= 0; k--) {
+        c = crc24_bit(c, (b >> k) & 1u, CRC24A_POLY);
+      }
+    }
+    c = wg_xor(mulmod24(c, p.crc_mult256[tj.crc_mult256_row * 256u + lane], CRC24A_POLY), red);
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (c >> (23u - lane)) & 1u;
+    }
+    n += 24;
+  }
+  __syncthreads();
+  if (job.crc24b) { // sch.c:276-284 / turbocoder.c:230-255
+    const uint32_t L  = (n + 255u) / 256u;
+    const int32_t  e1 = (int32_t)n - (int32_t)((255u - lane) * L), e0 = e1 - (int32_t)L;
+    uint32_t       v  = 0;
+    for (int32_t i = e0 < 0 ? 0 : e0; i < e1; i++) {
+      v = crc24_bit(v, sm[3u * (uint32_t)i], CRC24B_POLY);
+    }
+    v = wg_xor(mulmod24(v, p.crc_mult256[job.crc_mult256_row * 256u + lane], CRC24B_POLY), red);
+    if (lane < 24) {
+      sm[3u * (n + lane)] = (v >> (23u - lane)) & 1u;
+    }
+    __syncthreads();
+  }
+  // ---- both constituent encoders from the zero state: parity bits of this lane's stretch in a register (L <= 24 steps)
+  const RscTables T  = rsc_tables();
+  const uint32_t  L  = (K + 255u) / 256u;
+  const uint32_t  i0 = min(lane * L, K), i1 = min(i0 + L, K), len = i1 - i0;
+  uint32_t        par[2], fin[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    uint32_t s = 0, o, bits = 0;
+    Qpp      q;
+    q.start(i0, K, job.f1, job.f2);
+    for (uint32_t i = i0, j = 0; i < i1; i++, j++) {
+      const uint32_t b = sm[3u * (e == 0 ? i : q.pi)];
+      s                = rsc_step(s, b, &o);
+      bits |= o << j;
+      q.next();
+    }
+    // this lane's map: state' = A^(len mod 7) state + s.  Inclusive scan over the lanes of the wave (maps compose: later after earlier) ...
+    uint32_t me = len % 7u, mv = s;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+      const uint32_t pe = __shfl_up(me, off), pv = __shfl_up(mv, off);
+      if ((lane & 63u) >= off) {
+        mv = rsc_apply(T, me, pv) ^ mv; // (A^me (A^pe x + pv) + mv
+        me = (me + pe) % 7u;
+      }
+    }
+    // ... then over the four waves
+    if ((lane & 63u) == 63u) {
+      wtot[e][lane >> 6] = (me << 3) | mv;
+    }
+    __syncthreads();
+    uint32_t s_wave = 0; // state at the start of this lane's wave
+    for (uint32_t w = 0; w < (lane >> 6); w++) {
+      s_wave = rsc_apply(T, wtot[e][w] >> 3, s_wave) ^ (wtot[e][w] & 7u);
+    }
+    // entry state of the lane = the maps of all lanes before it applied to the zero state: the exclusive prefix
+    const uint32_t pe = __shfl_up(me, 1), pv = __shfl_up(mv, 1);
+    const uint32_t s_in = (lane & 63u) ? (rsc_apply(T, pe, s_wave) ^ pv) : s_wave;
+    // the encoder is linear: true parity = zero-state parity + zero-input response of the entry state
+    par[e] = bits ^ (rsc_resp(T, s_in) & ((1u << len) - 1u)); // (len <= 24)
+    // final state of the whole block (for the tail): what lane 255 leaves
+    uint32_t s_end = s_wave;
+    for (uint32_t w = (lane >> 6); w < 4; w++) {
+      s_end = rsc_apply(T, wtot[e][w] >> 3, s_end) ^ (wtot[e][w] & 7u);
+    }
+    fin[e] = s_end;
+    __syncthreads();
+  }
+  for (uint32_t j = 0; j < len; j++) {
+    sm[3u * (i0 + j) + 1] = (uint8_t)((par[0] >> j) & 1u);
+    sm[3u * (i0 + j) + 2] = (uint8_t)((par[1] >> j) & 1u);
+  }
+  if (lane < 2) { // turbocoder.c:150-185: three (systematic, parity) pairs per constituent encoder
+    uint32_t s = fin[lane];
+    for (int j = 0; j < 3; j++) {
+      const uint32_t bit = ((s >> 2) ^ (s >> 1)) & 1u;
+      uint32_t       o;
+      s                              = rsc_step(s, bit, &o);
+      sm[3u * K + lane * 6 + 2 * j]     = (uint8_t)bit;
+      sm[3u * K + lane * 6 + 2 * j + 1] = (uint8_t)o;
+    }
+  }
+  __syncthreads();
+  // ---- rate matching, as in the throughput kernel
+  const uint32_t first = job.out_bit, last = job.out_bit + job.E; // [first, last)
+  for (uint32_t byte = (first >> 3) + lane; byte <= ((last - 1) >> 3) && job.E; byte += 256) {
+    uint32_t v = 0, mask = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t ob = byte * 8u + k;
+      if (ob >= first && ob < last) {
+        uint32_t idx = ob - first;
+        idx -= idx >= job.table_len ? (idx / job.table_len) * job.table_len : 0u;
+        const uint32_t bit = sm[job.table[idx]];
+        v |= bit << (7u - k);
+        mask |= 1u << (7u - k);
+      }
+    }
+    if (mask == 0xffu) {
+      p.e_bits[byte] = (uint8_t)v;
+    } else {
+      atomicOr((unsigned int*)(p.e_bits + (byte & ~3u)), v << (8u * (byte & 3u)));
+    }
+  }
+}
+
 // ---- byte-packed per-block entry points (srsran_tcod_encode_lut / srsran_rm_turbo_tx_lut, turbocoder.c:188-343, rm_turbo.c:340-378)
 // One code block per launch: these exist for link-level compatibility; the batched transport-block kernel above is the
 // throughput path.
@@ -382,6 +603,15 @@ hipError_t launch_tb_crc24a(const TbParams& p, hipStream_t stream)
     return hipSuccess;
   }
   hipLaunchKernelGGL(tb_crc24a_kernel, dim3(p.n_tb), dim3(64), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tb_encode_lat(const TbParams& p, hipStream_t stream)
+{
+  if (p.n_cb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(tb_encode_lat_kernel, dim3(p.n_cb), dim3(256), 3 * 6144 + 16, stream, p);
   return hipGetLastError();
 }
 

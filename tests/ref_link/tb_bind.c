@@ -15,3 +15,20 @@ bool decode_tb_cb(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* 
 {
   return srsran_hip_decode_tb_cb(q, softbuffer, cb_segm, Qm, rv, nof_e_bits, e_bits, data);
 }
+
+/* Init-time work belongs to init: srsran_sch_init (sch.c:118-197) allocates, creates the turbo coder / decoder objects and calls
+ * srsran_rm_turbo_gentables().  With the reference's own rm_turbo.c still in the link (its non-LUT paths serve the sidelink channels) that call
+ * reaches the reference's table builder, not the library's init hook of the same name -- so the binding warms the device path here: the definition
+ * in the unmodified sch.o is renamed to srsran_sch_init_ref (objcopy --redefine-sym) and this one takes its name.  Afterwards the first transport
+ * block of the calling thread costs what a later one costs (profiles/r04_warm_probe.txt); an application with N PHY workers calls
+ * srsran_hip_warmup(N) once more after creating them. */
+extern int srsran_sch_init_ref(void* q);
+extern int srsran_hip_warmup(uint32_t nof_workers);
+int        srsran_sch_init(void* q)
+{
+  const int ret = srsran_sch_init_ref(q);
+  if (ret == 0) {
+    (void)srsran_hip_warmup(1);
+  }
+  return ret;
+}

@@ -74,6 +74,40 @@ def test_cellsearch_vs_oracle(hiplib, prb, N, frame, alg):
     S.lib().srsran_hip_cellsearch_free(h)
 
 
+def test_all_504_physical_cell_ids(hiplib):
+    """every physical cell id once (fft 128, one 5 ms capture per id, random delay, alternating subframe 0 / 5): the right hypothesis finds the peak where
+    the cell was put, N_id_1 = id / 3 from the 168-entry table and the whole 31 x 31 (m0, m1) space; peak position, m0, m1, N_id_1 and subframe equal to
+    the oracle's (restated pss.c:446-534, find_sss.c:99-192) for all 3 x 504 hypotheses"""
+    import srslte_amd as S
+
+    rng = np.random.default_rng(504)
+    prb, N, frame, alg = 6, 128, 9600, 1
+    ids = np.arange(504)
+    delays = rng.integers(0, frame - 15 * N, ids.size)
+    caps = np.stack([_capture(int(c), prb, N, frame, int(d), 0.05, rng, sf5=bool(i % 2)) for i, (c, d) in enumerate(zip(ids, delays))])
+    h, got = _run_batch(S, caps, frame, N, alg)
+    cp, cp0 = O.orc().orc_cp_len(N, 144), O.orc().orc_cp_len(N, 512)
+    seen_pairs = set()
+    for i, (cid, d) in enumerate(zip(ids, delays)):
+        for n2 in range(3):
+            g = got[i * 3 + n2]
+            pk, pv, psr = O.pss_find(caps[i], N, n2)[:3]
+            assert g.peak_pos == pk and abs(g.peak_value - pv) <= 1e-4 * pv, (cid, n2)
+            sss_idx = pk - 2 * (N + cp) + cp
+            if pk >= 2 * (N + cp0) and sss_idx + N <= frame:
+                m0, m1, v0, v1, nid, sf = O.sss_detect(caps[i][sss_idx:sss_idx + N], N, n2, alg)
+                assert g.sss_available == 1 and (g.m0, g.m1, g.N_id_1, g.sf_idx) == (m0, m1, nid, sf), (cid, n2)
+            else:
+                assert g.sss_available == 0
+        g = got[i * 3 + cid % 3]
+        assert g.peak_pos == d + 15 * N // 2 and g.psr > 3.0, cid
+        if g.sss_available:
+            assert g.N_id_1 == cid // 3 and g.sf_idx == (5 if i % 2 else 0), cid
+            seen_pairs.add((g.m0, g.m1))
+    assert len(seen_pairs) >= 300  # (subframe 0 carries (m0, m1), subframe 5 (m1, m0): both orders of most of the 168 pairs)
+    S.lib().srsran_hip_cellsearch_free(h)
+
+
 def test_full_capture_config5(hiplib):
     """BASELINE config 5: 10 ms at 30.72 Msps (307,200 samples, fft 2048); one capture checked against the oracle's
     direct correlation, the rest through invariants (known delay -> known peak; copies give identical results)"""

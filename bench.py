@@ -223,7 +223,7 @@ def make_turbo_pool(S, capi, torch, dev, stream, k_cb, pool_n, seed):
     sigma = torch.full((pool_n, 1), 10 ** (-3.0 / 20), device=dev)
     sigma[pool_n // 2:] = 10 ** (1.0 / 20)
     y = 2.0 * enc.float() - 1.0 + sigma * torch.randn((pool_n, 3 * k_cb + 12), generator=g, device=dev)
-    return torch.clamp(torch.round(100.0 * y), -32768, 32767).to(torch.int16)
+    return torch.clamp(torch.round(100.0 * y), -32768, 32767).to(torch.int16), msgs
 
 
 def plumbing_only(a, rank, world):
@@ -332,7 +332,7 @@ def worker(a):
 
     # ---- synthetic inputs, resident in HBM before the timed region
     pool_n = 64
-    d_pool = make_turbo_pool(S, capi, torch, dev, stream, k_cb, pool_n, 1000 + rank)
+    d_pool, d_msgs = make_turbo_pool(S, capi, torch, dev, stream, k_cb, pool_n, 1000 + rank)
     in_stride = 3 * k_cb + 12
     reps = (n_cb + pool_n - 1) // pool_n
     d_llr = d_pool.repeat(reps, 1)[:n_cb].contiguous()
@@ -409,6 +409,15 @@ def worker(a):
             cpu_bits, info = cpu_baseline(pool, a.cpu_sample)
             gpu_bits = d_bits[:pool_n].cpu().numpy()[:cpu_bits.shape[0]]
             info["parity_vs_gpu"] = "bit-exact" if np.array_equal(cpu_bits, gpu_bits) else "MISMATCH"
+            # block error rate of both decoders against the transmitted messages ("at matching BLER"): the 64 distinct code words of the step on the
+            # device, the sampled ones on the reference -- half of the pool sits in the waterfall (Es/N0 -1 dB), so the rate is not trivially zero
+            sent = np.packbits(d_msgs.cpu().numpy(), axis=1)
+            wrong_gpu = (d_bits[:pool_n].cpu().numpy() != sent).any(axis=1)
+            wrong_ref = (cpu_bits != sent[:cpu_bits.shape[0]]).any(axis=1)
+            res["bler"] = {"gpu": float(wrong_gpu.mean()), "gpu_blocks": int(pool_n), "reference": float(wrong_ref.mean()), "reference_blocks": int(cpu_bits.shape[0]),
+                           "gpu_on_reference_sample": float(wrong_gpu[:cpu_bits.shape[0]].mean()),
+                           "same_blocks_wrong": bool(np.array_equal(wrong_gpu[:cpu_bits.shape[0]], wrong_ref)),
+                           "note": "%d distinct code words, half at Es/N0 3 dB, half at -1 dB; %d half iterations, no early stop" % (pool_n, nit)}
             res["cpu_baseline"] = info
             res["speedup_vs_cpu_baseline"] = value / info["value"]
             if info["parity_vs_gpu"] != "bit-exact":

@@ -208,7 +208,7 @@ int knob_parse(int k, const char* v)
     case KNOB_TDEC_VARIANT:
       return !strcmp(v, "waves1") ? 1 : (!strcmp(v, "persistent") ? 2 : 0);
     case KNOB_PSS_VARIANT:
-      return !strcmp(v, "pair") ? 1 : (!strcmp(v, "block") ? 2 : 0);
+      return !strcmp(v, "pair") ? 1 : (!strcmp(v, "block") ? 2 : (!strcmp(v, "recompute") ? 3 : 0));
     case KNOB_TDEC_EXTRACT_ONLY:
       return 1;
     default:

@@ -75,6 +75,9 @@ static __device__ __forceinline__ void fft4096(cx (&v)[64], const cx (&T1)[8], c
 // One wave per overlap-save block and TWO waves per SIMD: a lone wave issues one vector instruction every four cycles, half of what
 // the SIMD takes, and stands still through every memory wait.  Two need <= 256 registers each, which leaves no room for the
 // block's spectrum next to the transform's working set -- it waits in global memory (see below).
+// RECOMP: the block's spectrum is not parked at all -- every hypothesis transforms the block again (it comes from L2, where this very wave has
+// just put it): 1.5x the transform work per block against 96 KB less HBM traffic (park once + read back twice: 62 % of what the kernel moves).
+template <bool RECOMP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void pss_wave_kernel(const PssParams p)
 {
   __shared__ float img[64 * 65];
@@ -135,13 +138,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       // place of the block itself -- the same 64 loads the forward transform would start with, and no second and third transform.
       // (Requesting it row by row while the previous hypothesis is post-processed, into the registers that become free, was built too:
       // the values carried around the loop cost 100 spilled registers and the kernel took 2.3 instead of 1.4 ms.)
-      if ((p.n_id_2_mask >> (h + 1)) != 0) {
+      if (!RECOMP && (p.n_id_2_mask >> (h + 1)) != 0) {
 #pragma unroll
         for (int r = 0; r < 64; r++) {
           spec[64 * r] = v[r];
         }
       }
-      have_spec = true;
+      have_spec = !RECOMP;
     } else {
 #pragma unroll
       for (int r = 0; r < 64; r++) {
@@ -549,7 +552,11 @@ hipError_t launch_pss_wave_blocks(const PssParams& p, hipStream_t stream)
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL(pss_wave_kernel, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
+  if (knob(KNOB_PSS_VARIANT) == 3) { // "recompute": no parked spectra (A/B against the product; tools/measure/pss_ab.py)
+    hipLaunchKernelGGL(pss_wave_kernel<true>, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(pss_wave_kernel<false>, dim3(p.n_blocks, p.n_cap), dim3(64), 0, stream, p);
+  }
   return hipGetLastError();
 }
 

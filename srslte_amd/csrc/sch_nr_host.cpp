@@ -703,6 +703,7 @@ extern "C" int srsran_hip_sch_nr_decode_tb(float scaling_fctr, uint32_t max_nof_
   const TailCopy tail[2] = {{s.pin + o_data, s.dev + o_data, (size_t)c.C * data_stride}, {s.pin + o_pay, s.dev + o_pay, c.A / 8}};
   if (sch_nr_decode(h, reinterpret_cast<const int8_t*>(s.pin + o_e), &tb, 1, reinterpret_cast<int8_t*>(s.dev + o_soft), sb_stride, flags, s.dev + o_data,
                     data_stride, s.dev + o_pay, &res, s.st, tail, 2) != SRSRAN_SUCCESS) {
+    (void)hipStreamSynchronize(s.st); // nothing of a failed call may still be in flight when the next one re-uses the images
     fprintf(stderr, "[srsran_phy_hip] sch_nr decode: %s\n", get_error());
     return SRSRAN_ERROR;
   }
@@ -889,6 +890,7 @@ extern "C" int srsran_hip_sch_nr_encode_tb(const srsran_hip_nr_tb_t* tb_in, cons
   tb.e_offset = tb.payload_offset = tb.first_cb = 0;
   // the kernels read the payload from, and the rate matcher writes the bits into, the pinned host image itself (read twice, written once)
   if (srsran_hip_sch_nr_encode(h, s.pin + o_pay, &tb, 1, s.pin + o_e, s.st) != SRSRAN_SUCCESS) {
+    (void)hipStreamSynchronize(s.st);
     fprintf(stderr, "[srsran_phy_hip] sch_nr encode: %s\n", get_error());
     return SRSRAN_ERROR;
   }

@@ -465,6 +465,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                                   "Es/N0 %.1f dB, at most %d half iterations with CRC early stop; %d distinct transport blocks (device transmit side + AWGN) tiled"
                                   % (ues, sf, otx.sf_sz // 15, tbs, ncb, snr, iters, pool_n)},
            "subframes_per_s": ctx.world * n_tb * steps / dt, "tb_crc_ok": [ok, n_tb], "payload_matches_on_ok_blocks": bool(good),
+           "bler_gpu": 1.0 - ok / float(n_tb),
            "avg_half_iterations": float(np.mean([r.avg_iterations for r in res])),
            "stage_ms": {"ofdm_rx": float(pm[0]), "gather+equaliser": float(pm[1]), "transform_deprecoding": float(pm[2]),
                         "demod_descramble": float(pm[3]), "dematch_turbo_crc": float(pm[4])},
@@ -514,6 +515,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
             llr_r = O.aligned_empty(G, np.int16)
             sym = O.aligned_empty(2 * n_re, np.float32)
             softr, same = chain.new_softbuffer(ncb), True
+            ref_fail, ref_seen, gpu_fail_same = 0, set(), 0
             t0 = time.perf_counter()
             while n_s < 4 or time.perf_counter() - t0 < 3.0:
                 i = n_s % min(n_tb, 64)
@@ -527,6 +529,10 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                 okr, data_r, avg_r = chain.decode_tb(tbs, Qm, 0, llr_r, softr, crc_r)
                 if i == 0:
                     same = (0 if okr else -1) == res[0].crc_ok and abs(avg_r - res[0].avg_iterations) < 1e-6 and np.array_equal(data_r[:tbs // 8], got[0][:tbs // 8])
+                if i not in ref_seen:  # block error rate on the distinct subframes the reference got through
+                    ref_seen.add(i)
+                    ref_fail += 0 if okr else 1
+                    gpu_fail_same += 0 if res[i].crc_ok == 0 else 1
                 n_s += 1
             tr = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": n_s * tbs / tr / 1e6, "unit": "Mbit/s", "cores": 1, "kind": "reference",
@@ -535,6 +541,7 @@ def leg_uplink(ctx, steps=3, warmup=1, want_cpu=True, ues=64, sf=184, snr=19.0, 
                                              "the scipy.fft port (the reference's dft_fftw.c needs FFTW, absent)" % (n_s, tr),
                                    "parity_vs_gpu": "identical verdict / iterations / bytes on the compared subframe" if same else "MISMATCH",
                                    "port_scalar_c": port}
+            out["bler_reference"] = {"value": ref_fail / float(len(ref_seen)), "blocks": len(ref_seen), "gpu_on_the_same_blocks": gpu_fail_same / float(len(ref_seen))}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     lib.srsran_hip_sch_free(sch)
     return out

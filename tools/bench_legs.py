@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0
 
 def load_traffic():
     """HBM traffic per launch from the PMC passes of the round (profiles/rNN_traffic.json, newest round first)"""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)

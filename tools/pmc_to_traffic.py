@@ -9,7 +9,7 @@ from collections import defaultdict
 UNITS = {  # kernel name fragment -> (key in the JSON, units per launch key, units per launch of bench.py's default shapes)
     "tdec_win_kernel<8, phyhip::turbo::Ar16, false>": ("tdec_win_kernel", "code_blocks_per_launch", 131040),
     "ofdm_kernel<phyhip::fft::Plan<2048": ("ofdm_kernel", "subframes_per_launch", 10080),
-    "ldpc_packed_kernel<false>": ("ldpc_packed_kernel", "code_words_per_launch", 16384),
+    "ldpc_packed_kernel<false, false>": ("ldpc_packed_kernel", "code_words_per_launch", 16384),
     "pss_wave_kernel": ("pss_wave_kernel", "captures_per_launch", 256),
     "ofdm_kernel<phyhip::fft::Plan<4096": ("ofdm_kernel_n4096", "slots_per_launch", 2048),
     "tdec_win_kernel<16, phyhip::turbo::Ar8, false>": ("tdec_win_kernel_8bit", "code_blocks_per_launch", 131040),

@@ -140,3 +140,35 @@ def test_ctest_line_through_the_grant_seam(entry, data_dir):
         tm = int(a[a.index("-t") + 1])
         assert pde_d > 0 and pde_r == 0, (a, share)  # every transport block is encoded on the device, whatever the transmission mode
         assert (pdd_d > 0 and pdd_r == 0) if tm == 1 else (pdd_r > 0), (a, share)  # one port, one antenna: decoded in one call too
+
+
+# ---- the LUT rate (de)matchers (tests/ref_link/Makefile target `rmlut`): rm_turbo.c stays in a reference build whole (its non-LUT functions serve the
+# sidelink / NB-IoT channels), and a definition in the program wins over the shared library's -- so the programs above run the REFERENCE's
+# srsran_rm_turbo_{rx,tx}_lut.  Here those entry points are renamed away in the unmodified rm_turbo.o: sch.c / pssch.c call the library's per code block, and
+# srsran_sch_init's srsran_rm_turbo_gentables() is the library's warm-start hook.  rm_turbo_test compares the library's LUT functions with the reference's own
+# bit-by-bit srsran_rm_turbo_tx / _rx.
+RMLUT_PROGRAMS = {"rm_turbo_test", "pdsch_test", "pusch_test", "pmch_test", "pssch_test"}
+
+
+def _selected_rmlut():
+    full = os.environ.get("REF_CTEST_FULL", "0") == "1"
+    seen = {}
+    for e in MANIFEST:
+        if e["program"] not in RMLUT_PROGRAMS:
+            continue
+        n = seen.get(e["program"], 0)
+        seen[e["program"]] = n + 1
+        if full or e["program"] in ("rm_turbo_test", "pusch_test", "pmch_test") or n % 8 == 0:
+            yield e
+
+
+@pytest.mark.parametrize("entry", list(_selected_rmlut()), ids=lambda e: "rmlut:%s:%s" % (e["program"], e["name"]))
+def test_ctest_line_on_the_librarys_lut_rate_matchers(entry, data_dir):
+    import subprocess
+
+    exe = os.path.join(HERE, "ref_link", "_build", "bin_rmlut", entry["program"])
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], stdout=subprocess.PIPE, text=True).stdout
+    assert "srsran_rm_turbo_gentables" in syms, "bin_rmlut/%s does not take its LUT rate matchers from the library" % entry["program"]
+    args = [str(data_dir / a[1:]) if a.startswith("@") else a for a in entry["args"]]
+    rc, out = run_program("bin_rmlut", entry["program"], args, data_dir, timeout=900)
+    assert rc == 0, "%s %s -> %d\n%s" % (entry["program"], " ".join(args), rc, out[-3000:])

@@ -7,6 +7,7 @@
 #include "sch_stage.h"
 #include "srsran_amd/phy_chan_abi.h"
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <vector>
@@ -146,7 +147,7 @@ float avg_power(const float* x, size_t n)
 
 struct PuschPlan { // one grant of a (multi-)call
   uint32_t                nof_symb = 0;
-  size_t                  o_sym = 0, o_ce = 0, o_x = 0, o_z = 0;
+  size_t                  o_sym = 0, o_ce = 0, o_x = 0, o_z = 0; // byte offsets in the pinned (symbols, estimates) and device (equalised, de-precoded) images
   srsran_cbsegm_t         seg;
   srsran_hip_sch_head_t   head;
   srsran_hip_dft_batch_t* plan = nullptr;
@@ -195,18 +196,34 @@ extern "C" int srsran_hip_pusch_decode_multi(uint32_t n, const srsran_hip_pusch_
       fprintf(stderr, "Error computing segmentation for TBS=%d\n", x.tb.tbs); // sch.c:1133-1136
       return SRSRAN_ERROR;
     }
-    const size_t nb = al256((size_t)x.tb.nof_re * sizeof(cf_t));
-    p.o_sym = pin_need;
-    p.o_ce  = pin_need + nb;
-    pin_need += 2 * nb;
-    p.o_x = dev_need;
-    p.o_z = dev_need + nb;
-    dev_need += 2 * nb;
     p.plan = s.plan(x.L_prb);
     if (!p.plan) {
       return SRSRAN_ERROR;
     }
   }
+  // Layout: the grants' REs packed one behind the other, ordered by allocation size -- four arrays of the same shape (symbols and estimates in the pinned
+  // image, equalised and de-precoded symbols on the device), so that ONE equaliser launch, one transform launch per allocation size and ONE demodulator
+  // launch serve all grants of the call (a launch costs 4-5 us whatever it carries: 25 grants x 3 kernels were 330 of the call's 390 us).
+  std::vector<uint32_t> ord(n);
+  for (uint32_t i = 0; i < n; i++) {
+    ord[i] = i;
+  }
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return g[a].L_prb < g[b].L_prb; });
+  size_t tot = 0, tiles = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    PuschPlan& p = pl[ord[k]];
+    p.o_sym = p.o_x = tot;
+    tot += (size_t)g[ord[k]].tb.nof_re * sizeof(cf_t);
+    tiles += modem::tiles_of(g[ord[k]].tb.mod, g[ord[k]].tb.nof_re);
+  }
+  const size_t region = al256(tot);
+  for (uint32_t i = 0; i < n; i++) {
+    pl[i].o_ce = region + pl[i].o_sym;
+    pl[i].o_z  = region + pl[i].o_x;
+  }
+  const size_t o_eqj = 2 * region, o_mj = al256(o_eqj + n * sizeof(modem::EqJob)), o_tj = al256(o_mj + n * sizeof(modem::Job));
+  pin_need = al256(o_tj + tiles * sizeof(uint32_t));
+  dev_need = 2 * region;
   if (!s.grow(pin_need, dev_need)) {
     fprintf(stderr, "[srsran_phy_hip] srsran_hip_pusch_decode: staging allocation failed\n");
     return SRSRAN_ERROR;
@@ -244,7 +261,71 @@ extern "C" int srsran_hip_pusch_decode_multi(uint32_t n, const srsran_hip_pusch_
     p.front = [=](hipStream_t st, void* d_e) { return enqueue_rx_front(st, tb, psym, pce, 1.0f, noise, L_prb, nsymb, dx, dz, plan, d_e); };
     items[i] = {&p.head, softbuffers[i], &p.seg, qm_rm(x.tb), x.tb.rv, x.tb.nof_re * qm_of(x.tb.mod), nullptr, &p.front, data[i], false};
   }
-  sch::decode_tbs_staged(items.data(), n);
+  // the front end of all grants at once (n > 1)
+  bool                     front_done = false;
+  size_t                   job_cur = 0, tile_cur = 0;
+  const sch::GroupFrontEnd group   = [&](hipStream_t st, const uint32_t* which, void* const* d_e, uint32_t m) -> bool {
+    if (!front_done) {
+      auto* ej = reinterpret_cast<modem::EqJob*>(s.pin + o_eqj);
+      for (uint32_t k = 0; k < n; k++) {
+        const srsran_hip_pusch_rx_t& x = g[ord[k]];
+        ej[k] = {(uint32_t)((pl[ord[k]].o_sym + (size_t)x.tb.nof_re * sizeof(cf_t)) / (2 * sizeof(cf_t))), x.noise_estimate, x.noise_estimate > 0.f ? 1u : 0u};
+      }
+      if (modem::launch_eq_jobs(s.pin, s.pin + region, s.dev, ej, n, (uint32_t)(tot / (2 * sizeof(cf_t))), 1.0f, st) != hipSuccess) {
+        set_error("grant front end: equaliser launch failed");
+        return false;
+      }
+      for (uint32_t k = 0; k < n;) { // one transform launch per run of grants of one allocation size
+        uint32_t e = k, symb = 0;
+        while (e < n && g[ord[e]].L_prb == g[ord[k]].L_prb) {
+          symb += pl[ord[e]].nof_symb;
+          e++;
+        }
+        const PuschPlan& p0 = pl[ord[k]];
+        if (srsran_hip_dft_batch_run(p0.plan, (const cf_t*)(s.dev + p0.o_x), (cf_t*)(s.dev + p0.o_z), symb, st) != SRSRAN_SUCCESS) {
+          return false;
+        }
+        k = e;
+      }
+      front_done = true;
+    }
+    const bool    llr8 = g[which[0]].tb.llr_is_8bit != 0;
+    const size_t  es   = llr8 ? 1 : 2;
+    modem::Params p;
+    if (!modem::params_for(p, llr8 ? modem::LLR_I8 : modem::LLR_I16)) {
+      return false;
+    }
+    uint8_t* base = static_cast<uint8_t*>(d_e[0]);
+    for (uint32_t k = 1; k < m; k++) {
+      base = static_cast<uint8_t*>(d_e[k]) < base ? static_cast<uint8_t*>(d_e[k]) : base;
+    }
+    auto*    mj  = reinterpret_cast<modem::Job*>(s.pin + o_mj) + job_cur;
+    auto*    tj  = reinterpret_cast<uint32_t*>(s.pin + o_tj) + tile_cur;
+    uint32_t nt  = 0;
+    for (uint32_t k = 0; k < m; k++) {
+      const srsran_hip_pusch_rx_t& x  = g[which[k]];
+      const uint32_t               t0 = nt, cnt = modem::tiles_of(x.tb.mod, x.tb.nof_re);
+      mj[k] = modem::Job{x.tb.mod, x.tb.nof_re, (uint32_t)(pl[which[k]].o_x / sizeof(cf_t)), (uint32_t)((size_t)(static_cast<uint8_t*>(d_e[k]) - base) / es), x.tb.seed, 1u, t0, cnt,
+                         12 * x.L_prb, pl[which[k]].nof_symb};
+      for (uint32_t t = 0; t < cnt; t++) {
+        tj[nt++] = k;
+      }
+    }
+    job_cur += m;
+    tile_cur += nt;
+    p.in       = s.dev + region;
+    p.out      = base;
+    p.jobs     = mj;
+    p.tile_job = tj;
+    p.n_jobs   = m;
+    p.n_tiles  = nt;
+    if (modem::launch(p, st) != hipSuccess) {
+      set_error("grant front end: demodulator launch failed");
+      return false;
+    }
+    return true;
+  };
+  sch::decode_tbs_staged(items.data(), n, n > 1 ? &group : nullptr);
   for (uint32_t i = 0; i < n; i++) {
     res[i].crc_ok               = items[i].ok ? 1 : 0;
     res[i].avg_iterations_block = pl[i].head.avg_iterations;

@@ -86,5 +86,14 @@ hipError_t launch(const Params& p, hipStream_t stream);
 // srsran_predecoding_single on device buffers (y, h, x: cf_t, 16-byte aligned; csi optional)
 hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t n, float scaling, float noise, hipStream_t stream);
 
+// the same for several grants at once: job j covers the symbol pairs [jobs[j - 1].end_pair, jobs[j].end_pair) of the three arrays with its own noise
+// estimate (add_noise as launch_eq derives it: noise > 0); `jobs` must be readable by the device (device memory or a pinned image)
+struct EqJob {
+  uint32_t end_pair;
+  float    noise;
+  uint32_t add_noise;
+};
+hipError_t launch_eq_jobs(const void* y, const void* h, void* x, const EqJob* jobs, uint32_t n_jobs, uint32_t n_pairs, float scaling, hipStream_t stream);
+
 } // namespace modem
 } // namespace phyhip

@@ -608,6 +608,41 @@ __global__ __launch_bounds__(256) void eq_kernel(const float4* y, const float4* 
   }
 }
 
+
+// the same over several grants in one launch: contiguous runs of symbol PAIRS, each with its own noise estimate (the grants of a TTI, chan_host.cpp).
+// jobs[j].end_pair = first pair behind grant j (ascending); every grant holds an even number of symbols.
+__global__ __launch_bounds__(256) void eq_jobs_kernel(const float4* y, const float4* h, float4* x, const EqJob* jobs, uint32_t n_jobs, uint32_t n_pairs, float inv_scaling)
+{
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_pairs) {
+    return;
+  }
+  uint32_t lo = 0, hi = n_jobs - 1; // smallest j with end_pair[j] > i
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (jobs[mid].end_pair > i) {
+      hi = mid;
+    } else {
+      lo = mid + 1;
+    }
+  }
+  const float  noise = jobs[lo].noise;
+  const bool   add_noise = jobs[lo].add_noise != 0;
+  const float4 yy = y[i], hh = h[i];
+  float        c0 = __fadd_rn(__fmul_rn(hh.x, hh.x), __fmul_rn(hh.y, hh.y));
+  float        c1 = __fadd_rn(__fmul_rn(hh.z, hh.z), __fmul_rn(hh.w, hh.w));
+  if (add_noise) {
+    c0 = __fadd_rn(c0, noise);
+    c1 = __fadd_rn(c1, noise);
+  }
+  float4 o;
+  o.x  = __fmul_rn(__fdiv_rn(__fadd_rn(__fmul_rn(yy.x, hh.x), __fmul_rn(yy.y, hh.y)), c0), inv_scaling);
+  o.y  = __fmul_rn(__fdiv_rn(__fsub_rn(__fmul_rn(yy.y, hh.x), __fmul_rn(yy.x, hh.y)), c0), inv_scaling);
+  o.z  = __fmul_rn(__fdiv_rn(__fadd_rn(__fmul_rn(yy.z, hh.z), __fmul_rn(yy.w, hh.w)), c1), inv_scaling);
+  o.w  = __fmul_rn(__fdiv_rn(__fsub_rn(__fmul_rn(yy.w, hh.z), __fmul_rn(yy.z, hh.w)), c1), inv_scaling);
+  x[i] = o;
+}
+
 } // namespace
 
 hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t n, float scaling, float noise, hipStream_t stream)
@@ -617,6 +652,16 @@ hipError_t launch_eq(const void* y, const void* h, void* x, float* csi, uint32_t
   }
   hipLaunchKernelGGL(eq_kernel, dim3(ceil_div(ceil_div(n, 2u), 256u)), dim3(256), 0, stream, (const float4*)y, (const float4*)h, (float4*)x,
                      (float2*)csi, n, 1.0f / scaling, noise, (csi != nullptr || noise > 0.f) ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_eq_jobs(const void* y, const void* h, void* x, const EqJob* jobs, uint32_t n_jobs, uint32_t n_pairs, float scaling, hipStream_t stream)
+{
+  if (n_jobs == 0 || n_pairs == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(eq_jobs_kernel, dim3(ceil_div(n_pairs, 256u)), dim3(256), 0, stream, (const float4*)y, (const float4*)h, (float4*)x, jobs, n_jobs, n_pairs,
+                     1.0f / scaling);
   return hipGetLastError();
 }
 

@@ -566,7 +566,7 @@ hipStream_t stage_stream()
 // ON THE DEVICE by the kernels `front(stream, d_e_bits)` enqueues in front of the de-matcher (chan_host.cpp: equaliser, transform de-precoding,
 // demodulator + descrambler never leave the device).  One call takes blocks of one soft-bit width, one iteration limit and one kind of e-bit source;
 // a mixed list is decoded piece by piece.
-static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n)
+static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n, const phyhip::sch::GroupFrontEnd* group, uint32_t base)
 {
   TraceRange trace_("decode_tb_cb (staged)");
   using phyhip::sch::TbItem;
@@ -722,7 +722,19 @@ static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n)
     (void)hipStreamSynchronize(s.st);
     return;
   }
-  if (dev_e) {
+  if (dev_e && group) {
+    std::vector<uint32_t> idx;
+    std::vector<void*>    de;
+    for (uint32_t t : who) {
+      idx.push_back(base + t);
+      de.push_back(s.dev + pl[t].o_e);
+    }
+    if (!(*group)(s.st, idx.data(), de.data(), (uint32_t)idx.size())) {
+      (void)hipStreamSynchronize(s.st);
+      fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());
+      return;
+    }
+  } else if (dev_e) {
     for (uint32_t t : who) {
       if (!(*it[t].front)(s.st, s.dev + pl[t].o_e)) {
         (void)hipStreamSynchronize(s.st); // nothing of a failed call may still be in flight when the next one re-uses the images
@@ -802,7 +814,7 @@ static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n)
   }
 }
 
-void phyhip::sch::decode_tbs_staged(TbItem* it, uint32_t n)
+void phyhip::sch::decode_tbs_staged(TbItem* it, uint32_t n, const GroupFrontEnd* group)
 {
   // validate, then cut the list into runs of blocks that can share a launch
   for (uint32_t t = 0; t < n; t++) {
@@ -831,7 +843,7 @@ void phyhip::sch::decode_tbs_staged(TbItem* it, uint32_t n)
       }
       b++;
     }
-    tbs_staged_homogeneous(it + a, b - a);
+    tbs_staged_homogeneous(it + a, b - a, group, a);
     a = b;
   }
 }

@@ -23,8 +23,13 @@ struct TbItem {
   bool                    ok; // out: what decode_tb_cb returns
 };
 
+// the same for several transport blocks of a call at once: `which` are indices into the item list given to decode_tbs_staged, d_e_bits[k] is where block
+// which[k]'s e bits are expected.  Called once per run of blocks that share a launch (normally once); the items' own `front` must be set (it marks the
+// e bits as device-made) but is not called when a group front end is given.
+using GroupFrontEnd = std::function<bool(hipStream_t stream, const uint32_t* which, void* const* d_e_bits, uint32_t n)>;
+
 hipStream_t stage_stream();
-void decode_tbs_staged(TbItem* items, uint32_t n);
+void decode_tbs_staged(TbItem* items, uint32_t n, const GroupFrontEnd* group = nullptr);
 bool decode_tb_staged(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, const void* e_bits,
                       const FrontEnd* front, uint8_t* data);
 

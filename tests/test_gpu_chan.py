@@ -234,8 +234,9 @@ def test_pusch_grants_of_a_tti_in_one_call(hiplib):
         nof_re = 12 * 12 * L_prb
         bits = rng.integers(0, 2, tbs).astype(np.uint8)
         grid, ce, seed = _pusch_signal(rng, nof_prb, cp_nsymb, n_prb, L_prb, 0, mod, tbs, 0, 0x100 + i, 4, 33, snr, bits)
+        # (a noise estimate of its own per grant, one of them none at all -- zero forcing: the one equaliser launch of the call takes them per grant)
         grants[i] = capi.HipPuschRx(capi.HipGrantTb(mod, tbs, 0, nof_re, seed, 8, 1 if llr8 else 0, 1), nof_prb, cp_nsymb, (C.c_uint32 * 2)(*n_prb), L_prb, 0,
-                                    0.01, 0)
+                                    (0.01, 0.0, 0.02, 0.005, 0.3, 0.015)[i], 0)
         grids.append(grid)
         ces.append(ce)
         Cn = O.cbsegm(tbs)["C"]

@@ -103,8 +103,13 @@ static int cmp_d(const void* a, const void* b)
   return (*(const double*)a > *(const double*)b) - (*(const double*)a < *(const double*)b);
 }
 
+/* TTI_PROBE_ONLY=<split index>,<mode: 1 single, 2 loop, 4 multi; sum> restricts the run (for a kernel timeline of one kind of call) */
 int main(void)
 {
+  int only_split = -1, modes = 7;
+  if (getenv("TTI_PROBE_ONLY")) {
+    sscanf(getenv("TTI_PROBE_ONLY"), "%d,%d", &only_split, &modes);
+  }
   srsran_hip_warmup(1);
   srsran_dft_precoding_t pre;
   if (srsran_dft_precoding_init_tx(&pre, NPRB)) {
@@ -122,6 +127,9 @@ int main(void)
                 {25, 4, 1, 1024, 1, "25 UEs x 4 PRB, QPSK, one code block of 1024"}};
   printf("%-52s %12s %12s %12s\n", "split of one 100-PRB subframe", "single us", "loop us", "multi us");
   for (unsigned s = 0; s < sizeof(splits) / sizeof(splits[0]); s++) {
+    if (only_split >= 0 && (int)s != only_split) {
+      continue;
+    }
     const uint32_t n   = splits[s].n;
     ue_t*          ue  = calloc(n, sizeof(ue_t));
     const uint32_t tbs = tbs_of(splits[s].K, splits[s].ncb);
@@ -143,30 +151,38 @@ int main(void)
     for (int r = 0; r < REP; r++) {
       reset(&ue[0]);
       double t0 = now_us();
-      ok &= srsran_hip_pusch_decode(&g[0], gr[0], ce[0], sb[0], out[0], &res[0]) == 0 && res[0].crc_ok;
-      t1[r] = now_us() - t0;
+      t1[r] = tl[r] = tm[r] = 0;
+      if (modes & 1) {
+        ok &= srsran_hip_pusch_decode(&g[0], gr[0], ce[0], sb[0], out[0], &res[0]) == 0 && res[0].crc_ok;
+        t1[r] = now_us() - t0;
+      }
       for (uint32_t i = 0; i < n; i++) {
         reset(&ue[i]);
       }
-      t0 = now_us();
-      for (uint32_t i = 0; i < n; i++) {
-        ok &= srsran_hip_pusch_decode(&g[i], gr[i], ce[i], sb[i], out[i], &res[i]) == 0 && res[i].crc_ok;
+      if (modes & 2) {
+        t0 = now_us();
+        for (uint32_t i = 0; i < n; i++) {
+          ok &= srsran_hip_pusch_decode(&g[i], gr[i], ce[i], sb[i], out[i], &res[i]) == 0 && res[i].crc_ok;
+        }
+        tl[r] = now_us() - t0;
+        for (uint32_t i = 0; i < n; i++) {
+          ok &= memcmp(ue[i].out, ue[i].payload, tbs / 8) == 0;
+          memset(ue[i].out, 0, tbs / 8);
+          reset(&ue[i]);
+        }
       }
-      tl[r] = now_us() - t0;
-      for (uint32_t i = 0; i < n; i++) {
-        ok &= memcmp(ue[i].out, ue[i].payload, tbs / 8) == 0;
-        memset(ue[i].out, 0, tbs / 8);
-        reset(&ue[i]);
-      }
-      t0 = now_us();
-      ok &= srsran_hip_pusch_decode_multi(n, g, gr, ce, sb, out, res) == 0;
-      tm[r] = now_us() - t0;
-      for (uint32_t i = 0; i < n; i++) {
-        ok &= res[i].crc_ok && memcmp(ue[i].out, ue[i].payload, tbs / 8) == 0;
+      if (modes & 4) {
+        t0 = now_us();
+        ok &= srsran_hip_pusch_decode_multi(n, g, gr, ce, sb, out, res) == 0;
+        tm[r] = now_us() - t0;
+        for (uint32_t i = 0; i < n; i++) {
+          ok &= res[i].crc_ok && memcmp(ue[i].out, ue[i].payload, tbs / 8) == 0;
+        }
       }
     }
     qsort(t1, REP, sizeof(double), cmp_d), qsort(tl, REP, sizeof(double), cmp_d), qsort(tm, REP, sizeof(double), cmp_d);
-    printf("%-52s %12.1f %12.1f %12.1f  %s (TBS %u per UE)\n", splits[s].what, t1[REP / 2], tl[REP / 2], tm[REP / 2], ok ? "ok" : "BAD", tbs);
+    printf("%-52s %12.1f %12.1f %12.1f  %s (TBS %u per UE, %.2f decoder iterations per block)\n", splits[s].what, t1[REP / 2], tl[REP / 2], tm[REP / 2],
+           ok ? "ok" : "BAD", tbs, res[0].avg_iterations_block);
   }
   return 0;
 }

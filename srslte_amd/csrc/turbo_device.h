@@ -64,7 +64,13 @@ struct GenParams {
   uint32_t        crc_poly;
   int*            noi;
   uint8_t*        crc_ok;
+  const uint32_t* crc_mult8; // latency kernel with crc_poly: x^(bits behind the eighth of lane l) mod g, 8 words (turbo_host.cpp: gen_crc_mult8)
 };
+// latency kernel of the scalar decoder (turbo_gen_lat_kernels.hip): 8 lanes per code block, the block's state in LDS; same GenParams, the workspace
+// (what a resumed run reads back) laid out per block: 15 (K + 4) int16 apart, seven arrays of K + 4
+hipError_t launch_gen_lat(const GenParams& p, hipStream_t stream);
+size_t     gen_lat_lds_bytes(uint32_t K);
+constexpr uint32_t kGenLatMaxBlocks = 2048; // one workgroup of 8 blocks per CU: beyond that the one-lane-per-block kernel has more blocks in flight
 
 // dwords of workspace per code block for the window decoder with nb sub-blocks
 static inline uint32_t win_ws_dwords(uint32_t K, int nb)

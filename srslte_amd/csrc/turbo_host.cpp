@@ -166,6 +166,7 @@ struct srsran_hip_tdec_batch {
   uint32_t  lat_cap       = 0;
   std::map<uint32_t, uint32_t*> crc_mult_lat; // per generator: one multiplier per 32-bit word of the kernel's hard-bit image
   bool      state_in_lat  = false; // the decoder state of the last launch lives in the latency kernel's workspace
+  bool      state_in_gen_lat = false; // scalar decoder: ... in the latency kernel's per-block layout of d_ws_gen
   // tables borrowed from the process-wide cache (never freed by the object); workspace taken from a caller's arena at every launch
   bool              tables_cached = false;
   turbo::WsArena*   arena         = nullptr;
@@ -188,7 +189,7 @@ ConstCache& ccache()
 {
   return device_local<ConstCache>(); // the constants of the calling thread's device; never destroyed
 }
-enum { CK_DEINT = 1, CK_INTER, CK_INTER16, CK_DEINTER16, CK_CRC_WIN, CK_CRC_LAT };
+enum { CK_DEINT = 1, CK_INTER, CK_INTER16, CK_DEINTER16, CK_CRC_WIN, CK_CRC_LAT, CK_CRC_GEN };
 inline uint64_t ckey(int kind, uint32_t K, int nb, uint32_t poly)
 {
   return ((uint64_t)kind << 56) | ((uint64_t)K << 40) | ((uint64_t)(uint32_t)nb << 32) | poly;
@@ -239,6 +240,31 @@ static bool want_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
   }
   const int k = knob(KNOB_TDEC_LAT);
   return k == 0 ? false : (k > 0 ? true : turbo::lat_waves(h->nb, n_cb) <= turbo::kLatMaxBlocks);
+}
+static uint32_t xpow_mod(uint64_t e, uint32_t poly);
+// the same for the scalar decoder (K <= 400 with AUTO): 8 lanes per block with the block in LDS, or one lane per block
+static bool want_gen_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
+{
+  if (h->nb || turbo::gen_lat_lds_bytes(h->K) > 156 * 1024) {
+    return false;
+  }
+  if (n_begin > 0) {
+    return h->state_in_gen_lat;
+  }
+  const int k = knob(KNOB_TDEC_LAT);
+  return k == 0 ? false : (k > 0 ? true : n_cb <= turbo::kGenLatMaxBlocks);
+}
+// lane l of a block's 8 takes the bits [l c, min((l + 1) c, K)), c = ceil(K / 8): x^(K - end) mod g shifts its remainder into place
+static uint32_t* gen_crc_mult8(uint32_t K, uint32_t poly)
+{
+  return static_cast<uint32_t*>(cached_const(ckey(CK_CRC_GEN, K, 0, poly), 8 * sizeof(uint32_t), [&](void* dst) {
+    uint32_t*      m = static_cast<uint32_t*>(dst);
+    const uint32_t c = (K + 7) / 8;
+    for (uint32_t l = 0; l < 8; l++) {
+      const uint32_t lo = l * c < K ? l * c : K, hi = lo + c < K ? lo + c : K;
+      m[l]              = xpow_mod((uint64_t)K - hi, poly);
+    }
+  }));
 }
 static int ensure_lat_ws(srsran_hip_tdec_batch* h, uint32_t n_cb)
 {
@@ -519,7 +545,13 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
     p.n_end      = n_end;
     p.n_cb       = (int)n_cb;
     p.in_is8     = in_is8 ? 1 : 0;
-    PHY_HIP_CHECK(turbo::launch_gen(p, stream), SRSRAN_ERROR);
+    if (want_gen_lat(h, n_cb, n_begin)) {
+      PHY_HIP_CHECK(turbo::launch_gen_lat(p, stream), SRSRAN_ERROR);
+      h->state_in_gen_lat = true;
+    } else {
+      PHY_HIP_CHECK(turbo::launch_gen(p, stream), SRSRAN_ERROR);
+      h->state_in_gen_lat = false;
+    }
   }
   return SRSRAN_SUCCESS;
 }
@@ -630,6 +662,16 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     g.crc_poly  = crc_poly;
     g.noi       = d_noi;
     g.crc_ok    = d_crc_ok;
+    if (want_gen_lat(h, n_cb, 0)) {
+      g.crc_mult8 = gen_crc_mult8(h->K, crc_poly);
+      if (!g.crc_mult8) {
+        return SRSRAN_ERROR;
+      }
+      PHY_HIP_CHECK(turbo::launch_gen_lat(g, stream), SRSRAN_ERROR);
+      h->state_in_gen_lat = true;
+      return SRSRAN_SUCCESS;
+    }
+    h->state_in_gen_lat = false;
     PHY_HIP_CHECK(turbo::launch_gen(g, stream), SRSRAN_ERROR);
     return SRSRAN_SUCCESS;
   }
@@ -768,6 +810,11 @@ bool phyhip::turbo::prebuild_tables()
         WsArena                  none; // (no workspace is needed to collect tables)
         if (tdec_batch_create(&b, K, 1, SRSRAN_TDEC_AUTO, api8 != 0, &none) != SRSRAN_SUCCESS) {
           continue;
+        }
+        if (!b->nb) {
+          for (uint32_t poly : polys) {
+            (void)gen_crc_mult8(K, poly);
+          }
         }
         if (b->nb) {
           const uint32_t nbq = (uint32_t)b->nb;

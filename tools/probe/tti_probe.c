@@ -124,7 +124,9 @@ int main(void)
                 {4, 25, 3, 6144, 3, "4 UEs x 25 PRB, 64-QAM, 3 code blocks each"},
                 {8, 12, 2, 5504, 1, "8 UEs x 12 PRB, 16-QAM, one code block of 5504"},
                 {16, 6, 2, 2816, 1, "16 UEs x 6 PRB, 16-QAM, one code block of 2816"},
-                {25, 4, 1, 1024, 1, "25 UEs x 4 PRB, QPSK, one code block of 1024"}};
+                {25, 4, 1, 1024, 1, "25 UEs x 4 PRB, QPSK, one code block of 1024"},
+                {25, 4, 1, 352, 1, "25 UEs x 4 PRB, QPSK, one block of 352 (scalar decoder)"},
+                {50, 2, 1, 176, 1, "50 UEs x 2 PRB, QPSK, one block of 176 (scalar decoder)"}};
   printf("%-52s %12s %12s %12s\n", "split of one 100-PRB subframe", "single us", "loop us", "multi us");
   for (unsigned s = 0; s < sizeof(splits) / sizeof(splits[0]); s++) {
     if (only_split >= 0 && (int)s != only_split) {

@@ -70,7 +70,7 @@ struct GenParams {
 // (what a resumed run reads back) laid out per block: 15 (K + 4) int16 apart, seven arrays of K + 4
 hipError_t launch_gen_lat(const GenParams& p, hipStream_t stream);
 size_t     gen_lat_lds_bytes(uint32_t K);
-constexpr uint32_t kGenLatMaxBlocks = 2048; // one workgroup of 8 blocks per CU: beyond that the one-lane-per-block kernel has more blocks in flight
+constexpr uint32_t kGenLatMaxBlocks = 8192; // (K = 400: 8192 blocks 0.33 against 0.51 ms per half iteration, 32768 blocks 1.36 against 0.69: tools/measure/gen_time.py)
 
 // dwords of workspace per code block for the window decoder with nb sub-blocks
 static inline uint32_t win_ws_dwords(uint32_t K, int nb)

@@ -245,7 +245,7 @@ static uint32_t xpow_mod(uint64_t e, uint32_t poly);
 // the same for the scalar decoder (K <= 400 with AUTO): 8 lanes per block with the block in LDS, or one lane per block
 static bool want_gen_lat(srsran_hip_tdec_batch* h, uint32_t n_cb, uint32_t n_begin)
 {
-  if (h->nb || turbo::gen_lat_lds_bytes(h->K) > 156 * 1024) {
+  if (h->nb || (h->K & 7u) || turbo::gen_lat_lds_bytes(h->K) > 156 * 1024) {
     return false;
   }
   if (n_begin > 0) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scalar decoder (K <= 400): one-lane-per-block kernel against the 8-lanes-per-block latency kernel, ms per launch over batch sizes and half-iteration
+"""scalar decoder (K <= 400): one-lane-per-block kernel against the latency kernel (turbo_gen_lat_kernels.hip), ms per launch over batch sizes and half-iteration
 counts (fixed iterations, device-resident input), outputs compared.  usage: gen_time.py [K ...]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,7 @@ for K in ([int(a) for a in sys.argv[1:]] or [40, 176, 400]):
                     best = min(best, e0.elapsed_time(e1))
                 row.append(best)
             outs.append(d_bits.cpu().numpy())
-        print("K=%d n_cb=%5d  one lane per block: %s   8 lanes per block: %s  (ms at 1/2/4/8 half iterations)  same bytes: %s" %
+        print("K=%d n_cb=%5d  one lane per block: %s   latency kernel: %s  (ms at 1/2/4/8 half iterations)  same bytes: %s" %
               (K, n_cb, " ".join("%.3f" % v for v in row[:4]), " ".join("%.3f" % v for v in row[4:]), bool(np.array_equal(outs[0], outs[1]))), flush=True)
         del dec
 lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", None)

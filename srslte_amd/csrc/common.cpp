@@ -195,7 +195,7 @@ void trace_pop()
 // ---- development knobs (hip_common.h)
 namespace {
 const char* const kKnobEnv[KNOB_COUNT] = {"SRSRAN_HIP_TDEC_VARIANT", "SRSRAN_HIP_PSS_VARIANT", "TDEC_DBG_EXTRACT_ONLY", "LDPC_PCPB", "LDPC_SLOTS", "LDPC_PACKED", "SRSRAN_HIP_TDEC_LAT",
-                                          "SRSRAN_HIP_LDPC_C2V_LDS", "SRSRAN_HIP_TCOD_LAT", "SRSRAN_HIP_LOGICAL_DEVICES"};
+                                          "SRSRAN_HIP_LDPC_C2V_LDS", "SRSRAN_HIP_TCOD_LAT", "SRSRAN_HIP_LOGICAL_DEVICES", "SRSRAN_HIP_TDEC_LAT2"};
 std::atomic<int>  g_knob[KNOB_COUNT];
 std::atomic<bool> g_knob_read[KNOB_COUNT];
 

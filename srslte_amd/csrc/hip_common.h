@@ -110,6 +110,7 @@ enum Knob {
   KNOB_LDPC_C2V_LDS,      // SRSRAN_HIP_LDPC_C2V_LDS: 0 = small LDPC batches keep their messages in the global slabs
   KNOB_TCOD_LAT,          // SRSRAN_HIP_TCOD_LAT: 0 = never use the one-launch transmit kernel for small batches
   KNOB_LOGICAL_DEVICES,   // SRSRAN_HIP_LOGICAL_DEVICES: n logical devices on the installed ones (development: the per-device bookkeeping on a 1-GPU box)
+  KNOB_TDEC_LAT2,         // SRSRAN_HIP_TDEC_LAT2: 0 = never use the two-wave form of the latency kernel, 1 = wherever it exists; unset: by batch size
   KNOB_COUNT
 };
 int knob(Knob k);

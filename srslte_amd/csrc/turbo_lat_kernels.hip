@@ -39,9 +39,12 @@ __host__ __device__ inline uint32_t ws_dwords(uint32_t K, int nb)
   return 6 * nblk * lpc * 8 + (nblk + 1) * lpc * 8 + 8;
 }
 
-template <int LPC, class AR, bool ES>
-__global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const WinParams p)
+// DUAL (16 sub-blocks, 16-bit): TWO waves per code block with the same lane mapping -- wave 0 runs the forward recursion, wave 1 the backward one, at
+// the same time; each files the metrics of the first half of its way in LDS and forms the outputs of the second half against what the other one filed.
+template <int LPC, class AR, bool ES, bool DUAL = false>
+__global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_lat_kernel(const WinParams p)
 {
+  static_assert(!DUAL || (LPC == 8 && !AR::kIs8), "the two-wave form exists for the 16-sub-block 16-bit decoder");
   constexpr int NB  = 2 * LPC;
   constexpr int G   = 8 * LPC;            // lanes per code block: 32 (two blocks per wave), 64 (one wave) or 128 (two waves, 32 sub-blocks)
   constexpr int BPW = G >= 64 ? 1 : 64 / G; // code blocks per workgroup
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
   __shared__ uint32_t xch[2][G > 64 ? G : 1];                  // lane exchange across the two waves of a 128-lane block
   __shared__ uint32_t xcrc[2];
 
-  const int      lane = threadIdx.x;
+  const int      lane = DUAL ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; // (DUAL: both waves number their lanes alike)
+  const int      wave = (int)(threadIdx.x >> 6);
   const int      grp  = lane / G, li = lane % G, pl = li >> 3, slot = li & 7;
   const int      gbase = grp * G;
   const int      cb_raw = (int)blockIdx.x * BPW + grp;
@@ -302,27 +306,47 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
     // (set = block index mod 3), so a set is filled two blocks before it is used and never copied: a copy of registers that a load is
     // still filling would wait for the load (the first version of this kernel did that and spent 40 % of its time in s_waitcnt vmcnt(0)).
     // The labelling residue of a block's first step is (8 b) mod 3 = (2 b) mod 3: a compile-time constant per set as well.
+    // (held as the packed type they are used as: sets written as 32-bit integers and read back as int16 pairs stay in SCRATCH memory -- the compiler folds
+    // the bit cast into the load, and a stack slot that is stored as one type and loaded as another is not promoted to registers: every operand went
+    // global load -> wait -> scratch store -> scratch load, 30 scratch operations per 8-step block, which is what "two blocks ahead" never overlapped)
     struct Ops {
-      uint32_t x[8], y[8], a[8];
+      s2 x[8], y[8], a[8];
     };
-    Ops  buf[3];
+    auto load8s = [&](const uint32_t* q, s2(&r)[8]) {
+      const uint4 a = *reinterpret_cast<const uint4*>(q), c = *reinterpret_cast<const uint4*>(q + 4);
+      r[0] = from_u(a.x), r[1] = from_u(a.y), r[2] = from_u(a.z), r[3] = from_u(a.w), r[4] = from_u(c.x), r[5] = from_u(c.y), r[6] = from_u(c.z), r[7] = from_u(c.w);
+    };
+    Ops  buf0, buf1, buf2; // (three variables, not an array: every use names its set at compile time)
+    auto bufsel = [&](auto I) -> Ops& {
+      if constexpr (decltype(I)::value == 0) {
+        return buf0;
+      } else if constexpr (decltype(I)::value == 1) {
+        return buf1;
+      } else {
+        return buf2;
+      }
+    };
+#define LAT_BUF(i) bufsel(std::integral_constant<int, (i)>{})
+// last statement of a switch arm that fills operand sets: arms that differ only in WHICH set they fill would otherwise be merged into one piece of code
+// with the set's address chosen by a phi -- and a set whose address is a run-time value lives in scratch memory, every element of it
+#define LAT_ARM(tag) asm volatile("; operand sets, arm " tag)
     auto issue = [&](uint32_t b, Ops& q) {
       const uint32_t at = (b * LPC + pl) * 8;
-      load8(X + at, q.x);
-      load8(Y + at, q.y);
+      load8s(X + at, q.x);
+      load8s(Y + at, q.y);
       if (has_app) {
-        load8(A1 + at, q.a);
+        load8s(A1 + at, q.a);
       }
     };
     // systematic (+ a-priori) and parity operands of the 8 steps of a block; ap: the a-priori values alone (extrinsic subtraction)
     auto prep = [&](const Ops& q, s2(&xs)[8], s2(&ys)[8], s2(&ap)[8]) {
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        xs[j] = from_u(q.x[j]);
-        ys[j] = from_u(q.y[j]);
+        xs[j] = q.x[j];
+        ys[j] = q.y[j];
         ap[j] = splat(0);
         if (has_app) {
-          ap[j] = from_u(q.a[j]);
+          ap[j] = q.a[j];
           xs[j] = AR::add(ap[j], xs[j]);
         }
       }
@@ -343,59 +367,435 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
     };
 #define LAT_RES(R0, j) std::integral_constant<int, ((R0) + (j)) % 3> {}
 
-    // ================= backward recursion (turbodecoder_win.h:551-681)
-    o = splat(-AR::kInf);
-    // pass 0: 40 steps on the head of every sub-block, all states unknown.  Blocks 4 ... 0: sets 1 0 2 1 0
-    {
-      constexpr int WB = TD_WIN_OVERLAP / 8; // 5
-      issue(WB - 1, buf[(WB - 1) % 3]);
-      issue(WB - 2, buf[(WB - 2) % 3]);
-      auto blk = [&](auto BC) {
-        constexpr int b = decltype(BC)::value, set = b % 3, R0 = (2 * b) % 3;
-        if constexpr (b >= 2) {
-          issue(b - 2, buf[(b - 2) % 3]);
-        }
-        s2 xs[8], ys[8], ap[8];
-        prep(buf[set], xs, ys, ap);
+    // ---- outputs of the 8 steps of block b from the branch sums of the forward recursion (t_o, t_c) and the backward metrics (bt): max-log-MAP
+    // output, extrinsic subtraction, exchange of the 8 rows into the other decoder's a-priori array, decision source
+    const uint32_t* lut  = dec1 ? p.deint : p.inter; // per (block, destination pair, step): row | source sub-blocks (turbo_host.cpp)
+    uint32_t*       dst  = dec1 ? A2 : A1;
+    const bool      last = (n + 1 == p.n_end) || crc_poly;
+    auto emit = [&](auto R0C, auto FULLC, uint32_t b, int len, const s2(&bt)[8], const s2(&t_o)[8], const s2(&t_c)[8], const s2(&xs)[8], const s2(&ap)[8],
+                    const uint32_t(&wrapj)[8], uint32_t trl_in) {
+      constexpr int  R0   = decltype(R0C)::value;
+      constexpr bool FULL = decltype(FULLC)::value;
+      // max-log-MAP outputs of the 8 steps, STAGE BY STAGE across the steps: the eight reductions are independent, so every cross-lane move
+      // reads a register written eight instructions earlier and needs no wait states (step by step, a fifth of the block was s_nop).
+      // Even slots collect the data-bit-0 maximum, odd slots the data-bit-1 one: a lane keeps the candidate of its class, sends the other to
+      // slot ^ 1, then ONE value per lane is reduced over slot ^ 2 and slot ^ 4.
+      s2 w[8], u[8];
 #pragma unroll
-        for (int j = 7; j >= 0; j--) {
-          if ((R0 + j) % 3 == 0) {
-            bstep(LAT_RES(0, 0), xs[j], ys[j]);
-          } else if ((R0 + j) % 3 == 1) {
-            bstep(LAT_RES(1, 0), xs[j], ys[j]);
-          } else {
-            bstep(LAT_RES(2, 0), xs[j], ys[j]);
-          }
-          if (AR::norm_at((uint32_t)b * 8 + j)) {
-            o = normalise<AR>(o);
-          }
-        }
-      };
-      static_assert(WB == 5, "warm-up of 40 steps");
-      blk(std::integral_constant<int, 4>{});
-      blk(std::integral_constant<int, 3>{});
-      blk(std::integral_constant<int, 2>{});
-      blk(std::integral_constant<int, 1>{});
-      blk(std::integral_constant<int, 0>{});
-    }
-    // hand every estimate (beta at step 0, labelling of residue 0) to the previous sub-block as its beta at step W (labelling of rW);
-    // the last sub-block starts from the tail trellis
-    {
-      short tr[8];
-      tail_trellis<AR>(xt, yt, tr);
-      const int st = state_of(rW, slot); // state this slot must hold; at residue 0 slot == state
-      short     tv = tr[0];
-#pragma unroll
-      for (int i = 1; i < 8; i++) {
-        tv = st == i ? tr[i] : tv;
+      for (int j = 0; j < 8; j++) {
+        const bool q = lk.q[(R0 + j) % 3];
+        w[j]         = AR::add_raw(bt[j], q ? t_o[j] : t_c[j]);
+        u[j]         = AR::add_raw(bt[j], q ? t_c[j] : t_o[j]);
       }
-      uint32_t own, next;
-      read2(to_u(o), gbase + pl * 8 + st, gbase + ((pl + 1) % LPC) * 8 + st, own, next);
-      const uint32_t lo   = own >> 16;
-      const uint32_t hi   = (pl == LPC - 1) ? (uint32_t)(uint16_t)tv : (next & 0xffffu);
-      o                   = from_u(lo | (hi << 16));
-      CK[nblk * G + li]   = to_u(o);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        u[j] = from_u(partner<0>(to_u(u[j])));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        w[j] = vmax(w[j], u[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        u[j] = from_u(partner<1>(to_u(w[j])));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        w[j] = vmax(w[j], u[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        u[j] = from_u(partner<2>(to_u(w[j])));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        w[j] = vmax(w[j], u[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        u[j] = from_u(partner<0>(to_u(w[j]))); // the other class' maximum
+      }
+      s2 kept = splat(0), keptraw = splat(0);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (FULL || j < len) {
+          const s2       m1  = lk.odd ? w[j] : u[j];
+          const s2       m0  = lk.odd ? u[j] : w[j];
+          const s2       llr = AR::llr(AR::clean(m1), AR::clean(m0));
+          const uint32_t k   = b * 8 + j;
+          // decoder 1: ext1 - app1 (the a-priori it just used; zero in the first half iteration); decoder 2: ext2 - its systematic input
+          s2 proc;
+          if constexpr (dec1) {
+            proc = AR::ex_sub(llr, ap[j], k == wrap_row);
+          } else {
+            proc = AR::ex_sub(llr, xs[j], AR::kIs8 && (wrapj[j] & 0xffffu) == wrap_row);
+          }
+          kept    = slot == j ? proc : kept; // lane (pair, j) keeps the output of step j
+          keptraw = slot == j ? llr : keptraw;
+        }
+      }
+      // exchange of the block's 8 rows: lane (pair p', step j) assembles the two values of its destination sub-blocks
+      const uint32_t trl = trl_in;
+      const uint32_t row = trl & 0xffffu, jlo = (trl >> 16) & 31u, jhi = (trl >> 21) & 31u;
+      const int      a_l = gbase + (int)(jlo >> 1) * 8 + slot, c_l = gbase + (int)(jhi >> 1) * 8 + slot;
+      auto           pick = [&](uint32_t v) {
+        uint32_t a, c;
+        read2(v, a_l, c_l, a, c);
+        const uint32_t lo = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
+        const uint32_t hi = (jhi & 1u) ? (c >> 16) : (c & 0xffffu);
+        return lo | (hi << 16);
+      };
+      const uint32_t v   = pick(to_u(kept));
+      const uint32_t dat = ((row >> 3) * LPC + pl) * 8 + (row & 7u);
+      if (slot < len) {
+        dst[dat] = v;
+      }
+      if (last) {
+        // what tdec_decision_byte reads (turbodecoder.c:370-378), natural order: ext1 after decoder 1, the de-interleaved ext2 after decoder 2
+        // (every lane takes part in the exchange: across two waves it has a barrier inside)
+        uint32_t r, at;
+        if constexpr (dec1) {
+          r  = to_u(keptraw);
+          at = (b * LPC + pl) * 8 + slot;
+        } else {
+          r  = pick(to_u(keptraw));
+          at = dat;
+        }
+        if (slot < len) {
+          D[at] = r;
+        }
+      }
+    };
+
+    // backward recursion, start: 40 steps on the head of every sub-block, then every estimate handed to the sub-block in front (turbodecoder_win.h:551-625)
+    auto beta_start = [&]() {
+      o = splat(-AR::kInf);
+      // pass 0: 40 steps on the head of every sub-block, all states unknown.  Blocks 4 ... 0: sets 1 0 2 1 0
+      {
+        constexpr int WB = TD_WIN_OVERLAP / 8; // 5
+        issue(WB - 1, LAT_BUF((WB - 1) % 3));
+        issue(WB - 2, LAT_BUF((WB - 2) % 3));
+        auto blk = [&](auto BC) {
+          constexpr int b = decltype(BC)::value, set = b % 3, R0 = (2 * b) % 3;
+          if constexpr (b >= 2) {
+            issue(b - 2, LAT_BUF((b - 2) % 3));
+          }
+          s2 xs[8], ys[8], ap[8];
+          prep(LAT_BUF(set), xs, ys, ap);
+  #pragma unroll
+          for (int j = 7; j >= 0; j--) {
+            if ((R0 + j) % 3 == 0) {
+              bstep(LAT_RES(0, 0), xs[j], ys[j]);
+            } else if ((R0 + j) % 3 == 1) {
+              bstep(LAT_RES(1, 0), xs[j], ys[j]);
+            } else {
+              bstep(LAT_RES(2, 0), xs[j], ys[j]);
+            }
+            if (AR::norm_at((uint32_t)b * 8 + j)) {
+              o = normalise<AR>(o);
+            }
+          }
+        };
+        static_assert(WB == 5, "warm-up of 40 steps");
+        blk(std::integral_constant<int, 4>{});
+        blk(std::integral_constant<int, 3>{});
+        blk(std::integral_constant<int, 2>{});
+        blk(std::integral_constant<int, 1>{});
+        blk(std::integral_constant<int, 0>{});
+      }
+      // hand every estimate (beta at step 0, labelling of residue 0) to the previous sub-block as its beta at step W (labelling of rW);
+      // the last sub-block starts from the tail trellis
+      {
+        short tr[8];
+        tail_trellis<AR>(xt, yt, tr);
+        const int st = state_of(rW, slot); // state this slot must hold; at residue 0 slot == state
+        short     tv = tr[0];
+  #pragma unroll
+        for (int i = 1; i < 8; i++) {
+          tv = st == i ? tr[i] : tv;
+        }
+        uint32_t own, next;
+        read2(to_u(o), gbase + pl * 8 + st, gbase + ((pl + 1) % LPC) * 8 + st, own, next);
+        const uint32_t lo   = own >> 16;
+        const uint32_t hi   = (pl == LPC - 1) ? (uint32_t)(uint16_t)tv : (next & 0xffffu);
+        o                   = from_u(lo | (hi << 16));
+        CK[nblk * G + li]   = to_u(o);
+      }
+    };
+    // forward recursion, start: the last 40 steps of every sub-block, then every estimate handed to the sub-block behind (turbodecoder_win.h:684-750)
+    auto alpha_start = [&]() {
+      o = splat(-AR::kInf);
+      {
+        // warm-up: the last 40 steps of every sub-block, blocks w0 / 8 ... (W - 1) / 8, block b in set b mod 3
+        const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
+        const uint32_t bl = (long_sb - 1) >> 3, b0 = w0 >> 3;
+        auto           blk = [&](auto SET, uint32_t b) {
+          constexpr int set = decltype(SET)::value, R0 = (2 * set) % 3;
+          if (b + 2 <= bl) {
+            issue(b + 2, LAT_BUF((set + 2) % 3));
+          }
+          s2 xs[8], ys[8], ap[8];
+          prep(LAT_BUF(set), xs, ys, ap);
+  #pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t k = b * 8 + j;
+            if (k >= w0 && k < long_sb) {
+              if ((R0 + j) % 3 == 0) {
+                astep(LAT_RES(0, 0), xs[j], ys[j]);
+              } else if ((R0 + j) % 3 == 1) {
+                astep(LAT_RES(1, 0), xs[j], ys[j]);
+              } else {
+                astep(LAT_RES(2, 0), xs[j], ys[j]);
+              }
+              if (AR::norm_at(k - w0)) {
+                o = normalise<AR>(o);
+              }
+            }
+          }
+        };
+        switch (b0 % 3) {
+          case 0: issue(b0, LAT_BUF(0)); issue(b0 + 1, LAT_BUF(1)); LAT_ARM("case0"); break;
+          case 1: issue(b0, LAT_BUF(1)); issue(b0 + 1, LAT_BUF(2)); LAT_ARM("case1"); break;
+          default: issue(b0, LAT_BUF(2)); issue(b0 + 1, LAT_BUF(0)); LAT_ARM("default"); break;
+        }
+        uint32_t b = b0;
+        if (b % 3 == 1) {
+          blk(std::integral_constant<int, 1>{}, b++);
+        }
+        if (b % 3 == 2 && b <= bl) {
+          blk(std::integral_constant<int, 2>{}, b++);
+        }
+        for (; b + 2 <= bl; b += 3) {
+          blk(std::integral_constant<int, 0>{}, b);
+          blk(std::integral_constant<int, 1>{}, b + 1);
+          blk(std::integral_constant<int, 2>{}, b + 2);
+        }
+        if (b <= bl) {
+          blk(std::integral_constant<int, 0>{}, b++);
+        }
+        if (b <= bl) {
+          blk(std::integral_constant<int, 1>{}, b++);
+        }
+      }
+      // hand every estimate (alpha at step W, labelling of rW) to the next sub-block as its alpha at step 0 (slot == state); the first
+      // sub-block starts in state 0
+      {
+        const int      src  = slot_of(rW, slot); // slot that holds state `slot` in the labelling of rW
+        uint32_t own, prev;
+        read2(to_u(o), gbase + pl * 8 + src, gbase + ((pl + LPC - 1) % LPC) * 8 + src, own, prev);
+        const uint32_t lo   = (pl == 0) ? (uint32_t)(uint16_t)(short)(slot ? -AR::kInf : 0) : (prev >> 16);
+        const uint32_t hi   = own & 0xffffu;
+        o                   = from_u(lo | (hi << 16));
+      }
+    };
+
+    if constexpr (DUAL) {
+      // ================= both recursions at once, one per wave.  Blocks [0, hb) are the forward wave's first half and the backward wave's second,
+      // blocks [hb, nblk) the other way round.  In its first half a wave files, per step, the metric the OTHER one's output needs: the forward
+      // state in front of step k (what the branch sums start from), the backward metric of index k + 1 as the reference stores it (before
+      // re-basing).  One barrier at the half-way mark; in its second half a wave forms the outputs of its blocks from its own running metric and
+      // the filed rows, 8 steps at a time through emit() like the one-wave form -- without check-points and without re-deriving anything.
+      extern __shared__ uint32_t drows[];
+      const uint32_t hb = ((nblk >> 1) / 3) * 3; // (a multiple of three: the block loops below run in threes, operand set = block index mod 3)
+      uint32_t*      RA = drows;                  // forward rows of the blocks [0, hb): (b, j) at (8 b + j) x 64 + lane
+      uint32_t*      RB = drows + (size_t)hb * 512; // backward rows of the blocks [hb, nblk): (b, j) at (8 (b - hb) + j) x 64 + lane
+      using T = std::true_type;
+      using F = std::false_type;
+      const uint32_t wrapj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (wave == 1) {
+        beta_start();
+        s2   bprev = o; // the backward metric of index k + 1 as filed, k the step about to be taken
+        auto blk = [&](auto SET, auto FULLC, auto SECONDC, int b) {
+          constexpr int  set = decltype(SET)::value, R0 = (2 * set) % 3;
+          constexpr bool FULL = decltype(FULLC)::value, SECOND = decltype(SECONDC)::value;
+          if (b >= 2) {
+            issue((uint32_t)b - 2, LAT_BUF((set + 1) % 3));
+          }
+          s2 xs[8], ys[8], ap[8];
+          prep(LAT_BUF(set), xs, ys, ap);
+          if constexpr (!SECOND) {
+#pragma unroll
+            for (int j = 7; j >= 0; j--) {
+              const uint32_t k = (uint32_t)b * 8 + j;
+              if (FULL || k < long_sb) {
+                RB[(((uint32_t)b - hb) * 8 + j) * 64 + li] = to_u(bprev);
+                if ((R0 + j) % 3 == 0) {
+                  bstep(LAT_RES(0, 0), xs[j], ys[j]);
+                } else if ((R0 + j) % 3 == 1) {
+                  bstep(LAT_RES(1, 0), xs[j], ys[j]);
+                } else {
+                  bstep(LAT_RES(2, 0), xs[j], ys[j]);
+                }
+                bprev = o;
+                if (AR::norm_at(k)) {
+                  o = normalise<AR>(o);
+                }
+              }
+            }
+          } else {
+            const uint32_t trl = lut[((uint32_t)b * LPC + pl) * 8 + slot];
+            uint32_t       ar[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              ar[j] = RA[((uint32_t)b * 8 + j) * 64 + li];
+            }
+            s2 go[8], gc[8], bt[8], t_o[8], t_c[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              if ((R0 + j) % 3 == 0) {
+                gammas<AR, 0>(lk, xs[j], ys[j], go[j], gc[j]);
+                t_c[j] = AR::add_raw(from_u(partner<0>(ar[j])), gc[j]);
+              } else if ((R0 + j) % 3 == 1) {
+                gammas<AR, 1>(lk, xs[j], ys[j], go[j], gc[j]);
+                t_c[j] = AR::add_raw(from_u(partner<1>(ar[j])), gc[j]);
+              } else {
+                gammas<AR, 2>(lk, xs[j], ys[j], go[j], gc[j]);
+                t_c[j] = AR::add_raw(from_u(partner<2>(ar[j])), gc[j]);
+              }
+              t_o[j] = AR::add_raw(from_u(ar[j]), go[j]);
+            }
+#pragma unroll
+            for (int j = 7; j >= 0; j--) {
+              bt[j] = bprev;
+              if ((R0 + j) % 3 == 0) {
+                o = beta_step<AR, 0>(o, go[j], gc[j]);
+              } else if ((R0 + j) % 3 == 1) {
+                o = beta_step<AR, 1>(o, go[j], gc[j]);
+              } else {
+                o = beta_step<AR, 2>(o, go[j], gc[j]);
+              }
+              bprev = o;
+              if (AR::norm_at((uint32_t)b * 8 + j)) {
+                o = normalise<AR>(o);
+              }
+            }
+            emit(std::integral_constant<int, R0>{}, T{}, (uint32_t)b, 8, bt, t_o, t_c, xs, ap, wrapj, trl);
+          }
+        };
+        int b = (int)nblk - 1;
+        switch (b % 3) {
+          case 0: issue((uint32_t)b, LAT_BUF(0)); issue((uint32_t)b - 1, LAT_BUF(2)); LAT_ARM("case0"); break;
+          case 1: issue((uint32_t)b, LAT_BUF(1)); issue((uint32_t)b - 1, LAT_BUF(0)); LAT_ARM("case1"); break;
+          default: issue((uint32_t)b, LAT_BUF(2)); issue((uint32_t)b - 1, LAT_BUF(1)); LAT_ARM("default"); break;
+        }
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        switch (b % 3) { // (the last block of a sub-block may be ragged: guarded code for that one)
+          case 0: blk(S0{}, F{}, F{}, b--); break;
+          case 1: blk(S1{}, F{}, F{}, b--); break;
+          default: blk(S2{}, F{}, F{}, b--); break;
+        }
+        if (b % 3 == 1) {
+          blk(S1{}, T{}, F{}, b--);
+        }
+        if (b % 3 == 0) {
+          blk(S0{}, T{}, F{}, b--);
+        }
+        for (; b >= (int)hb + 2; b -= 3) { // (nblk >= 7 and hb <= nblk / 2: the blocks above never reach below hb; hb = 0 mod 3: this loop ends on it)
+          blk(S2{}, T{}, F{}, b);
+          blk(S1{}, T{}, F{}, b - 1);
+          blk(S0{}, T{}, F{}, b - 2);
+        }
+        __syncthreads();
+        for (; b >= 2; b -= 3) {
+          blk(S2{}, T{}, T{}, b);
+          blk(S1{}, T{}, T{}, b - 1);
+          blk(S0{}, T{}, T{}, b - 2);
+        }
+      } else {
+        alpha_start();
+        auto blk = [&](auto SET, auto FULLC, auto SECONDC, uint32_t b) {
+          constexpr int  set = decltype(SET)::value, R0 = (2 * set) % 3;
+          constexpr bool FULL = decltype(FULLC)::value, SECOND = decltype(SECONDC)::value;
+          const int      len = FULL ? 8 : ((long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8);
+          if (b + 2 < nblk) {
+            issue(b + 2, LAT_BUF((set + 2) % 3));
+          }
+          s2 xs[8], ys[8], ap[8];
+          prep(LAT_BUF(set), xs, ys, ap);
+          if constexpr (!SECOND) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              RA[(b * 8 + j) * 64 + li] = to_u(o);
+              if ((R0 + j) % 3 == 0) {
+                astep(LAT_RES(0, 0), xs[j], ys[j]);
+              } else if ((R0 + j) % 3 == 1) {
+                astep(LAT_RES(1, 0), xs[j], ys[j]);
+              } else {
+                astep(LAT_RES(2, 0), xs[j], ys[j]);
+              }
+              if (AR::norm_at(b * 8 + j)) {
+                o = normalise<AR>(o);
+              }
+            }
+          } else {
+            const uint32_t trl = lut[(b * LPC + pl) * 8 + slot];
+            s2             go[8], gc[8], bt[8], t_o[8], t_c[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              bt[j] = from_u(RB[((b - hb) * 8 + j) * 64 + li]);
+              if ((R0 + j) % 3 == 0) {
+                gammas<AR, 0>(lk, xs[j], ys[j], go[j], gc[j]);
+              } else if ((R0 + j) % 3 == 1) {
+                gammas<AR, 1>(lk, xs[j], ys[j], go[j], gc[j]);
+              } else {
+                gammas<AR, 2>(lk, xs[j], ys[j], go[j], gc[j]);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              t_o[j] = t_c[j] = splat(0);
+              if (FULL || j < len) {
+                if ((R0 + j) % 3 == 0) {
+                  alpha_branches<AR, 0>(o, go[j], gc[j], t_o[j], t_c[j]);
+                } else if ((R0 + j) % 3 == 1) {
+                  alpha_branches<AR, 1>(o, go[j], gc[j], t_o[j], t_c[j]);
+                } else {
+                  alpha_branches<AR, 2>(o, go[j], gc[j], t_o[j], t_c[j]);
+                }
+                if (AR::norm_at(b * 8 + j)) {
+                  o = normalise<AR>(o);
+                }
+              }
+            }
+            emit(std::integral_constant<int, R0>{}, FULLC, b, len, bt, t_o, t_c, xs, ap, wrapj, trl);
+          }
+        };
+        issue(0, LAT_BUF(0));
+        issue(1, LAT_BUF(1));
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        uint32_t b = 0;
+        for (; b < hb; b += 3) {
+          blk(S0{}, T{}, F{}, b);
+          blk(S1{}, T{}, F{}, b + 1);
+          blk(S2{}, T{}, F{}, b + 2);
+        }
+        __syncthreads();
+        for (; b + 3 < nblk; b += 3) { // full blocks only: the last block of the sub-block is left to the guarded code below
+          blk(S0{}, T{}, T{}, b);
+          blk(S1{}, T{}, T{}, b + 1);
+          blk(S2{}, T{}, T{}, b + 2);
+        }
+        if (b + 1 < nblk) {
+          blk(S0{}, T{}, T{}, b++);
+          if (b + 1 < nblk) {
+            blk(S1{}, T{}, T{}, b++);
+          }
+        }
+        switch (b % 3) { // b == nblk - 1
+          case 0: blk(S0{}, F{}, T{}, b); break;
+          case 1: blk(S1{}, F{}, T{}, b); break;
+          default: blk(S2{}, F{}, T{}, b); break;
+        }
+      }
+      __syncthreads();
+      return;
     }
+    // ================= backward recursion (turbodecoder_win.h:551-681)
+    beta_start();
     // pass 1: whole sub-block, a check-point at every block boundary; blocks nblk - 1 ... 0, block b in set b mod 3, block b - 2 requested
     {
       // FULL: all 8 steps of the block exist (every block but a ragged last one): no per-step conditions, one scheduling region
@@ -403,10 +803,10 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
         constexpr int  set = decltype(SET)::value, R0 = (2 * set) % 3;
         constexpr bool FULL = decltype(FULLC)::value;
         if (b >= 2) {
-          issue((uint32_t)b - 2, buf[(set + 1) % 3]);
+          issue((uint32_t)b - 2, LAT_BUF((set + 1) % 3));
         }
         s2 xs[8], ys[8], ap[8];
-        prep(buf[set], xs, ys, ap);
+        prep(LAT_BUF(set), xs, ys, ap);
 #pragma unroll
         for (int j = 7; j >= 0; j--) {
           const uint32_t k = (uint32_t)b * 8 + j;
@@ -430,9 +830,9 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
       int b = (int)nblk - 1;
       // (the sets of the two first blocks are only known at run time: their loads go through a switch once)
       switch (b % 3) {
-        case 0: issue((uint32_t)b, buf[0]); issue((uint32_t)b - 1, buf[2]); break;
-        case 1: issue((uint32_t)b, buf[1]); issue((uint32_t)b - 1, buf[0]); break;
-        default: issue((uint32_t)b, buf[2]); issue((uint32_t)b - 1, buf[1]); break;
+        case 0: issue((uint32_t)b, LAT_BUF(0)); issue((uint32_t)b - 1, LAT_BUF(2)); LAT_ARM("case0"); break;
+        case 1: issue((uint32_t)b, LAT_BUF(1)); issue((uint32_t)b - 1, LAT_BUF(0)); LAT_ARM("case1"); break;
+        default: issue((uint32_t)b, LAT_BUF(2)); issue((uint32_t)b - 1, LAT_BUF(1)); LAT_ARM("default"); break;
       }
       // the first block may be ragged (W not a multiple of 8): guarded code for that one
       using T = std::true_type;
@@ -457,73 +857,8 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
     __syncthreads(); // check-point stores before their loads
 
     // ================= forward recursion + LLR (turbodecoder_win.h:684-832)
-    o = splat(-AR::kInf);
-    {
-      // warm-up: the last 40 steps of every sub-block, blocks w0 / 8 ... (W - 1) / 8, block b in set b mod 3
-      const uint32_t w0 = long_sb - TD_WIN_OVERLAP;
-      const uint32_t bl = (long_sb - 1) >> 3, b0 = w0 >> 3;
-      auto           blk = [&](auto SET, uint32_t b) {
-        constexpr int set = decltype(SET)::value, R0 = (2 * set) % 3;
-        if (b + 2 <= bl) {
-          issue(b + 2, buf[(set + 2) % 3]);
-        }
-        s2 xs[8], ys[8], ap[8];
-        prep(buf[set], xs, ys, ap);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const uint32_t k = b * 8 + j;
-          if (k >= w0 && k < long_sb) {
-            if ((R0 + j) % 3 == 0) {
-              astep(LAT_RES(0, 0), xs[j], ys[j]);
-            } else if ((R0 + j) % 3 == 1) {
-              astep(LAT_RES(1, 0), xs[j], ys[j]);
-            } else {
-              astep(LAT_RES(2, 0), xs[j], ys[j]);
-            }
-            if (AR::norm_at(k - w0)) {
-              o = normalise<AR>(o);
-            }
-          }
-        }
-      };
-      switch (b0 % 3) {
-        case 0: issue(b0, buf[0]); issue(b0 + 1, buf[1]); break;
-        case 1: issue(b0, buf[1]); issue(b0 + 1, buf[2]); break;
-        default: issue(b0, buf[2]); issue(b0 + 1, buf[0]); break;
-      }
-      uint32_t b = b0;
-      if (b % 3 == 1) {
-        blk(std::integral_constant<int, 1>{}, b++);
-      }
-      if (b % 3 == 2 && b <= bl) {
-        blk(std::integral_constant<int, 2>{}, b++);
-      }
-      for (; b + 2 <= bl; b += 3) {
-        blk(std::integral_constant<int, 0>{}, b);
-        blk(std::integral_constant<int, 1>{}, b + 1);
-        blk(std::integral_constant<int, 2>{}, b + 2);
-      }
-      if (b <= bl) {
-        blk(std::integral_constant<int, 0>{}, b++);
-      }
-      if (b <= bl) {
-        blk(std::integral_constant<int, 1>{}, b++);
-      }
-    }
-    // hand every estimate (alpha at step W, labelling of rW) to the next sub-block as its alpha at step 0 (slot == state); the first
-    // sub-block starts in state 0
-    {
-      const int      src  = slot_of(rW, slot); // slot that holds state `slot` in the labelling of rW
-      uint32_t own, prev;
-      read2(to_u(o), gbase + pl * 8 + src, gbase + ((pl + LPC - 1) % LPC) * 8 + src, own, prev);
-      const uint32_t lo   = (pl == 0) ? (uint32_t)(uint16_t)(short)(slot ? -AR::kInf : 0) : (prev >> 16);
-      const uint32_t hi   = own & 0xffffu;
-      o                   = from_u(lo | (hi << 16));
-    }
+    alpha_start();
 
-    const uint32_t* lut  = dec1 ? p.deint : p.inter; // per (block, destination pair, step): row | source sub-blocks (turbo_host.cpp)
-    uint32_t*       dst  = dec1 ? A2 : A1;
-    const bool      last = (n + 1 == p.n_end) || crc_poly;
     {
       uint32_t ckb[3], trb[3]; // check-point and exchange entry of a block, same three-set scheme
       auto     issue_aux = [&](uint32_t b, int set) {
@@ -535,11 +870,11 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
         constexpr bool FULL = decltype(FULLC)::value;
         const int      len = FULL ? 8 : ((long_sb - b * 8) < 8 ? (int)(long_sb - b * 8) : 8);
         if (b + 2 < nblk) {
-          issue(b + 2, buf[(set + 2) % 3]);
+          issue(b + 2, LAT_BUF((set + 2) % 3));
           issue_aux(b + 2, (set + 2) % 3);
         }
         s2 xs[8], ys[8], ap[8];
-        prep(buf[set], xs, ys, ap);
+        prep(LAT_BUF(set), xs, ys, ap);
         uint32_t wrapj[8]; // (8-bit only) destination rows of the 8 steps: the wrap flag of the extrinsic subtraction
         if (AR::kIs8 && !dec1 && wrap_row != 0xffffffffu) {
           load8(lut + (b * LPC + pl) * 8, wrapj);
@@ -598,99 +933,11 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
             }
           }
         }
-        // max-log-MAP outputs of the 8 steps, STAGE BY STAGE across the steps: the eight reductions are independent, so every cross-lane move
-        // reads a register written eight instructions earlier and needs no wait states (step by step, a fifth of the block was s_nop).
-        // Even slots collect the data-bit-0 maximum, odd slots the data-bit-1 one: a lane keeps the candidate of its class, sends the other to
-        // slot ^ 1, then ONE value per lane is reduced over slot ^ 2 and slot ^ 4.
-        s2 w[8], u[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const bool q = lk.q[(R0 + j) % 3];
-          w[j]         = AR::add_raw(bt[j], q ? t_o[j] : t_c[j]);
-          u[j]         = AR::add_raw(bt[j], q ? t_c[j] : t_o[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          u[j] = from_u(partner<0>(to_u(u[j])));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          w[j] = vmax(w[j], u[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          u[j] = from_u(partner<1>(to_u(w[j])));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          w[j] = vmax(w[j], u[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          u[j] = from_u(partner<2>(to_u(w[j])));
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          w[j] = vmax(w[j], u[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          u[j] = from_u(partner<0>(to_u(w[j]))); // the other class' maximum
-        }
-        s2 kept = splat(0), keptraw = splat(0);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          if (FULL || j < len) {
-            const s2       m1  = lk.odd ? w[j] : u[j];
-            const s2       m0  = lk.odd ? u[j] : w[j];
-            const s2       llr = AR::llr(AR::clean(m1), AR::clean(m0));
-            const uint32_t k   = b * 8 + j;
-            // decoder 1: ext1 - app1 (the a-priori it just used; zero in the first half iteration); decoder 2: ext2 - its systematic input
-            s2 proc;
-            if constexpr (dec1) {
-              proc = AR::ex_sub(llr, ap[j], k == wrap_row);
-            } else {
-              proc = AR::ex_sub(llr, xs[j], AR::kIs8 && (wrapj[j] & 0xffffu) == wrap_row);
-            }
-            kept    = slot == j ? proc : kept; // lane (pair, j) keeps the output of step j
-            keptraw = slot == j ? llr : keptraw;
-          }
-        }
-        // exchange of the block's 8 rows: lane (pair p', step j) assembles the two values of its destination sub-blocks
-        const uint32_t trl = trb[set];
-        const uint32_t row = trl & 0xffffu, jlo = (trl >> 16) & 31u, jhi = (trl >> 21) & 31u;
-        const int      a_l = gbase + (int)(jlo >> 1) * 8 + slot, c_l = gbase + (int)(jhi >> 1) * 8 + slot;
-        auto           pick = [&](uint32_t v) {
-          uint32_t a, c;
-          read2(v, a_l, c_l, a, c);
-          const uint32_t lo = (jlo & 1u) ? (a >> 16) : (a & 0xffffu);
-          const uint32_t hi = (jhi & 1u) ? (c >> 16) : (c & 0xffffu);
-          return lo | (hi << 16);
-        };
-        const uint32_t v   = pick(to_u(kept));
-        const uint32_t dat = ((row >> 3) * LPC + pl) * 8 + (row & 7u);
-        if (slot < len) {
-          dst[dat] = v;
-        }
-        if (last) {
-          // what tdec_decision_byte reads (turbodecoder.c:370-378), natural order: ext1 after decoder 1, the de-interleaved ext2 after decoder 2
-          // (every lane takes part in the exchange: across two waves it has a barrier inside)
-          uint32_t r, at;
-          if constexpr (dec1) {
-            r  = to_u(keptraw);
-            at = (b * LPC + pl) * 8 + slot;
-          } else {
-            r  = pick(to_u(keptraw));
-            at = dat;
-          }
-          if (slot < len) {
-            D[at] = r;
-          }
-        }
+        emit(std::integral_constant<int, R0>{}, FULLC, b, len, bt, t_o, t_c, xs, ap, wrapj, trb[set]);
       };
-      issue(0, buf[0]);
+      issue(0, LAT_BUF(0));
       issue_aux(0, 0);
-      issue(1, buf[1]);
+      issue(1, LAT_BUF(1));
       issue_aux(1, 1);
       using T = std::true_type;
       using F = std::false_type;
@@ -713,6 +960,8 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
       }
     }
 #undef LAT_RES
+#undef LAT_BUF
+#undef LAT_ARM
     __syncthreads();
   };
 
@@ -748,6 +997,37 @@ __global__ __launch_bounds__(LPC > 8 ? 8 * LPC : 64) void tdec_lat_kernel(const 
 uint32_t lat_ws_dwords(uint32_t K, int nb)
 {
   return (lat::ws_dwords(K, nb) + 3u) & ~3u;
+}
+
+// two waves per code block, one per recursion (16 sub-blocks, 16-bit): LDS for the filed metric rows, 2 KB per 8-step block
+size_t lat2_lds_bytes(uint32_t K)
+{
+  const uint32_t long_sb = K / 16, nblk = (long_sb + 7) / 8;
+  return (size_t)nblk * 512 * sizeof(uint32_t);
+}
+hipError_t launch_lat2(const WinParams& p, hipStream_t stream)
+{
+  const bool   es  = p.crc_poly || p.desc;
+  const size_t lds = lat2_lds_bytes(p.K);
+  if (lds > 120 * 1024 || p.K < 16 * (TD_WIN_OVERLAP + 8)) {
+    return hipErrorInvalidValue;
+  }
+  static bool attr_set[kMaxDevices][2] = {};
+  const int   dev = current_device(), di = dev >= 0 && dev < kMaxDevices ? dev : 0;
+  if (!attr_set[di][es]) {
+    const hipError_t e = es ? hipFuncSetAttribute(reinterpret_cast<const void*>(lat::tdec_lat_kernel<8, Ar16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(lat::tdec_lat_kernel<8, Ar16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e != hipSuccess) {
+      return e;
+    }
+    attr_set[di][es] = true;
+  }
+  if (es) {
+    hipLaunchKernelGGL((lat::tdec_lat_kernel<8, Ar16, true, true>), dim3((unsigned)p.n_cb), dim3(128), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL((lat::tdec_lat_kernel<8, Ar16, false, true>), dim3((unsigned)p.n_cb), dim3(128), lds, stream, p);
+  }
+  return hipGetLastError();
 }
 
 // latency kernel: 16 / 8 sub-blocks with 16-bit arithmetic, 32 / 16 sub-blocks with 8-bit arithmetic (32 sub-blocks: two waves per block)

@@ -11,14 +11,18 @@ import oracle_api as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["throughput kernel", "latency kernel"])
+@pytest.fixture(autouse=True, params=["throughput kernel", "latency kernel", "latency kernel, two waves"])
 def tdec_kernel(request, hiplib):
     """every test of this module runs twice: with the throughput kernel (8 code blocks per wave, turbo_kernels.hip) and with the latency kernel
     (one code block per wave, states across lanes, turbo_lat_kernels.hip) wherever the latter exists (16 sub-blocks, and 8 sub-blocks 16-bit) --
     SRSRAN_HIP_TDEC_LAT = 0 / 1; unset, the library picks by batch size (turbo_device.h: kLatMaxBlocks)"""
-    assert hiplib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", b"1" if request.param == "latency kernel" else b"0") == 0
+    # (third run: the two-wave form of the latency kernel -- forward and backward recursion of a block at once, 16 sub-blocks / 16-bit -- SRSRAN_HIP_TDEC_LAT2;
+    # the scalar decoder's latency kernel, turbo_gen_lat_kernels.hip, follows SRSRAN_HIP_TDEC_LAT as well)
+    assert hiplib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", b"0" if request.param == "throughput kernel" else b"1") == 0
+    assert hiplib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT2", b"1" if request.param == "latency kernel, two waves" else b"0") == 0
     yield request.param
     assert hiplib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", None) == 0
+    assert hiplib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT2", None) == 0
 SB = 18600
 
 

@@ -16,13 +16,14 @@ _, pool = (O.turbo_llrs_8bit if llr8 else O.turbo_llrs)(K, 16, 1.0, seed=1)
 if sb:
     pool = np.stack([O.natural_to_sb_layout(pool[i], K, 32 if llr8 else 16) for i in range(16)])
 stride = pool.shape[1]
-for n_cb in (13, 104, 832, 1024, 2048, 4096, 8192):
+for n_cb in (1, 13, 104, 256, 512, 832, 1024, 2048, 4096, 8192):
     d_llr = torch.from_numpy(pool).to(dev).repeat((n_cb + 15) // 16, 1)[:n_cb].contiguous()
     d_bits = torch.zeros((n_cb, K // 8), dtype=torch.uint8, device=dev)
     dec = S.TdecBatch(K, n_cb, capi.TDEC_AUTO, llr8=llr8)
     row = []
-    for lat in (b"0", b"1"):
+    for lat, lat2 in ((b"0", b"0"), (b"1", b"0"), (b"1", b"1")):
         lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", lat)
+        lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT2", lat2)
         for nit in (1, 2, 4, 8):
             best = 1e9
             for rep in range(4):
@@ -35,7 +36,7 @@ for n_cb in (13, 104, 832, 1024, 2048, 4096, 8192):
                 e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1))
             row.append(best)
-    print("K=%d sb=%d n_cb=%5d  throughput kernel: %s   latency kernel: %s  (ms at 1/2/4/8 half iterations)" %
-          (K, sb, n_cb, " ".join("%.3f" % v for v in row[:4]), " ".join("%.3f" % v for v in row[4:])), flush=True)
+    print("K=%d sb=%d n_cb=%5d  throughput kernel: %s   latency kernel: %s   two waves per block: %s  (ms at 1/2/4/8 half iterations)" %
+          (K, sb, n_cb, " ".join("%.3f" % v for v in row[:4]), " ".join("%.3f" % v for v in row[4:8]), " ".join("%.3f" % v for v in row[8:])), flush=True)
     del dec
-lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", None)
+lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT", None); lib.srsran_hip_dev_knob(b"SRSRAN_HIP_TDEC_LAT2", None)

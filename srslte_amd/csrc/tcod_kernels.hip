@@ -254,49 +254,47 @@ __global__ __launch_bounds__(64) void tb_encode_kernel(const TbParams p)
 // A has period 7), and because the encoder is linear the true parity bits are the zero-state ones XOR the zero-input response of the entry
 // state (period 7).  The transport-block CRC is formed by the workgroup of the block that carries it.
 
-// A^e s for e = 0..6, s = 0..7 (zero-input steps of the constituent encoder), 3 bits per entry
-struct RscTables {
-  uint32_t pow[7];  // pow[e] >> (3 s) & 7 = A^e s
-  uint32_t resp[8]; // resp[s]: bit j = parity output of zero-input step j from state s, j = 0..6 (period 7), repeated up to bit 27
-};
-__device__ __forceinline__ RscTables rsc_tables()
+// Zero-input steps of the constituent encoder are linear in the state: A^e s (e = 0 ... 6: A has period 7) and the parity bits the next steps put out
+// from state s are XORs of what the three unit states give -- compile-time constants picked by the bits of s.  (As tables indexed by e / s the
+// compiler kept them in SCRATCH memory: a dependent scratch load per step of the scan.)
+__host__ __device__ constexpr uint32_t rsc_next0(uint32_t s) // rsc_step(s, 0)
 {
-  RscTables t;
-#pragma unroll
-  for (int e = 0; e < 7; e++) {
-    t.pow[e] = 0;
-  }
-#pragma unroll
-  for (uint32_t s0 = 0; s0 < 8; s0++) {
-    uint32_t s = s0, r = 0;
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-      t.pow[j] |= s << (3 * s0);
-      uint32_t o;
-      s = rsc_step(s, 0u, &o);
-      r |= o << j;
-    }
-    t.resp[s0] = r | (r << 7) | (r << 14) | (r << 21);
-  }
-  return t;
+  const uint32_t r0 = s & 1u, r1 = (s >> 1) & 1u, r2 = (s >> 2) & 1u;
+  return (r2 ^ r1) | (r0 << 1) | (r1 << 2);
 }
-__device__ __forceinline__ uint32_t rsc_resp(const RscTables& t, uint32_t s)
+__host__ __device__ constexpr uint32_t rsc_out0(uint32_t s) // its parity output: r2 ^ r0 ^ (r2 ^ r1)
 {
-  uint32_t w = t.resp[0];
-#pragma unroll
-  for (int k = 1; k < 8; k++) {
-    w = s == (uint32_t)k ? t.resp[k] : w;
+  return (s ^ (s >> 1)) & 1u;
+}
+__host__ __device__ constexpr uint32_t rsc_pow_col(int j) // A^e (1 << j) at bits 3 e, e = 0 ... 6
+{
+  uint32_t s = 1u << j, w = 0;
+  for (int e = 0; e < 7; e++) {
+    w |= s << (3 * e);
+    s = rsc_next0(s);
   }
   return w;
 }
-__device__ __forceinline__ uint32_t rsc_apply(const RscTables& t, uint32_t e, uint32_t s) // A^e s
+__host__ __device__ constexpr uint32_t rsc_resp_col(int j) // bit i = parity output of zero-input step i from state 1 << j, period 7, up to bit 27
 {
-  uint32_t w = t.pow[0];
-#pragma unroll
-  for (int k = 1; k < 7; k++) {
-    w = e == (uint32_t)k ? t.pow[k] : w;
+  uint32_t s = 1u << j, r = 0;
+  for (int i = 0; i < 7; i++) {
+    r |= rsc_out0(s) << i;
+    s = rsc_next0(s);
   }
-  return (w >> (3u * s)) & 7u;
+  return r | (r << 7) | (r << 14) | (r << 21);
+}
+static_assert(rsc_next0(rsc_next0(rsc_next0(rsc_next0(rsc_next0(rsc_next0(rsc_next0(5u))))))) == 5u, "period 7");
+__device__ __forceinline__ uint32_t rsc_resp(uint32_t s)
+{
+  constexpr uint32_t R0 = rsc_resp_col(0), R1 = rsc_resp_col(1), R2 = rsc_resp_col(2);
+  return ((s & 1u) ? R0 : 0u) ^ ((s & 2u) ? R1 : 0u) ^ ((s & 4u) ? R2 : 0u);
+}
+__device__ __forceinline__ uint32_t rsc_apply(uint32_t e, uint32_t s) // A^e s, e < 7
+{
+  constexpr uint32_t P0 = rsc_pow_col(0), P1 = rsc_pow_col(1), P2 = rsc_pow_col(2);
+  const uint32_t     sh = 3u * e;
+  return (((s & 1u) ? (P0 >> sh) : 0u) ^ ((s & 2u) ? (P1 >> sh) : 0u) ^ ((s & 4u) ? (P2 >> sh) : 0u)) & 7u;
 }
 
 // XOR over the 256 lanes of the workgroup (4 waves); red: 4 words of LDS
@@ -381,7 +379,6 @@ __global__ __launch_bounds__(256) void tb_encode_lat_kernel(const TbParams p)
     __syncthreads();
   }
   // ---- both constituent encoders from the zero state: parity bits of this lane's stretch in a register (L <= 24 steps)
-  const RscTables T  = rsc_tables();
   const uint32_t  L  = (K + 255u) / 256u;
   const uint32_t  i0 = min(lane * L, K), i1 = min(i0 + L, K), len = i1 - i0;
   uint32_t        par[2], fin[2];
@@ -402,7 +399,7 @@ __global__ __launch_bounds__(256) void tb_encode_lat_kernel(const TbParams p)
     for (uint32_t off = 1; off < 64; off <<= 1) {
       const uint32_t pe = __shfl_up(me, off), pv = __shfl_up(mv, off);
       if ((lane & 63u) >= off) {
-        mv = rsc_apply(T, me, pv) ^ mv; // (A^me (A^pe x + pv) + mv
+        mv = rsc_apply(me, pv) ^ mv; // (A^me (A^pe x + pv) + mv
         me = (me + pe) % 7u;
       }
     }
@@ -413,17 +410,17 @@ __global__ __launch_bounds__(256) void tb_encode_lat_kernel(const TbParams p)
     __syncthreads();
     uint32_t s_wave = 0; // state at the start of this lane's wave
     for (uint32_t w = 0; w < (lane >> 6); w++) {
-      s_wave = rsc_apply(T, wtot[e][w] >> 3, s_wave) ^ (wtot[e][w] & 7u);
+      s_wave = rsc_apply(wtot[e][w] >> 3, s_wave) ^ (wtot[e][w] & 7u);
     }
     // entry state of the lane = the maps of all lanes before it applied to the zero state: the exclusive prefix
     const uint32_t pe = __shfl_up(me, 1), pv = __shfl_up(mv, 1);
-    const uint32_t s_in = (lane & 63u) ? (rsc_apply(T, pe, s_wave) ^ pv) : s_wave;
+    const uint32_t s_in = (lane & 63u) ? (rsc_apply(pe, s_wave) ^ pv) : s_wave;
     // the encoder is linear: true parity = zero-state parity + zero-input response of the entry state
-    par[e] = bits ^ (rsc_resp(T, s_in) & ((1u << len) - 1u)); // (len <= 24)
+    par[e] = bits ^ (rsc_resp(s_in) & ((1u << len) - 1u)); // (len <= 24)
     // final state of the whole block (for the tail): what lane 255 leaves
     uint32_t s_end = s_wave;
     for (uint32_t w = (lane >> 6); w < 4; w++) {
-      s_end = rsc_apply(T, wtot[e][w] >> 3, s_end) ^ (wtot[e][w] & 7u);
+      s_end = rsc_apply(wtot[e][w] >> 3, s_end) ^ (wtot[e][w] & 7u);
     }
     fin[e] = s_end;
     __syncthreads();

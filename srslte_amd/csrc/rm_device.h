@@ -32,7 +32,7 @@ struct TbCrcResult {
 // d_cb_ok: the decoder's verdict per code block of the launch (1 = CRC good)
 // d_mult: rows of 256 multipliers (tb_crc_multipliers(), one row per distinct tbs of the launch)
 hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, const uint32_t* d_mult,
-                         TbCrcResult* d_res, hipStream_t stream);
+                         TbCrcResult* d_res, hipStream_t stream, uint8_t* host_data = nullptr);
 // the kernel's split of a block of tbs / 8 bytes over its 256 lanes, and what lane l multiplies its chunk's remainder with
 void tb_crc_multipliers(uint32_t tbs, uint32_t poly, uint32_t out[256]);
 

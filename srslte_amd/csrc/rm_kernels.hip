@@ -285,13 +285,24 @@ __device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b, uint32_t p
 __host__ __device__ static inline uint32_t tb_crc_chunk(uint32_t nb) { return (nb + 255) / 256; }
 
 __global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const TbCrcJob* jobs, uint32_t poly_full, const uint8_t* cb_ok,
-                                                     const uint32_t* mult, TbCrcResult* res)
+                                                     const uint32_t* mult, TbCrcResult* res, uint8_t* host_data)
 {
   __shared__ uint32_t red[256];
   __shared__ uint32_t tab[256];
   __shared__ uint32_t s_good;
   const TbCrcJob jb   = jobs[blockIdx.x];
   const uint32_t poly = poly_full & 0xffffffu;
+  if (host_data) {
+    // single transport blocks on host buffers (decode_tb_cb): the decoded bytes -- payload, transport CRC and the last block's own CRC behind it -- go
+    // to the caller's pinned image from here instead of a copy operation of their own behind this kernel (a launch more in a chain of seven)
+    // (16 bytes per lane: a block's place in both images starts on a 256-byte boundary and is padded to one, sch_host.cpp)
+    const uint32_t nvec = (jb.tbs / 8 + 6 + 15) / 16;
+    const uint4*   src  = reinterpret_cast<const uint4*>(data + jb.data_offset);
+    uint4*         dst  = reinterpret_cast<uint4*>(host_data + jb.data_offset);
+    for (uint32_t i = threadIdx.x; i < nvec; i += 256) {
+      dst[i] = src[i];
+    }
+  }
   {
     uint32_t c = (uint32_t)threadIdx.x << 16;
     for (int b = 0; b < 8; b++) {
@@ -345,9 +356,9 @@ __global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* data, const 
 }
 
 hipError_t launch_tb_crc(const uint8_t* d_data, const TbCrcJob* d_jobs, int n_jobs, uint32_t poly, const uint8_t* d_cb_ok, const uint32_t* d_mult,
-                         TbCrcResult* d_res, hipStream_t stream)
+                         TbCrcResult* d_res, hipStream_t stream, uint8_t* host_data)
 {
-  hipLaunchKernelGGL(tb_crc_kernel, dim3(n_jobs), dim3(256), 0, stream, d_data, d_jobs, poly, d_cb_ok, d_mult, d_res);
+  hipLaunchKernelGGL(tb_crc_kernel, dim3(n_jobs), dim3(256), 0, stream, d_data, d_jobs, poly, d_cb_ok, d_mult, d_res, host_data);
   return hipGetLastError();
 }
 

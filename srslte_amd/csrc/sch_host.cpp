@@ -140,7 +140,7 @@ struct TailCopy {
 };
 static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hip_tb_t* tbs, uint32_t n_tb, uint32_t max_iterations, void* d_softbuf,
                       uint8_t* cb_crc, uint8_t* d_data, srsran_hip_tb_result_t* results, void* stream, bool llr8, const TailCopy* tail = nullptr,
-                      int n_tail = 0)
+                      int n_tail = 0, uint8_t* host_data = nullptr) // host_data: pinned mirror of d_data the transport-CRC kernel fills (tb_crc_kernel)
 {
   TraceRange trace_("srsran_hip_sch_decode");
   if (h) {
@@ -397,7 +397,7 @@ static int sch_decode(srsran_hip_sch_t* h, const void* d_e_bits, const srsran_hi
   }
   // transport-block CRC (sch.c:473-477,540-560) of the blocks whose code blocks are all good, straight behind the decoders
   if (n_crc) {
-    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)n_crc, CRC24A, d_ok, h->d_crc_mult, d_tbr, st), SRSRAN_ERROR);
+    PHY_HIP_CHECK(rm::launch_tb_crc(d_data, d_tbj, (int)n_crc, CRC24A, d_ok, h->d_crc_mult, d_tbr, st, host_data), SRSRAN_ERROR);
   }
   if (!direct && (n || n_crc)) {
     PHY_HIP_CHECK(hipMemcpyAsync(hb + o_noi, base + o_noi, o_tbr + n_crc * sizeof(rm::TbCrcResult) - o_noi, hipMemcpyDeviceToHost, st), SRSRAN_ERROR);
@@ -743,10 +743,10 @@ static void tbs_staged_homogeneous(phyhip::sch::TbItem* it, uint32_t n, const ph
       }
     }
   }
-  // the decoded bytes come back in front of the call's one host wait; the combined soft bits only when a block failed (second wait, below)
-  const TailCopy tail[1] = {{s.pin + o_data0, s.dev + o_data0, total - o_data0}};
-  const int      rc = sch_decode(s.sch, dev_e ? s.dev : s.pin, tbs.data(), (uint32_t)tbs.size(), q0->max_iterations ? q0->max_iterations : 1, s.dev,
-                                 cbflags.data(), s.dev + o_data0, res.data(), s.st, llr8, tail, 1);
+  // the decoded bytes come back in front of the call's one host wait (the transport-CRC kernel writes them into the pinned image); the combined soft bits
+  // only when a block failed (second wait, below)
+  const int rc = sch_decode(s.sch, dev_e ? s.dev : s.pin, tbs.data(), (uint32_t)tbs.size(), q0->max_iterations ? q0->max_iterations : 1, s.dev, cbflags.data(),
+                            s.dev + o_data0, res.data(), s.st, llr8, nullptr, 0, s.pin + o_data0);
   if (rc != SRSRAN_SUCCESS) {
     (void)hipStreamSynchronize(s.st);
     fprintf(stderr, "[srsran_phy_hip] decode_tb_cb: %s\n", get_error());

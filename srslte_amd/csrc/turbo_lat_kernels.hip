@@ -112,7 +112,7 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
         return (uint32_t)(uint16_t)AR::conv_in((int)(short)(w & 0xffffu)) | ((uint32_t)(uint16_t)AR::conv_in((int)(short)(w >> 16)) << 16);
       };
       constexpr uint32_t UB = 4;
-      for (uint32_t b0 = 0; b0 < nblk; b0 += UB) {
+      for (uint32_t b0 = DUAL ? UB * (uint32_t)wave : 0u; b0 < nblk; b0 += DUAL ? 2 * UB : UB) { // (DUAL: the two waves share the blocks)
         uint32_t v[UB][3];
 #pragma unroll
         for (uint32_t u = 0; u < UB; u++) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
         }
       }
     }
-    for (uint32_t b = p.sb_layout ? nblk : 0; b < nblk; b++) {
+    for (uint32_t b = (p.sb_layout ? nblk : 0) + (DUAL ? (uint32_t)wave : 0u); b < nblk; b += DUAL ? 2 : 1) {
       const uint32_t k  = b * 8 + slot;
       const uint32_t kk = k < long_sb ? k : long_sb - 1;
       uint32_t       v[3];

@@ -92,6 +92,10 @@ typedef struct SRSRAN_API {
 SRSRAN_API int srsran_hip_pdsch_encode(const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, cf_t* symbols);
 /* the same, and e_out (or NULL) <- the scrambled, byte-packed coded bits the reference leaves in q->e[cw] (pdsch.c:1005-1012), nof_re * Qm bits rounded
  * up to whole bytes */
+/* the codewords of one TTI in ONE call (the loop over the scheduled UEs of srsenb/src/phy/lte/cc_worker.cc encode_pdsch, each of which ends in
+ * srsran_pdsch_encode, pdsch.c:1017): arrays of n entries, one coding launch over the code blocks of all of them and one scrambling + modulation launch. */
+SRSRAN_API int srsran_hip_pdsch_encode_multi(uint32_t n, const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* const* softbuffers, uint8_t* const* data,
+                                             cf_t* const* symbols);
 SRSRAN_API int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* softbuffer, uint8_t* data, cf_t* symbols, uint8_t* e_out);
 
 /* ---- UL-SCH transmit without UCI (srsran_ulsch_encode, sch.c:1194-1340, with no ACK / RI / CQI configured): encode_tb -> channel

@@ -502,6 +502,7 @@ def lib():
             "srsran_hip_pdsch_encode": (i32, [C.POINTER(HipPdschTx), C.POINTER(SoftbufferTx), vp, vp]),
             "srsran_hip_pdsch_decode_dbg": (i32, [C.POINTER(HipPdschRx), vp, vp, C.POINTER(SoftbufferRx), vp, C.POINTER(HipGrantRes), vp, vp]),
             "srsran_hip_pdsch_encode_dbg": (i32, [C.POINTER(HipPdschTx), C.POINTER(SoftbufferTx), vp, vp, vp]),
+            "srsran_hip_pdsch_encode_multi": (i32, [u32, C.POINTER(HipPdschTx), C.POINTER(C.POINTER(SoftbufferTx)), C.POINTER(vp), C.POINTER(vp)]),
             "srsran_hip_ulsch_encode": (i32, [C.POINTER(HipGrantTb), u32, C.POINTER(SoftbufferTx), vp, vp]),
             "srsran_hip_modulate_bytes": (i32, [u32, vp, vp, u32, u32, u32, C.c_float]),
             "srsran_hip_cellsearch_create": (i32, [C.POINTER(vp), u32, u32, i32, i32, u32]),

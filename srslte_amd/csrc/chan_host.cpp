@@ -423,7 +423,7 @@ bool enqueue_mod(hipStream_t st, const uint8_t* d_bits, uint32_t mod, uint32_t n
   if (!tab) {
     return false;
   }
-  modem::ModParams p;
+  modem::ModParams p = {};
   p.bits     = d_bits;
   p.out      = reinterpret_cast<float2*>(p_out);
   p.table    = tab;
@@ -499,6 +499,88 @@ extern "C" int srsran_hip_pdsch_encode_dbg(const srsran_hip_pdsch_tx_t* g, srsra
   memcpy(symbols, s.pin, nb);
   if (want_e) {
     memcpy(e_out, p_e, ((size_t)tb.nof_re * qm_of(tb.mod) + 7) / 8);
+  }
+  return SRSRAN_SUCCESS;
+}
+
+// the codewords of a TTI (srsenb/src/phy/lte/cc_worker.cc encode_pdsch: one srsran_enb_dl_put_pdsch per scheduled UE) in ONE call: one coding launch over
+// the code blocks of all of them, one scrambling + modulation launch, one host wait
+extern "C" int srsran_hip_pdsch_encode_multi(uint32_t n, const srsran_hip_pdsch_tx_t* g, srsran_softbuffer_tx_t* const* softbuffers, uint8_t* const* data,
+                                             cf_t* const* symbols)
+{
+  TraceRange trace_("srsran_hip_pdsch_encode");
+  if (n == 0) {
+    return SRSRAN_SUCCESS;
+  }
+  if (!g || !softbuffers || !data || !symbols) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  if (n == 1) {
+    return srsran_hip_pdsch_encode(&g[0], softbuffers[0], data[0], symbols[0]);
+  }
+  if (!device_available()) {
+    fprintf(stderr, "[srsran_phy_hip] srsran_hip_pdsch_encode: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  bind_thread();
+  ChanStage&                   s = stage();
+  std::vector<srsran_cbsegm_t> seg(n);
+  std::vector<sch::TxItem>     items(n);
+  std::vector<size_t>          o_out(n);
+  size_t                       out_bytes = 0, tiles = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (!softbuffers[i] || !symbols[i] || !tb_valid(g[i].tb, "srsran_hip_pdsch_encode")) {
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    if (srsran_cbsegm(&seg[i], g[i].tb.tbs) != SRSRAN_SUCCESS) {
+      fprintf(stderr, "Error computing segmentation for TBS=%d\n", g[i].tb.tbs); // sch.c:637-640
+      return SRSRAN_ERROR;
+    }
+    items[i] = {softbuffers[i], &seg[i], qm_rm(g[i].tb), g[i].tb.rv, g[i].tb.nof_re * qm_of(g[i].tb.mod), data[i], 0};
+    o_out[i] = out_bytes;
+    out_bytes += al256((size_t)g[i].tb.nof_re * sizeof(cf_t));
+    tiles += (g[i].tb.nof_re + MODEM_TILE_SYMS - 1) / MODEM_TILE_SYMS;
+  }
+  const size_t o_jobs = out_bytes, o_tj = al256(o_jobs + n * sizeof(modem::ModJob));
+  if (!s.grow(al256(o_tj + tiles * sizeof(uint32_t)), 0)) {
+    return SRSRAN_ERROR;
+  }
+  const sch::GroupBackEnd back = [&](hipStream_t st, const uint8_t* d_e, const uint32_t* e_byte_off, uint32_t m) -> bool {
+    modem::Params sp;
+    const float2* tab = modem::mod_tables();
+    if (m != n || !modem::params_for(sp, modem::LLR_I16) || !tab) {
+      return false;
+    }
+    auto*    mj = reinterpret_cast<modem::ModJob*>(s.pin + o_jobs);
+    auto*    tj = reinterpret_cast<uint32_t*>(s.pin + o_tj);
+    uint32_t nt = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t cnt = (g[i].tb.nof_re + MODEM_TILE_SYMS - 1) / MODEM_TILE_SYMS;
+      mj[i] = {g[i].tb.mod, g[i].tb.nof_re, g[i].tb.seed, 1u, g[i].scaling != 0.f ? g[i].scaling : 1.0f, e_byte_off[i], (uint32_t)(o_out[i] / sizeof(cf_t)), nt};
+      for (uint32_t t = 0; t < cnt; t++) {
+        tj[nt++] = i;
+      }
+    }
+    modem::ModParams p = {};
+    p.bits     = d_e;
+    p.out      = reinterpret_cast<float2*>(s.pin);
+    p.table    = tab;
+    p.x1_bits  = sp.x1_bits;
+    p.x2_cols  = sp.x2_cols;
+    p.jobs     = mj;
+    p.tile_job = tj;
+    if (modem::launch_mod_jobs(p, nt, st) != hipSuccess) {
+      set_error("modulator launch failed");
+      return false;
+    }
+    return true;
+  };
+  const int rc = sch::encode_tbs_staged(items.data(), n, &back);
+  if (rc != SRSRAN_SUCCESS) {
+    return rc;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    memcpy(symbols[i], s.pin + o_out[i], (size_t)g[i].tb.nof_re * sizeof(cf_t));
   }
   return SRSRAN_SUCCESS;
 }

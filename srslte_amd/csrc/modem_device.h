@@ -68,12 +68,24 @@ struct ModParams {
   float           scale;   // 1.0f: none
   const uint32_t* x1_bits;
   const uint32_t* x2_cols;
+  // several code words in one launch (the grants of a TTI, chan_host.cpp): jobs != nullptr replaces mod / n / seed / scramble / scale per job, `bits` and
+  // `out` are the bases the jobs' offsets count from; tile_job[workgroup] = its job (device-readable arrays)
+  const struct ModJob* jobs;
+  const uint32_t*      tile_job;
+};
+struct ModJob {
+  uint32_t mod, n, seed, scramble;
+  float    scale;
+  uint32_t bits_off; // first byte of the job's packed bits
+  uint32_t out_off;  // first constellation point
+  uint32_t tile0;    // first workgroup of the job
 };
 __host__ __device__ inline uint32_t mod_table_offset(uint32_t mod) // BPSK 2 | QPSK 4 | 16-QAM 16 | 64-QAM 64 | 256-QAM 256 points
 {
   return mod == 0 ? 0u : (mod == 1 ? 2u : (mod == 2 ? 6u : (mod == 3 ? 22u : 86u)));
 }
 hipError_t launch_mod(const ModParams& p, hipStream_t stream);
+hipError_t launch_mod_jobs(const ModParams& p, uint32_t n_tiles, hipStream_t stream); // p.jobs / p.tile_job set
 // srsran_sequence_apply_packed (sequence.c): out = in ^ c, byte-packed bits, MSB first; nbits is rounded up to whole 32-bit words (both buffers must hold them)
 hipError_t launch_scramble_packed(const uint8_t* in, uint8_t* out, uint32_t nbits, uint32_t seed, const uint32_t* x1_bits, const uint32_t* x2_cols, hipStream_t stream);
 // host side (modem_host.cpp): parameter block with the sequence tables and thresholds filled in; the constellation tables on the device

@@ -474,11 +474,11 @@ __global__ __launch_bounds__(256) void modem_kernel(const Params p)
 
 // ---- modulator: one workgroup = MODEM_TILE_SYMS symbols, a quarter per wave; the wave's chips as in demod_tile
 template <int MOD>
-__device__ __forceinline__ void mod_tile(const ModParams& p, uint32_t* cbw)
+__device__ __forceinline__ void mod_tile(const ModParams& p, uint32_t tile, uint32_t* cbw)
 {
   constexpr int  QM   = MOD == 0 ? 1 : 2 * MOD;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t w0   = blockIdx.x * MODEM_TILE_SYMS + (threadIdx.x >> 6) * (MODEM_TILE_SYMS / 4);
+  const uint32_t w0   = tile * MODEM_TILE_SYMS + (threadIdx.x >> 6) * (MODEM_TILE_SYMS / 4);
   if (w0 >= p.n) {
     return;
   }
@@ -512,29 +512,42 @@ __device__ __forceinline__ void mod_tile(const ModParams& p, uint32_t* cbw)
   }
 }
 
-__global__ __launch_bounds__(256) void mod_kernel(const ModParams p)
+__global__ __launch_bounds__(256) void mod_kernel(const ModParams pin)
 {
   __shared__ __attribute__((aligned(16))) uint32_t cb[4][MODEM_TILE_BITS / 128 + 4];
   if ((threadIdx.x & 63u) == 0) {
     cb[threadIdx.x >> 6][MODEM_TILE_BITS / 128] = 0;
   }
+  __shared__ ModJob sjob;
+  if (pin.jobs && threadIdx.x < sizeof(ModJob) / 4) {
+    ((uint32_t*)&sjob)[threadIdx.x] = ((const uint32_t*)(pin.jobs + pin.tile_job[blockIdx.x]))[threadIdx.x];
+  }
   __syncthreads();
+  ModParams p    = pin;
+  uint32_t  tile = blockIdx.x;
+  if (pin.jobs) {
+    const ModJob j = sjob;
+    p.bits += j.bits_off;
+    p.out += j.out_off;
+    p.mod = j.mod, p.n = j.n, p.seed = j.seed, p.scramble = j.scramble, p.scale = j.scale;
+    tile -= j.tile0;
+  }
   uint32_t* cbw = cb[threadIdx.x >> 6];
   switch (p.mod) {
     case 0:
-      mod_tile<0>(p, cbw);
+      mod_tile<0>(p, tile, cbw);
       break;
     case 1:
-      mod_tile<1>(p, cbw);
+      mod_tile<1>(p, tile, cbw);
       break;
     case 2:
-      mod_tile<2>(p, cbw);
+      mod_tile<2>(p, tile, cbw);
       break;
     case 3:
-      mod_tile<3>(p, cbw);
+      mod_tile<3>(p, tile, cbw);
       break;
     default:
-      mod_tile<4>(p, cbw);
+      mod_tile<4>(p, tile, cbw);
       break;
   }
 }
@@ -671,6 +684,15 @@ hipError_t launch_mod(const ModParams& p, hipStream_t stream)
     return hipSuccess;
   }
   hipLaunchKernelGGL(mod_kernel, dim3(ceil_div(p.n, MODEM_TILE_SYMS)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_mod_jobs(const ModParams& p, uint32_t n_tiles, hipStream_t stream)
+{
+  if (n_tiles == 0 || !p.jobs || !p.tile_job) {
+    return n_tiles ? hipErrorInvalidValue : hipSuccess;
+  }
+  hipLaunchKernelGGL(mod_kernel, dim3(n_tiles), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -35,6 +35,17 @@ bool decode_tb_staged(void* q, srsran_softbuffer_rx_t* softbuffer, srsran_cbsegm
 
 // transmit side: encode_tb on the thread's stage (tcod_host.cpp).  `back` consumes the e bits (byte packed) on the device instead of a download.
 using BackEnd = std::function<bool(hipStream_t stream, const uint8_t* d_e_bits)>;
+// the same for n transport blocks in one call: ONE coding launch over the code blocks of all of them; `back` gets the device image of the e bits and every
+// block's first BYTE in it (a block's bits start on a 256-byte boundary)
+struct TxItem {
+  srsran_softbuffer_tx_t* sb;
+  srsran_cbsegm_t*        seg;
+  uint32_t                Qm, rv, nof_e_bits;
+  uint8_t*                data; // payload, or NULL: retransmission of what the soft buffer holds
+  uint32_t                e_byte_off; // out
+};
+using GroupBackEnd = std::function<bool(hipStream_t stream, const uint8_t* d_e_bits, const uint32_t* e_byte_off, uint32_t n)>;
+int encode_tbs_staged(TxItem* items, uint32_t n, const GroupBackEnd* back);
 int encode_tb_staged(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, uint8_t* data, uint8_t* e_bits,
                      const BackEnd* back);
 

@@ -685,6 +685,94 @@ extern "C" int srsran_hip_encode_tb(srsran_softbuffer_tx_t* softbuffer, srsran_c
   return phyhip::sch::encode_tb_staged(softbuffer, cb_segm, Qm, rv, nof_e_bits, data, e_bits, nullptr);
 }
 
+// n transport blocks, their e bits consumed on the device (sch_stage.h)
+int phyhip::sch::encode_tbs_staged(TxItem* it, uint32_t n, const GroupBackEnd* back)
+{
+  if (!it || !back || n == 0) {
+    return SRSRAN_ERROR_INVALID_INPUTS;
+  }
+  auto   al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t pay_bytes = 0, e_bytes = 0, n_cb = 0;
+  for (uint32_t t = 0; t < n; t++) {
+    TxItem& x = it[t];
+    if (!x.seg || !x.sb) {
+      fprintf(stderr, "Invalid parameters: e_bits=%d, cb_segm=%d, softbuffer=%d\n", 1, x.seg != 0, x.sb != 0); // sch.c:351
+      return SRSRAN_ERROR_INVALID_INPUTS;
+    }
+    if (x.seg->F) {
+      fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // :254-257
+      return SRSRAN_ERROR;
+    }
+    if (x.seg->C > x.sb->max_cb) {
+      fprintf(stderr, "Error number of CB to encode (%d) exceeds soft buffer size (%d CBs)\n", x.seg->C, x.sb->max_cb); // :259-262
+      return SRSRAN_ERROR;
+    }
+    if (x.Qm == 0 || x.rv > 3 || x.seg->C == 0 || x.seg->tbs == 0 || x.nof_e_bits == 0) {
+      fprintf(stderr, "Invalid Qm\n"); // :264-267
+      return SRSRAN_ERROR;
+    }
+    pay_bytes += al(x.seg->tbs / 8 + 8);
+    e_bytes += al((x.nof_e_bits + 7) / 8 + 8);
+    n_cb += x.seg->C;
+  }
+  static thread_local StageRef<TxTbStage> ref;
+  TxTbStage&                             s = ref.get();
+  if (!s.ready()) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: %s (there is no CPU fallback)\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  if (!s.grow(e_bytes + pay_bytes + 512)) { // pinned: [payloads]; device: [e bits | payloads]
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: staging allocation failed\n");
+    return SRSRAN_ERROR;
+  }
+  std::vector<srsran_hip_tb_t> tbs(n);
+  std::vector<uint32_t>        e_off(n);
+  size_t                       po = 0, eo = 0;
+  for (uint32_t t = 0; t < n; t++) {
+    TxItem&        x = it[t];
+    const uint32_t C = x.seg->C;
+    uint32_t       rp = 0;
+    for (uint32_t i = 0; i < C; i++) { // payload slices of the code blocks in the transmit side's order (the C2 smaller blocks first, sch.c:284-290)
+      const uint32_t K    = i < x.seg->C2 ? x.seg->K2 : x.seg->K1;
+      const uint32_t rlen = C > 1 ? K - 24 : K;
+      const uint32_t nb   = (i + 1 == C ? rlen - 24 : rlen) / 8;
+      if (!x.sb->buffer_b[i]) {
+        return SRSRAN_ERROR;
+      }
+      if (x.data) {
+        memcpy(x.sb->buffer_b[i], x.data + rp / 8, nb);
+      }
+      memcpy(s.pin + po + rp / 8, x.sb->buffer_b[i], nb);
+      rp += 8 * nb;
+    }
+    if (rp != x.seg->tbs) {
+      fprintf(stderr, "[srsran_phy_hip] encode_tb: segmentation does not add up to the transport block size (%u != %u)\n", rp, x.seg->tbs);
+      return SRSRAN_ERROR;
+    }
+    tbs[t]       = {x.seg->tbs, x.Qm, x.rv, x.nof_e_bits, (uint32_t)(8 * eo), (uint32_t)po, 0};
+    e_off[t]     = (uint32_t)eo;
+    x.e_byte_off = (uint32_t)eo;
+    po += al(x.seg->tbs / 8 + 8);
+    eo += al((x.nof_e_bits + 7) / 8 + 8);
+  }
+  const bool direct = n_cb <= 64 && knob(KNOB_TCOD_LAT) != 0; // (as encode_tb_staged: the one-launch kernel reads the payload from the pinned image)
+  if (!direct) {
+    PHY_HIP_CHECK(hipMemcpyAsync(s.dev + e_bytes, s.pin, pay_bytes, hipMemcpyHostToDevice, s.st), SRSRAN_ERROR);
+  }
+  if (srsran_hip_sch_encode(s.enc, direct ? s.pin : s.dev + e_bytes, tbs.data(), n, s.dev, s.st) != SRSRAN_SUCCESS) {
+    (void)hipStreamSynchronize(s.st);
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  const bool ok = (*back)(s.st, s.dev, e_off.data(), n);
+  PHY_HIP_CHECK(hipStreamSynchronize(s.st), SRSRAN_ERROR); // (also after a failed enqueue: nothing may be in flight when the images are re-used)
+  if (!ok) {
+    fprintf(stderr, "[srsran_phy_hip] encode_tb: %s\n", get_error());
+    return SRSRAN_ERROR;
+  }
+  return SRSRAN_SUCCESS;
+}
+
 // `back` given: the e bits stay on the device and the kernels back(stream, d_e_bits) enqueues consume them there (chan_host.cpp: scrambling +
 // modulation, or the UL channel interleaver) -- their results are the caller's to collect after this function's one host wait
 int phyhip::sch::encode_tb_staged(srsran_softbuffer_tx_t* softbuffer, srsran_cbsegm_t* cb_segm, uint32_t Qm, uint32_t rv, uint32_t nof_e_bits, uint8_t* data,

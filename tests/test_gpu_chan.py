@@ -388,6 +388,47 @@ def test_pdsch_codeword_encode_in_one_call(hiplib, mod, tbs, nof_re, nl, scaling
         assert np.array_equal(np.unpackbits(e_out)[:nbits], scr) and np.all(e_out[(nbits + 7) // 8:] == 0xEE), rv
 
 
+def test_pdsch_codewords_of_a_tti_in_one_call(hiplib):
+    """srsran_hip_pdsch_encode_multi: the codewords of one TTI (different modulations, sizes, redundancy versions, power scalings, two layers; one of them a
+    retransmission from its soft buffer) in one call give the oracle's chain for each -- and what the single call gives"""
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    rng = np.random.default_rng(2024)
+    ues = [  # mod, tbs, nof_re, nl, scaling, rv
+        (3, 36696, 7200, 1, 1.0, 0), (2, 6200, 2400, 2, 1.0, 2), (1, 328, 300, 1, 1.4142135, 0), (4, 31704, 5200, 1, 0.5, 3), (1, 40, 120, 1, 1.0, 1), (3, 18336, 3600, 1, 1.0, 0),
+    ]
+    n = len(ues)
+    grants = (capi.HipPdschTx * n)()
+    sbs, pays, outs, wants = [], [], [], []
+    for i, (mod, tbs, nof_re, nl, scaling, rv) in enumerate(ues):
+        Qm, nbits = O.QM[mod], nof_re * O.QM[mod]
+        seed = O.pdsch_seed(0x50 + i, 0, 6, 401)
+        payload = rng.integers(0, 256, tbs // 8).astype(np.uint8)
+        grants[i] = capi.HipPdschTx(capi.HipGrantTb(mod, tbs, rv, nof_re, seed, 0, 0, nl), scaling)
+        sb = _tx_softbuffer(capi, O.cbsegm(tbs)["C"])
+        if i == 3:  # a retransmission: the first transmission (rv 0) left the payload in the soft buffer
+            g0 = capi.HipPdschTx(capi.HipGrantTb(mod, tbs, 0, nof_re, seed, 0, 0, nl), scaling)
+            tmp = np.zeros(nof_re, np.complex64)
+            assert lib.srsran_hip_pdsch_encode(C.byref(g0), C.byref(sb[0]), O.P(payload), O.P(tmp)) == 0
+        e, _ = O.tb_coded_bits(tbs, Qm * nl, nbits, rv, None, payload=np.unpackbits(payload), tx_order=True)
+        wants.append(O.modulate_bytes(mod, np.packbits(e), nbits, seed=seed, scramble=True, scaling=scaling))
+        sbs.append(sb)
+        pays.append(payload)
+        outs.append(np.zeros(nof_re + 8, np.complex64))
+    data = (C.c_void_p * n)(*[None if i == 3 else pays[i].ctypes.data for i in range(n)])
+    assert lib.srsran_hip_pdsch_encode_multi(n, grants, (C.POINTER(capi.SoftbufferTx) * n)(*[C.pointer(s[0]) for s in sbs]), data,
+                                             (C.c_void_p * n)(*[o.ctypes.data for o in outs])) == 0, capi.last_error()
+    for i, (mod, tbs, nof_re, nl, scaling, rv) in enumerate(ues):
+        assert np.array_equal(outs[i][:nof_re].view(np.uint32), wants[i].view(np.uint32)), i
+        assert not outs[i][nof_re:].any(), i
+        single = np.zeros(nof_re, np.complex64)
+        assert lib.srsran_hip_pdsch_encode(C.byref(grants[i]), C.byref(sbs[i][0]), None, O.P(single)) == 0  # (from the soft buffer the multi call filled)
+        assert np.array_equal(single.view(np.uint32), outs[i][:nof_re].view(np.uint32)), i
+    assert lib.srsran_hip_pdsch_encode_multi(0, None, None, None, None) == 0
+
+
 @pytest.mark.parametrize("mod,tbs,L_prb,nsymb", [(3, 75376, 100, 12), (2, 6200, 25, 11), (1, 328, 4, 12), (2, 11448, 45, 10)], ids=["64qam_100prb", "16qam_srs", "qpsk", "ext_cp"])
 def test_ulsch_encode_in_one_call(hiplib, mod, tbs, L_prb, nsymb):
     """UE transmit side without UCI: encode_tb + the channel interleaver on the device = the oracle's e bits read through the oracle's table"""

@@ -186,5 +186,57 @@ int main(void)
     printf("%-52s %12.1f %12.1f %12.1f  %s (TBS %u per UE, %.2f decoder iterations per block)\n", splits[s].what, t1[REP / 2], tl[REP / 2], tm[REP / 2],
            ok ? "ok" : "BAD", tbs, res[0].avg_iterations_block);
   }
+  /* ---- downlink: the PDSCH codewords of one TTI, one srsran_hip_pdsch_encode per UE against one srsran_hip_pdsch_encode_multi */
+  if (only_split < 0) {
+    const struct {
+      uint32_t n, prb, mod, tbs;
+      const char* what;
+    } dl[] = {{1, 100, 3, 75376, "1 UE x 100 PRB, 64-QAM (13 code blocks)"},
+              {4, 25, 3, 18336, "4 UEs x 25 PRB, 64-QAM (3 code blocks each)"},
+              {8, 12, 2, 5736, "8 UEs x 12 PRB, 16-QAM (one code block)"},
+              {16, 6, 2, 2792, "16 UEs x 6 PRB, 16-QAM"},
+              {25, 4, 1, 1000, "25 UEs x 4 PRB, QPSK"}};
+    printf("%-52s %12s %12s\n", "PDSCH codewords of one TTI (encode)", "loop us", "multi us");
+    for (unsigned s = 0; s < sizeof(dl) / sizeof(dl[0]); s++) {
+      const uint32_t n = dl[s].n, nof_re = dl[s].prb * 12 * 11, tbs = dl[s].tbs; /* (11 of 14 symbols carry PDSCH, reference signals not taken out) */
+      srsran_hip_pdsch_tx_t*   g   = calloc(n, sizeof(*g));
+      srsran_softbuffer_tx_t*  sb  = calloc(n, sizeof(*sb));
+      srsran_softbuffer_tx_t** sbp = calloc(n, sizeof(*sbp));
+      uint8_t**                pay = calloc(n, sizeof(*pay));
+      cf_t **                  o1 = calloc(n, sizeof(*o1)), **o2 = calloc(n, sizeof(*o2));
+      for (uint32_t i = 0; i < n; i++) {
+        g[i] = (srsran_hip_pdsch_tx_t){{dl[s].mod, tbs, 0, nof_re, 0x1234u + i, 0, 0, 1}, 1.0f};
+        uint8_t** rows = calloc(13, sizeof(uint8_t*));
+        for (int r = 0; r < 13; r++) {
+          rows[r] = calloc(SB, 1);
+        }
+        sb[i]  = (srsran_softbuffer_tx_t){13, SB, rows};
+        sbp[i] = &sb[i];
+        pay[i] = calloc(tbs / 8 + 8, 1);
+        for (uint32_t k = 0; k < tbs / 8; k++) {
+          pay[i][k] = (uint8_t)(k * 37 + i * 11 + 3);
+        }
+        o1[i] = calloc(nof_re, sizeof(cf_t)), o2[i] = calloc(nof_re, sizeof(cf_t));
+      }
+      enum { REP = 60 };
+      double tl[REP], tm[REP];
+      int    ok = 1;
+      for (int r = 0; r < REP; r++) {
+        double t0 = now_us();
+        for (uint32_t i = 0; i < n; i++) {
+          ok &= srsran_hip_pdsch_encode(&g[i], &sb[i], pay[i], o1[i]) == 0;
+        }
+        tl[r] = now_us() - t0;
+        t0    = now_us();
+        ok &= srsran_hip_pdsch_encode_multi(n, g, sbp, pay, o2) == 0;
+        tm[r] = now_us() - t0;
+        for (uint32_t i = 0; i < n; i++) {
+          ok &= memcmp(o1[i], o2[i], nof_re * sizeof(cf_t)) == 0;
+        }
+      }
+      qsort(tl, REP, sizeof(double), cmp_d), qsort(tm, REP, sizeof(double), cmp_d);
+      printf("%-52s %12.1f %12.1f  %s (TBS %u per UE)\n", dl[s].what, tl[REP / 2], tm[REP / 2], ok ? "ok" : "BAD", tbs);
+    }
+  }
   return 0;
 }

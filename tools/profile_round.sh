@@ -5,7 +5,7 @@
 # Outputs go to gpurun_out/round/; the summaries to keep are copied into profiles/ by hand afterwards.
 set -o pipefail
 export TMPDIR=/tmp
-OUT=gpurun_out/round4
+OUT=${OUT:-gpurun_out/round4}
 mkdir -p $OUT
 B="python bench.py --steps 2 --warmup 1 --extra-steps 2 --no-cpu"
 if [ "$SKIP_PYTEST" != "1" ]; then
@@ -23,7 +23,9 @@ python tools/bench_ref_programs.py > $OUT/ref_programs.json 2> $OUT/ref_programs
 python tools/measure/ldpc_small.py > $OUT/ldpc_small.txt 2> /dev/null &&
 python tools/measure/pss_ab.py > $OUT/pss_ab.txt 2> /dev/null &&
 python tools/measure/es_time.py 1 > $OUT/es_time.txt 2> /dev/null && python tools/measure/es_time.py 64 >> $OUT/es_time.txt 2> /dev/null &&
-( python tools/measure/lat_time.py 6144 0; python tools/measure/lat_time.py 5824 1; python tools/measure/lat_time.py 6144 0 8 ) > $OUT/lat_time.txt 2> /dev/null &&
+( python tools/measure/lat_time.py 6144 0; python tools/measure/lat_time.py 5824 1; python tools/measure/lat_time.py 1024 1; python tools/measure/lat_time.py 6144 0 8 ) 2> /dev/null | grep "K=" > $OUT/lat_time.txt &&
+python tools/measure/gen_time.py 2> /dev/null | grep "K=" > $OUT/gen_time.txt &&
+( bash tools/measure/grant_timeline.sh $PWD/$OUT/tl > /dev/null 2>&1; grep -v "simple_timer\|generateRocpd\|tool.cpp" $OUT/tl/timeline.txt > $OUT/grant_timeline.txt; rm -rf $OUT/tl ) &&
 python tools/bench_sch.py > $OUT/bench_sch.json 2> $OUT/bench_sch.err &&
 python tools/bench_pusch_rx.py > $OUT/bench_pusch_rx.json 2> $OUT/bench_pusch_rx.err &&
 python tools/bench_nr_rx.py > $OUT/bench_nr_rx.json 2> $OUT/bench_nr_rx.err &&
@@ -38,6 +40,7 @@ python tools/rocpd_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > $OUT/p
 ( rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -d $OUT/pmc_lds -o p -- $B > /dev/null 2> $OUT/pmc_lds.err &&
   python tools/rocpd_summary.py $OUT/pmc_lds > $OUT/pmc_lds.txt ) || echo "LDS counter pass failed (see pmc_lds.err)"
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_lds
+if [ "$SKIP_VARIANTS" != "1" ]; then
 # ---- turbo launch-shape variants (DESIGN.md par. 3.2): time, traffic, VALU and wait counters of each
 T="python bench.py --steps 3 --warmup 1 --no-extras --no-cpu"
 : > $OUT/turbo_variants.txt
@@ -77,6 +80,7 @@ for V in wave recompute pair block; do
   rm -rf $OUT/v_s $OUT/v_l $OUT/v_f $OUT/v_w
 done
 unset SRSRAN_HIP_PSS_VARIANT SRSRAN_HIP_LIB
+fi
 ( cd tools/probe && hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o roundtrip_probe roundtrip_probe.hip -lpthread 2> /dev/null; ./roundtrip_probe 0 ) > $OUT/roundtrip_probe.txt 2>&1
 ( cd tools/probe && gcc -O2 -I../../include seam_threads.c -o seam_threads -L../../srslte_amd/lib -lsrsran_phy_hip -Wl,-rpath,'$ORIGIN/../../srslte_amd/lib' -lpthread -lm 2> /dev/null
   echo "== the library's default (it asks for 8 hardware queues)"; ./seam_threads; echo "== GPU_MAX_HW_QUEUES=4 (the runtime's own default)"; GPU_MAX_HW_QUEUES=4 ./seam_threads ) > $OUT/seam_threads.txt 2>&1

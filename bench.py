@@ -47,7 +47,7 @@ K_CB = 6144
 NIT = 8
 CB_PER_SF = 13  # 20 MHz, 64-QAM, MCS 28: TBS 75376 -> 13 code blocks (cbsegm.c:62-117)
 N_FFT, N_PRB = 2048, 100
-EXTRAS = ("ldpc", "cellsearch", "uplink", "uplink_waterfall", "turbo8", "seam")
+EXTRAS = ("ldpc", "cellsearch", "uplink", "uplink_waterfall", "turbo8", "seam", "grant")
 
 
 def parse(argv=None):

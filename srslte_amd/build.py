@@ -134,5 +134,7 @@ def _drain(procs):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
-    if "--variants" in sys.argv:
+    # the variants library links the product's objects: once it exists it follows the product (a stale one lacks new entry points and the ctypes mirror
+    # refuses to load it)
+    if "--variants" in sys.argv or os.path.exists(VARIANTS_LIB):
         print(build_variants(force="--force" in sys.argv))

@@ -849,3 +849,152 @@ def leg_seam(ctx, steps=3, warmup=1, want_cpu=True):
     p16 = [p for p in lte["points"] if p["llr"] == "int16"][0]
     return {"metric": "one transport block per call through the reference's own seam, host to host (latency)", "value": p16["p50_ms"], "unit": "ms",
             "higher_is_better": False, "config": {"workload": lte["what"]}, "lte": lte["points"], "nr": nr}
+
+
+# ------------------------------------------------------------------------------------------------ one device call per grant / per TTI
+
+def leg_grant(ctx, steps=3, warmup=1, want_cpu=True):
+    """The grant-level entry points (include/srsran_amd/phy_chan_abi.h) from HOST buffers, host to host, p50 / p99 of 100 calls: one full-band PUSCH grant
+    per call; the 8 grants of a TTI one call each and all in ONE srsran_hip_pusch_decode_multi; the same for the PDSCH codewords of a TTI on the transmit
+    side.  The signal is made by the library's own transmit side (srsran_hip_ulsch_encode -> srsran_hip_modulate_bytes with the PUSCH seed ->
+    srsran_dft_precoding -> resource grid), every payload is checked.  Latency, not throughput: `value` is the full-band grant's p50 in ms.  The reference's
+    own figure for the same grants (its pusch_test / pdsch_test stopwatch on one core) is in profiles/r04_ref_programs.json: 514 us (100 PRB), 32 us (12 PRB)."""
+    import ctypes as C
+    import time
+
+    import numpy as np
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    SB, NPRB = 18600, 100
+    pre = capi.DftPrecoding()
+    capi.check(lib.srsran_dft_precoding_init(C.byref(pre), NPRB, True), "dft_precoding_init")
+
+    def P(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def tx_sb(n_cb):
+        rows = [np.zeros(SB, np.uint8) for _ in range(n_cb)]
+        return capi.SoftbufferTx(n_cb, SB, (C.c_void_p * n_cb)(*[r.ctypes.data for r in rows])), rows
+
+    def rx_sb(n_cb):
+        rows = [np.zeros(SB, np.int16) for _ in range(n_cb)]
+        keep = [np.zeros(SB // 8, np.uint8) for _ in range(n_cb)]
+        flags = np.zeros(n_cb, np.bool_)
+        return capi.SoftbufferRx(n_cb, SB, (C.c_void_p * n_cb)(*[r.ctypes.data for r in rows]), (C.c_void_p * n_cb)(*[k.ctypes.data for k in keep]),
+                                 flags.ctypes.data_as(C.POINTER(C.c_bool)), False), rows, keep, flags
+
+    def make_ue(first_prb, L, mod, tbs, ident):
+        nsymb, nsc, qm = 12, 12 * L, 2 * mod
+        nof_re = nsymb * nsc
+        payload = ((np.arange(tbs // 8) * 131 + ident * 17 + 5) & 0xff).astype(np.uint8)
+        seed = lib.srsran_hip_sequence_pusch_seed(0x100 + ident, 4, 77)
+        tb = capi.HipGrantTb(mod, tbs, 0, nof_re, seed, 10, 0, 1)
+        sbt = tx_sb(13)
+        q = np.zeros(nof_re * qm // 8 + 8, np.uint8)
+        d, z = np.zeros(nof_re, np.complex64), np.zeros(nof_re, np.complex64)
+        capi.check(lib.srsran_hip_ulsch_encode(C.byref(tb), nsymb, C.byref(sbt[0]), P(payload), P(q)), "ulsch_encode")
+        assert lib.srsran_hip_modulate_bytes(mod, P(q), P(d), nof_re * qm, seed, 1, 1.0) == nof_re
+        capi.check(lib.srsran_dft_precoding(C.byref(pre), P(d), P(z), L, nsymb), "dft_precoding")
+        grid = np.zeros((14, 12 * NPRB), np.complex64)
+        rows = [s for s in range(14) if s not in (3, 10)]
+        grid[rows, 12 * first_prb:12 * first_prb + nsc] = z.reshape(nsymb, nsc)
+        g = capi.HipPuschRx(tb, NPRB, 7, (C.c_uint32 * 2)(first_prb, first_prb), L, 0, 0.0, 0)
+        return {"g": g, "grid": np.ascontiguousarray(grid.reshape(-1)), "ce": np.ones(14 * 12 * NPRB, np.complex64), "payload": payload, "out": np.zeros(tbs // 8 + 16, np.uint8),
+                "rx": rx_sb(13), "tbs": tbs}
+
+    def reset(u):
+        for r in u["rx"][1]:
+            r[:] = 0
+        u["rx"][3][:] = False
+
+    def pct(ts):
+        ts = sorted(ts)
+        return {"p50_us": ts[len(ts) // 2] * 1e6, "p99_us": ts[min(len(ts) - 1, int(len(ts) * 0.99))] * 1e6}
+
+    calls = 100
+    out = {}
+    # ---- one full-band grant per call (12 code blocks of 6144)
+    u = make_ue(0, 100, 3, 12 * (6144 - 24) - 24, 0)
+    res = capi.HipGrantRes()
+    ts, ok = [], True
+    for i in range(calls + 10):
+        reset(u)
+        t0 = time.perf_counter()
+        rc = lib.srsran_hip_pusch_decode(C.byref(u["g"]), P(u["grid"]), P(u["ce"]), C.byref(u["rx"][0]), P(u["out"]), C.byref(res))
+        t1 = time.perf_counter()
+        ok = ok and rc == 0 and res.crc_ok == 1 and np.array_equal(u["out"][:u["tbs"] // 8], u["payload"])
+        if i >= 10:
+            ts.append(t1 - t0)
+    out["pusch_100prb"] = dict(pct(ts), ok=bool(ok), what="1 UE x 100 PRB, 64-QAM, TBS %d (12 code blocks of 6144), %.1f decoder half iterations per block" % (u["tbs"], res.avg_iterations_block))
+    # ---- the 8 grants of a TTI (12 PRB each, 16-QAM, one code block of 5504): looped and in one call
+    n = 8
+    ues = [make_ue(12 * i, 12, 2, 5504 - 24, 10 + i) for i in range(n)]
+    grants = (capi.HipPuschRx * n)(*[x["g"] for x in ues])
+    gp = (C.c_void_p * n)(*[x["grid"].ctypes.data for x in ues])
+    cp = (C.c_void_p * n)(*[x["ce"].ctypes.data for x in ues])
+    sp = (C.POINTER(capi.SoftbufferRx) * n)(*[C.pointer(x["rx"][0]) for x in ues])
+    dp = (C.c_void_p * n)(*[x["out"].ctypes.data for x in ues])
+    rs = (capi.HipGrantRes * n)()
+    tl, tm, ok = [], [], True
+    for i in range(calls + 10):
+        for x in ues:
+            reset(x)
+        t0 = time.perf_counter()
+        for k, x in enumerate(ues):
+            ok = ok and lib.srsran_hip_pusch_decode(C.byref(grants[k]), P(x["grid"]), P(x["ce"]), C.byref(x["rx"][0]), P(x["out"]), C.byref(rs[k])) == 0 and rs[k].crc_ok == 1
+        t1 = time.perf_counter()
+        for x in ues:
+            ok = ok and np.array_equal(x["out"][:x["tbs"] // 8], x["payload"])
+            x["out"][:] = 0
+            reset(x)
+        t2 = time.perf_counter()
+        ok = ok and lib.srsran_hip_pusch_decode_multi(n, grants, gp, cp, sp, dp, rs) == 0
+        t3 = time.perf_counter()
+        for k, x in enumerate(ues):
+            ok = ok and rs[k].crc_ok == 1 and np.array_equal(x["out"][:x["tbs"] // 8], x["payload"])
+        if i >= 10:
+            tl.append(t1 - t0)
+            tm.append(t3 - t2)
+    out["pusch_8x12prb_looped"] = dict(pct(tl), ok=bool(ok), what="8 UEs x 12 PRB, 16-QAM, one code block of 5504 each: one srsran_hip_pusch_decode per grant")
+    out["pusch_8x12prb_one_call"] = dict(pct(tm), ok=bool(ok), what="the same 8 grants in ONE srsran_hip_pusch_decode_multi")
+    # ---- transmit side: the PDSCH codewords of a TTI
+    def make_cw(prb, mod, tbs, ident):
+        nof_re = prb * 12 * 11
+        return {"g": capi.HipPdschTx(capi.HipGrantTb(mod, tbs, 0, nof_re, 0x1234 + ident, 0, 0, 1), 1.0), "sb": tx_sb(13),
+                "payload": ((np.arange(tbs // 8) * 37 + ident * 11 + 3) & 0xff).astype(np.uint8), "o1": np.zeros(nof_re, np.complex64), "o2": np.zeros(nof_re, np.complex64)}
+
+    c100 = make_cw(100, 3, 75376, 0)
+    ts, ok = [], True
+    for i in range(calls + 10):
+        t0 = time.perf_counter()
+        ok = ok and lib.srsran_hip_pdsch_encode(C.byref(c100["g"]), C.byref(c100["sb"][0]), P(c100["payload"]), P(c100["o1"])) == 0
+        t1 = time.perf_counter()
+        if i >= 10:
+            ts.append(t1 - t0)
+    out["pdsch_encode_100prb"] = dict(pct(ts), ok=bool(ok), what="one codeword, 100 PRB, 64-QAM, TBS 75376 (13 code blocks)")
+    cws = [make_cw(12, 2, 5736, 20 + i) for i in range(n)]
+    gt = (capi.HipPdschTx * n)(*[x["g"] for x in cws])
+    st = (C.POINTER(capi.SoftbufferTx) * n)(*[C.pointer(x["sb"][0]) for x in cws])
+    pp = (C.c_void_p * n)(*[x["payload"].ctypes.data for x in cws])
+    op = (C.c_void_p * n)(*[x["o2"].ctypes.data for x in cws])
+    tl, tm, ok = [], [], True
+    for i in range(calls + 10):
+        t0 = time.perf_counter()
+        for k, x in enumerate(cws):
+            ok = ok and lib.srsran_hip_pdsch_encode(C.byref(gt[k]), C.byref(x["sb"][0]), P(x["payload"]), P(x["o1"])) == 0
+        t1 = time.perf_counter()
+        ok = ok and lib.srsran_hip_pdsch_encode_multi(n, gt, st, pp, op) == 0
+        t2 = time.perf_counter()
+        for x in cws:
+            ok = ok and np.array_equal(x["o1"].view(np.uint32), x["o2"].view(np.uint32))
+        if i >= 10:
+            tl.append(t1 - t0)
+            tm.append(t2 - t1)
+    out["pdsch_encode_8x12prb_looped"] = dict(pct(tl), ok=bool(ok), what="8 codewords x 12 PRB, 16-QAM: one srsran_hip_pdsch_encode per codeword")
+    out["pdsch_encode_8x12prb_one_call"] = dict(pct(tm), ok=bool(ok), what="the same 8 codewords in ONE srsran_hip_pdsch_encode_multi")
+    lib.srsran_dft_precoding_free(C.byref(pre))
+    return {"metric": "one full-band PUSCH grant per call through the grant-level entry point, host grids in, payload out (latency)", "value": out["pusch_100prb"]["p50_us"] / 1e3,
+            "unit": "ms", "higher_is_better": False, "config": {"workload": out["pusch_100prb"]["what"]}, "calls": calls, "points": out,
+            "all_payloads_ok": all(v["ok"] for v in out.values())}

@@ -88,11 +88,11 @@ hipError_t launch_win(int nb, bool arith8, const WinParams& p, hipStream_t strea
 // latency kernel (turbo_lat_kernels.hip): one code block per wave, states across lanes; same WinParams with its own workspace layout
 // (lat_ws_dwords per code block).  Exists for every window decoder: 16 / 8 sub-blocks (16-bit), 32 / 16 sub-blocks (8-bit; 32 sub-blocks = two waves per block).
 hipError_t launch_lat(int nb, bool arith8, const WinParams& p, hipStream_t stream);
-// its two-wave form (16 sub-blocks, 16-bit arithmetic): forward and backward recursion of a block at the same time, one wave each; same workspace layout,
+// its two-wave form (16 sub-blocks: K > 800 with 16-bit soft bits, 800 < K <= 2048 with 8-bit ones): forward and backward recursion of a block at the same time, one wave each; same workspace layout,
 // so a run may change between the two forms from launch to launch
-hipError_t launch_lat2(const WinParams& p, hipStream_t stream);
+hipError_t launch_lat2(bool arith8, const WinParams& p, hipStream_t stream);
 size_t     lat2_lds_bytes(uint32_t K);
-constexpr uint32_t kLat2MaxBlocks = 256; // (two waves and up to 96 KB of LDS per block: one block per CU; K = 6144, 8 half iterations: 256 blocks 0.27 against 0.51 ms, 512 blocks 0.54 against 0.57)
+constexpr uint32_t kLat2MaxBlocks = 256; // per block-per-CU the filed rows allow (turbo_host.cpp: want_lat2)
 uint32_t   lat_ws_dwords(uint32_t K, int nb);
 static inline bool lat_exists(int nb, bool arith8)
 {

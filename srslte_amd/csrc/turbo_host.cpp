@@ -266,14 +266,17 @@ static uint32_t* gen_crc_mult8(uint32_t K, uint32_t poly)
     }
   }));
 }
-// the latency kernel's two-wave form: 16 sub-blocks, 16-bit arithmetic, few blocks (it takes two waves and up to 96 KB of LDS per block)
+// the latency kernel's two-wave form: 16 sub-blocks, few blocks (it takes two waves and up to 96 KB of LDS per block)
 static bool want_lat2(srsran_hip_tdec_batch* h, uint32_t n_cb)
 {
-  if (h->nb != 16 || h->arith8 || turbo::lat2_lds_bytes(h->K) > 120 * 1024) {
+  if (h->nb != 16 || turbo::lat2_lds_bytes(h->K) > 120 * 1024) {
     return false;
   }
   const int k = knob(KNOB_TDEC_LAT2);
-  return k == 0 ? false : (k > 0 ? true : n_cb <= turbo::kLat2MaxBlocks);
+  // one round of the chip: a block's two waves and its filed rows -- up to four blocks per CU where the rows are small (K = 1024: 1024 blocks 0.155 against
+  // 0.199 ms per 8 half iterations, 2048 blocks 0.37 against 0.28; K = 6144, one block per CU: 256 blocks 0.27 against 0.51, 512 blocks 0.54 against 0.57)
+  const size_t per_cu = std::min<size_t>(4, (150 * 1024) / turbo::lat2_lds_bytes(h->K));
+  return k == 0 ? false : (k > 0 ? true : n_cb <= turbo::kLat2MaxBlocks * per_cu);
 }
 static int ensure_lat_ws(srsran_hip_tdec_batch* h, uint32_t n_cb)
 {
@@ -532,7 +535,7 @@ static int tdec_batch_run_range(srsran_hip_tdec_batch_t* h, const void* d_input_
       }
       p.ws        = h->d_ws_lat;
       p.ws_stride = turbo::lat_ws_dwords(h->K, h->nb);
-      PHY_HIP_CHECK(want_lat2(h, n_cb) ? turbo::launch_lat2(p, stream) : turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+      PHY_HIP_CHECK(want_lat2(h, n_cb) ? turbo::launch_lat2(h->arith8, p, stream) : turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
       h->state_in_lat = true;
     } else {
       PHY_HIP_CHECK(turbo::launch_win(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
@@ -744,7 +747,7 @@ int phyhip::turbo::batch_run_early_stop(srsran_hip_tdec_batch_t* h, const void* 
     p.crc_mult  = d_ml;
     p.ws        = h->d_ws_lat;
     p.ws_stride = turbo::lat_ws_dwords(h->K, h->nb);
-    PHY_HIP_CHECK(want_lat2(h, n_cb) ? turbo::launch_lat2(p, stream) : turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
+    PHY_HIP_CHECK(want_lat2(h, n_cb) ? turbo::launch_lat2(h->arith8, p, stream) : turbo::launch_lat(h->nb, h->arith8, p, stream), SRSRAN_ERROR);
     h->state_in_lat = true;
     return SRSRAN_SUCCESS;
   }

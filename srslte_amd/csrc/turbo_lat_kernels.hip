@@ -44,7 +44,7 @@ __host__ __device__ inline uint32_t ws_dwords(uint32_t K, int nb)
 template <int LPC, class AR, bool ES, bool DUAL = false>
 __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_lat_kernel(const WinParams p)
 {
-  static_assert(!DUAL || (LPC == 8 && !AR::kIs8), "the two-wave form exists for the 16-sub-block 16-bit decoder");
+  static_assert(!DUAL || LPC == 8, "the two-wave form exists for the 16-sub-block decoders");
   constexpr int NB  = 2 * LPC;
   constexpr int G   = 8 * LPC;            // lanes per code block: 32 (two blocks per wave), 64 (one wave) or 128 (two waves, 32 sub-blocks)
   constexpr int BPW = G >= 64 ? 1 : 64 / G; // code blocks per workgroup
@@ -601,7 +601,6 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
       uint32_t*      RB = drows + (size_t)hb * 512; // backward rows of the blocks [hb, nblk): (b, j) at (8 (b - hb) + j) x 64 + lane
       using T = std::true_type;
       using F = std::false_type;
-      const uint32_t wrapj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (wave == 1) {
         beta_start();
         s2   bprev = o; // the backward metric of index k + 1 as filed, k the step about to be taken
@@ -634,6 +633,10 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
             }
           } else {
             const uint32_t trl = lut[((uint32_t)b * LPC + pl) * 8 + slot];
+            uint32_t       wrapj[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // (8-bit only) destination rows of the 8 steps: the wrap flag of the extrinsic subtraction
+            if (AR::kIs8 && !dec1 && wrap_row != 0xffffffffu) {
+              load8(lut + ((uint32_t)b * LPC + pl) * 8, wrapj);
+            }
             uint32_t       ar[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -731,6 +734,10 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
             }
           } else {
             const uint32_t trl = lut[(b * LPC + pl) * 8 + slot];
+            uint32_t       wrapj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (AR::kIs8 && !dec1 && wrap_row != 0xffffffffu) {
+              load8(lut + (b * LPC + pl) * 8, wrapj);
+            }
             s2             go[8], gc[8], bt[8], t_o[8], t_c[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -1005,29 +1012,32 @@ size_t lat2_lds_bytes(uint32_t K)
   const uint32_t long_sb = K / 16, nblk = (long_sb + 7) / 8;
   return (size_t)nblk * 512 * sizeof(uint32_t);
 }
-hipError_t launch_lat2(const WinParams& p, hipStream_t stream)
+template <class AR, bool ES>
+static hipError_t launch_lat2_as(const WinParams& p, size_t lds, hipStream_t stream)
+{
+  static bool attr_set[kMaxDevices] = {};
+  const int   dev = current_device(), di = dev >= 0 && dev < kMaxDevices ? dev : 0;
+  if (!attr_set[di]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lat::tdec_lat_kernel<8, AR, ES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e != hipSuccess) {
+      return e;
+    }
+    attr_set[di] = true;
+  }
+  hipLaunchKernelGGL((lat::tdec_lat_kernel<8, AR, ES, true>), dim3((unsigned)p.n_cb), dim3(128), lds, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_lat2(bool arith8, const WinParams& p, hipStream_t stream)
 {
   const bool   es  = p.crc_poly || p.desc;
   const size_t lds = lat2_lds_bytes(p.K);
   if (lds > 120 * 1024 || p.K < 16 * (TD_WIN_OVERLAP + 8)) {
     return hipErrorInvalidValue;
   }
-  static bool attr_set[kMaxDevices][2] = {};
-  const int   dev = current_device(), di = dev >= 0 && dev < kMaxDevices ? dev : 0;
-  if (!attr_set[di][es]) {
-    const hipError_t e = es ? hipFuncSetAttribute(reinterpret_cast<const void*>(lat::tdec_lat_kernel<8, Ar16, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)
-                            : hipFuncSetAttribute(reinterpret_cast<const void*>(lat::tdec_lat_kernel<8, Ar16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-    if (e != hipSuccess) {
-      return e;
-    }
-    attr_set[di][es] = true;
+  if (arith8) {
+    return es ? launch_lat2_as<Ar8, true>(p, lds, stream) : launch_lat2_as<Ar8, false>(p, lds, stream);
   }
-  if (es) {
-    hipLaunchKernelGGL((lat::tdec_lat_kernel<8, Ar16, true, true>), dim3((unsigned)p.n_cb), dim3(128), lds, stream, p);
-  } else {
-    hipLaunchKernelGGL((lat::tdec_lat_kernel<8, Ar16, false, true>), dim3((unsigned)p.n_cb), dim3(128), lds, stream, p);
-  }
-  return hipGetLastError();
+  return es ? launch_lat2_as<Ar16, true>(p, lds, stream) : launch_lat2_as<Ar16, false>(p, lds, stream);
 }
 
 // latency kernel: 16 / 8 sub-blocks with 16-bit arithmetic, 32 / 16 sub-blocks with 8-bit arithmetic (32 sub-blocks: two waves per block)

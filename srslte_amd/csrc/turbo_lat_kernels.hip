@@ -191,7 +191,7 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
     {
       const int sh = (lane & 63) & ~7; // this pair's byte in the ballots of its wave
       constexpr uint32_t UD = 8; // loads in flight (24 were slower: the registers they take are spilled state of the caller)
-      for (uint32_t b0 = 0; b0 < nblk; b0 += UD) {
+      for (uint32_t b0 = DUAL ? UD * (uint32_t)wave : 0u; b0 < nblk; b0 += DUAL ? 2 * UD : UD) { // (DUAL: the two waves share the blocks, the words and the bytes)
         uint32_t r[UD];
 #pragma unroll
         for (uint32_t u = 0; u < UD; u++) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
         return r;
       };
       const uint32_t wps = sbs4 >> 2, nw = (uint32_t)NB * wps;
-      for (uint32_t w = li; w < nw; w += G) {
+      for (uint32_t w = (uint32_t)li + (DUAL ? 64u * (uint32_t)wave : 0u); w < nw; w += DUAL ? 2 * G : G) {
         const uint32_t d = w / wps, wi = w - d * wps;
         const int      nbit = (int)long_sb - (int)(32 * wi) > 32 ? 32 : (int)long_sb - (int)(32 * wi);
         if (nbit > 0) {
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
       for (int off = (G < 64 ? G : 64) / 2; off > 0; off >>= 1) {
         crc ^= __shfl_xor(crc, off, G < 64 ? G : 64);
       }
-      if constexpr (G > 64) { // the two waves of the block
+      if constexpr (G > 64 || DUAL) { // the two waves of the block
         if ((lane & 63) == 0) {
-          xcrc[lane >> 6] = crc;
+          xcrc[wave] = crc;
         }
         __syncthreads();
         crc = xcrc[0] ^ xcrc[1];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(DUAL ? 128 : (LPC > 8 ? 8 * LPC : 64)) void tdec_la
     if (write && live && (!crc_poly || crc == 0 || final_try)) {
       const uint32_t nbytes = K / 8;
       const uint32_t lim    = out_bytes < nbytes ? out_bytes : nbytes;
-      for (uint32_t w = li; w < nbytes; w += G) {
+      for (uint32_t w = (uint32_t)li + (DUAL ? 64u * (uint32_t)wave : 0u); w < nbytes; w += DUAL ? 2 * G : G) {
         uint32_t v;
         if (whole) {
           const uint32_t d = w / bps;

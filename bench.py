@@ -402,7 +402,8 @@ def worker(a):
                                  "check-points); what of it streams through HBM is `traffic` (DESIGN.md par. 3.2)"},
             "roofline_ofdm": {"kernel": "ofdm_kernel<Plan<2048,...>,rx>", "bound": "hbm", "achieved": r_o,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_o / HBM_PEAK_GBS, "traffic": traffic_o,
-                              "avg_launch_ms": t_ofdm * 1e3, "algorithmic_bytes_per_launch": n_sf * sf_bytes},
+                              "avg_launch_ms": t_ofdm * 1e3, "algorithmic_bytes_per_launch": n_sf * sf_bytes,
+                              "traffic_rate_gbs": (traffic_o / t_ofdm / 1e9) if traffic_o else None},
         }
         if not a.no_cpu and world == 1:
             pool = d_pool.cpu().numpy()

@@ -449,3 +449,67 @@ def test_ulsch_encode_in_one_call(hiplib, mod, tbs, L_prb, nsymb):
         g, _ = O.tb_coded_bits(tbs, Qm, nof_re * Qm, rv, None, payload=np.unpackbits(payload), tx_order=True)
         assert np.array_equal(np.unpackbits(q[:nof_re * Qm // 8]), g[lut]), rv
         assert np.all(q[nof_re * Qm // 8:] == 0xFF)
+
+
+def test_multi_grant_calls_from_worker_threads(hiplib):
+    """three worker threads at once, each decoding its own TTI's grants in one srsran_hip_pusch_decode_multi and encoding its own codewords in one
+    srsran_hip_pdsch_encode_multi, 20 rounds: every call of every thread gives what the single calls gave (staging contexts, job lists in the pinned
+    images and the two-wave / scalar latency kernels are per thread or re-entrant; the reference runs one PHY worker thread per subframe in flight)"""
+    import threading
+
+    import srslte_amd as S
+    from srslte_amd import capi
+
+    lib = S.lib()
+    nof_prb, cp_nsymb = 100, 7
+
+    def worker(tid, errors):
+        try:
+            rng = np.random.default_rng(500 + tid)
+            ues = [((0, 0), 25, 3, 18336, 29.0), ((25, 25), (12, 15, 16)[tid], 2, 5480, 17.0), ((50, 50), 4, 1, 328, 8.0), ((60, 60), 30, 3, 21384, 29.0)]
+            n = len(ues)
+            grants = (capi.HipPuschRx * n)()
+            grids, ces, want = [], [], []
+            for i, (n_prb, L_prb, mod, tbs, snr) in enumerate(ues):
+                nof_re = 12 * 12 * L_prb
+                bits = rng.integers(0, 2, tbs).astype(np.uint8)
+                grid, ce, seed = _pusch_signal(rng, nof_prb, cp_nsymb, n_prb, L_prb, 0, mod, tbs, 0, 0x300 + 16 * tid + i, 4, 33, snr, bits)
+                grants[i] = capi.HipPuschRx(capi.HipGrantTb(mod, tbs, 0, nof_re, seed, 8, 0, 1), nof_prb, cp_nsymb, (C.c_uint32 * 2)(*n_prb), L_prb, 0, 0.01, 0)
+                grids.append(grid)
+                ces.append(ce)
+                want.append(np.packbits(bits))
+            cws = [(3, 18336, 3600, 0), (2, 5736, 1584, 2), (1, 328, 300, 0)]
+            m = len(cws)
+            tx = (capi.HipPdschTx * m)()
+            sbt, pays, single = [], [], []
+            for i, (mod, tbs, nof_re, rv) in enumerate(cws):
+                tx[i] = capi.HipPdschTx(capi.HipGrantTb(mod, tbs, rv, nof_re, 0x4000 + 64 * tid + i, 0, 0, 1), 1.0)
+                sbt.append(_tx_softbuffer(capi, O.cbsegm(tbs)["C"]))
+                pays.append(rng.integers(0, 256, tbs // 8).astype(np.uint8))
+                o = np.zeros(nof_re, np.complex64)
+                assert lib.srsran_hip_pdsch_encode(C.byref(tx[i]), C.byref(sbt[i][0]), O.P(pays[i]), O.P(o)) == 0
+                single.append(o)
+            for rnd in range(20):
+                sbs = [_rx_softbuffer(capi, O.cbsegm(u[3])["C"], np.int16) for u in ues]
+                datas = [np.zeros(u[3] // 8 + 16, np.uint8) for u in ues]
+                res = (capi.HipGrantRes * n)()
+                assert lib.srsran_hip_pusch_decode_multi(n, grants, (C.c_void_p * n)(*[a.ctypes.data for a in grids]), (C.c_void_p * n)(*[a.ctypes.data for a in ces]),
+                                                         (C.POINTER(capi.SoftbufferRx) * n)(*[C.pointer(s[0]) for s in sbs]),
+                                                         (C.c_void_p * n)(*[a.ctypes.data for a in datas]), res) == 0, capi.last_error()
+                for i, u in enumerate(ues):
+                    assert res[i].crc_ok == 1 and np.array_equal(datas[i][:u[3] // 8], want[i]), (tid, rnd, i)
+                outs = [np.zeros(c[2], np.complex64) for c in cws]
+                assert lib.srsran_hip_pdsch_encode_multi(m, tx, (C.POINTER(capi.SoftbufferTx) * m)(*[C.pointer(s[0]) for s in sbt]),
+                                                         (C.c_void_p * m)(*[p.ctypes.data for p in pays]), (C.c_void_p * m)(*[o.ctypes.data for o in outs])) == 0
+                for i in range(m):
+                    assert np.array_equal(outs[i].view(np.uint32), single[i].view(np.uint32)), (tid, rnd, i)
+        except BaseException as e:  # noqa: B902 -- carried to the main thread
+            errors.append((tid, repr(e)))
+
+    errors = []
+    ths = [threading.Thread(target=worker, args=(t, errors)) for t in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
